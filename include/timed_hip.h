@@ -1,0 +1,142 @@
+/*
+ * timed_hip.h — C ABI of libtimedhip.so, the MI355X (gfx950) engine behind the reference's two
+ * numeric seams.  Plain pointers and sizes only; no C++/torch types; never throws across the ABI.
+ *
+ * The reference (wells-wood-research/timed-design) has no FFI/plugin layer: the seams are Python
+ * call sites.  Each entry point below names the reference interface it replaces (file:line are
+ * relative to the reference repo).  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *   - every function returns 0 (TH_OK) or a negative TH_E* code; th_last_error() returns a
+ *     thread-local human-readable message for the last failure on the calling thread.
+ *   - the caller owns every host buffer; the library owns device buffers it allocates.
+ *   - a th_model handle is bound to one device and is NOT re-entrant; distinct handles may be
+ *     driven from distinct threads (ctypes releases the GIL).
+ *   - frames are channels-last [n, D, H, W, C], C fastest — the layout
+ *     design_utils/utils.py:519-527 (load_batch) builds and Keras consumes.
+ */
+#ifndef TIMED_HIP_H
+#define TIMED_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TH_OK 0
+#define TH_EINVAL (-1)   /* bad argument / shape / dtype                     */
+#define TH_EIO (-2)      /* pack file unreadable or malformed                */
+#define TH_EHIP (-3)     /* a HIP runtime call failed (message has details)  */
+#define TH_EUNSUP (-4)   /* layer/option outside the supported op set        */
+#define TH_ENOMEM (-5)
+#define TH_ECOMM (-6)    /* RCCL failure / librccl.so not loadable           */
+
+/* element types accepted for frames (what load_batch can hand to Model.predict,
+ * design_utils/utils.py:518-521: float64 when voxels_as_gaussian else bool) */
+#define TH_F32 0
+#define TH_F64 1
+#define TH_U8 2
+#define TH_BOOL 3
+#define TH_F16 4
+
+/* th_model_load flags */
+#define TH_LOAD_DEFAULT 0u
+#define TH_LOAD_NO_FUSE 1u      /* one kernel per Keras layer (debug / parity bisecting)          */
+#define TH_LOAD_NO_MFMA 2u      /* direct (VALU) convolution kernels only                         */
+#define TH_LOAD_KEEP_ALL 4u     /* keep every layer output materialised (th_model_fetch)          */
+
+/* th_predict* flags */
+#define TH_PREDICT_DEFAULT 0u
+#define TH_PREDICT_LOGITS 1u    /* skip the final Softmax: return its input (parity on the logits) */
+
+typedef struct th_model th_model;
+typedef struct th_comm th_comm;
+
+/* ---- library ---------------------------------------------------------------------------- */
+int th_version(void);                 /* ABI version, currently 1 */
+const char* th_last_error(void);
+int th_device_count(int* n_out);
+/* name/arch of a device, e.g. "AMD Instinct MI355X" / "gfx950" */
+int th_device_info(int device, char* name, size_t name_len, char* arch, size_t arch_len, int* cus);
+
+/* ---- model: replaces tf.keras.models.load_model(path) — predict.py:121 ------------------- */
+/* `pack_path` is a THPK0001 pack written by timed_hip/pack.py from the .h5's model_config+weights */
+int th_model_load(const char* pack_path, int device, unsigned flags, th_model** out);
+int th_model_load_mem(const void* pack, size_t nbytes, int device, unsigned flags, th_model** out);
+void th_model_free(th_model* m);
+/* input dims {D,H,W,C} (= dataset attr frame_dims, utils.py:515) and width of the output row */
+int th_model_info(const th_model* m, int dims[4], int* n_classes);
+/* algorithmic work per frame: FLOPs (2*V*k^3*Cin*Cout per conv + 2*F*out per Dense) and the
+ * executed FLOPs including tile padding; number of device launches per chunk */
+int th_model_cost(const th_model* m, double* algo_flops, double* exec_flops, int* n_steps);
+/* frames processed per internal pass (Keras' own predict() minibatch is 32 — no numeric effect) */
+int th_model_set_chunk(th_model* m, int frames_per_chunk);
+
+/* ---- forward: replaces frame_model.predict(X_batch) — predict.py:142 --------------------- */
+/* host frames [n,D,H,W,C] of `dtype` -> host probs_out [n,n_classes] fp32 (rows sum to 1) */
+int th_predict(th_model* m, const void* frames, int dtype, int64_t n, float* probs_out, unsigned flags);
+/* same with frames and probabilities already resident in this model's device memory */
+int th_predict_device(th_model* m, const void* d_frames, int dtype, int64_t n, float* d_probs, unsigned flags);
+/* copy a layer's output for the first n frames of the LAST chunk run (TH_LOAD_KEEP_ALL / unfused
+ * layers only): out is [n, D,H,W,C] or [n,F] fp32.  Debug/parity aid. */
+int th_model_fetch(th_model* m, const char* layer_name, int64_t n, float* out, int64_t out_floats);
+
+/* per-launch timing of the last th_predict_device call, HIP events on the model's stream */
+int th_model_profile(th_model* m, int enable);
+/* step i of the plan: kernel label, accumulated ms and launch count since profiling was enabled,
+ * algorithmic FLOPs and bytes per frame attributed to the step */
+int th_model_step_info(const th_model* m, int i, char* label, size_t label_len, double* ms, int64_t* launches,
+                       double* flops_per_frame, double* exec_flops_per_frame, double* bytes_per_frame);
+
+/* ---- device memory helpers (so host code needs no torch/hip-python for resident buffers) -- */
+int th_dev_alloc(int device, size_t bytes, void** d_out);
+int th_dev_free(int device, void* d);
+int th_dev_upload(int device, void* d_dst, const void* h_src, size_t bytes);
+int th_dev_download(int device, void* h_dst, const void* d_src, size_t bytes);
+int th_dev_sync(int device);
+/* fill d_frames [n,side,side,side,channels] fp32 with synthetic Gaussian-splat frames generated on
+ * the device (Philox; statistically like timed_hip.synth.synthetic_frames, not bit-identical) */
+int th_dev_synth_frames(int device, float* d_frames, int64_t n, int side, int channels, int atoms, uint64_t seed);
+
+/* ---- sampler: replaces design_utils/sampling_utils.py ------------------------------------- */
+/* apply_temp_to_probs (sampling_utils.py:139-161): q = p**(1/t), rows renormalised; fp64 */
+int th_apply_temp(const double* probs, int64_t n_res, int n_cls, double t, double* out);
+/* random_choice_prob_index (sampling_utils.py:53-90, kernel lines 81-82), n_samples draws fused:
+ *   idx[s,i] = first j with cumsum_j(q[i,:]) > r[s,i], 0 if none   (q = tempered probs, t==1: q=p)
+ * rng_mode 0: r = uniforms[s*n_res+i] supplied by the caller (e.g. np.random.rand — bit-exact
+ *             replay of the reference's MT19937 stream);
+ * rng_mode 1: r drawn on the device: rocRAND Philox4x32-10, seed, subsequence s*n_res+i;
+ * rng_mode 2: r drawn on the device from MT19937 seeded like np.random.seed(seed), consumed in the
+ *             reference's single-process order (for s: r = rand(n_res)). */
+#define TH_RNG_HOST 0
+#define TH_RNG_PHILOX 1
+#define TH_RNG_MT19937 2
+int th_sample(const double* probs, int64_t n_res, int n_cls, int64_t n_samples, double temperature,
+              int rng_mode, uint64_t seed, const double* uniforms, int32_t* idx_out);
+/* optionally also return the uniforms the device drew (r_out [n_samples,n_res], may be NULL) and
+ * residue letters (letters_out [n_samples, n_res] bytes, via cat_letters[n_cls], may be NULL) */
+/* rng_offset = uniforms already consumed from the device stream (Philox: added to the subsequence
+ * index; MT19937: doubles skipped) so successive calls continue one stream, as the reference's
+ * per-PDB loop does.  q_out (may be NULL) receives the tempered probabilities [n_res,n_cls]. */
+int th_sample_ex(const double* probs, int64_t n_res, int n_cls, int64_t n_samples, double temperature,
+                 int rng_mode, uint64_t seed, uint64_t rng_offset, const double* uniforms, int32_t* idx_out,
+                 double* r_out, const char* cat_letters, char* letters_out, double* q_out, int device);
+
+/* ---- multi-GPU reassembly (no reference counterpart: the reference is single-process) ----- */
+/* one process per GPU; rank 0 creates the id and ships it to the others out of band */
+#define TH_COMM_ID_BYTES 128
+int th_comm_unique_id(char id[TH_COMM_ID_BYTES]);
+int th_comm_init(const char id[TH_COMM_ID_BYTES], int n_ranks, int rank, int device, th_comm** out);
+void th_comm_free(th_comm* c);
+/* gather contiguous per-rank row shards [counts[r], width] fp32 (device pointers) into
+ * d_out [sum(counts), width] on `root` (RCCL send/recv over xGMI; d_out ignored elsewhere) */
+int th_comm_gather_rows(th_comm* c, const float* d_local, const int64_t* counts, int width, int root,
+                        float* d_out);
+int th_comm_barrier(th_comm* c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TIMED_HIP_H */

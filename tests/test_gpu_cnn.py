@@ -1,0 +1,125 @@
+"""Parity proper: the HIP engine, called through the C ABI, against the CPU oracle and the golden
+vectors.  Tolerance (BASELINE.json north_star): 1e-4 absolute on the logits and on the
+probabilities, identical argmax.  fp32 MFMA is an exact fmaf chain, so the observed error is
+accumulation-order noise (~1e-6)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import cnn_oracle
+from timed_hip import _lib, engine, synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+CASES = ["timed20", "timed338", "timed20_c5_bias", "timed20_bool", "densecpd20", "prodconn20", "timed_small"]
+
+
+def _build(meta, name):
+    m = next(x for x in meta if x["name"] == name)
+    cfg, weights = getattr(synth, m["builder"])(**m["kwargs"])
+    frames = synth.synthetic_frames(m["n"], **m["frame_kwargs"])
+    return cfg, weights, frames
+
+
+def _logits_oracle(cfg, weights, frames):
+    vals = cnn_oracle.forward(cfg, weights, frames, np.float32, return_all=True)
+    layers = cfg["config"]["layers"]
+    out = cfg["config"]["output_layers"][0][0]
+    last = next(l for l in layers if l["name"] == out)
+    if last["class_name"] == "Softmax":
+        return vals[last["inbound_nodes"][0][0][0]], vals[out]
+    return None, vals[out]
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("flags", [0, _lib.TH_LOAD_NO_MFMA, _lib.TH_LOAD_NO_FUSE | _lib.TH_LOAD_NO_MFMA, _lib.TH_LOAD_NO_FUSE],
+                         ids=["fused_mfma", "fused_direct", "unfused_direct", "unfused_mfma"])
+def test_forward_matches_oracle_and_golden(gpu, cnn_golden, name, flags):
+    z, meta = cnn_golden
+    cfg, weights, frames = _build(meta, name)
+    model = engine.HipFrameModel.from_keras(cfg, weights, device=gpu, flags=flags)
+    probs = model.predict(frames)
+    assert probs.dtype == np.float32 and probs.shape == z[f"{name}__torch32"].shape
+    logits_ref, probs_ref = _logits_oracle(cfg, weights, frames)
+    np.testing.assert_allclose(probs, probs_ref, atol=TOL, rtol=0)
+    np.testing.assert_allclose(probs, z[f"{name}__torch64"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(probs.sum(1), 1.0, atol=1e-5)
+    assert np.array_equal(probs.argmax(1), probs_ref.argmax(1))
+    if logits_ref is not None:
+        logits = model.predict(frames, logits=True)
+        np.testing.assert_allclose(logits, logits_ref, atol=TOL, rtol=0)
+    model.close()
+
+
+def test_input_dtypes_agree(gpu):
+    """load_batch hands float64 or bool (reference utils.py:518-521); Keras casts to fp32."""
+    cfg, weights = synth.timed_synth(20, widths=(8, 16), side=9, in_channels=5)
+    fb = synth.synthetic_frames(5, side=9, channels=5, gaussian=False, atoms=40, seed=8)
+    model = engine.HipFrameModel.from_keras(cfg, weights, device=gpu)
+    base = model.predict(fb.astype(np.float32))
+    for dt in (np.float64, np.uint8, np.bool_, np.float16):
+        assert np.array_equal(model.predict(fb.astype(dt)), base), dt
+    ref = cnn_oracle.forward(cfg, weights, fb)
+    np.testing.assert_allclose(base, ref, atol=TOL, rtol=0)
+
+
+@pytest.mark.parametrize("n,chunk", [(1, 4), (7, 4), (8, 4), (33, 16), (0, 4)])
+def test_ragged_batches_and_chunking(gpu, n, chunk):
+    """Any batch size, including a partial last chunk, a partial last frame-group and an empty batch."""
+    cfg, weights = synth.timed_synth(20, widths=(8, 16, 16), side=9, in_channels=4, bias_std=0.1)
+    frames = synth.synthetic_frames(max(n, 1), side=9, channels=4, atoms=30, seed=n)[:n]
+    model = engine.HipFrameModel.from_keras(cfg, weights, device=gpu)
+    model.set_chunk(chunk)
+    probs = model.predict(frames)
+    assert probs.shape == (n, 20)
+    if n:
+        ref = cnn_oracle.forward(cfg, weights, frames)
+        np.testing.assert_allclose(probs, ref, atol=TOL, rtol=0)
+        # frame independence: the same frame gives the same bits wherever it sits in the batch
+        again = model.predict(frames[::-1].copy())[::-1]
+        assert np.array_equal(again, probs)
+
+
+def test_bad_shape_raises(gpu):
+    cfg, weights = synth.timed_synth(20, widths=(4,), side=5, in_channels=2)
+    model = engine.HipFrameModel.from_keras(cfg, weights, device=gpu)
+    with pytest.raises(ValueError):
+        model.predict(np.zeros((2, 5, 5, 5, 3), np.float32))
+    with pytest.raises(_lib.TimedHipError):
+        engine.HipFrameModel(b"not a pack at all" * 10, device=gpu)
+
+
+def test_layerwise_outputs_match_oracle(gpu):
+    """Every layer of TIMED-synth, unfused and kept, against the oracle's per-layer tensors."""
+    cfg, weights = synth.timed_synth(20)
+    frames = synth.synthetic_frames(2, seed=77)
+    vals = cnn_oracle.forward(cfg, weights, frames, np.float32, return_all=True)
+    model = engine.HipFrameModel.from_keras(cfg, weights, device=gpu, flags=_lib.TH_LOAD_KEEP_ALL)
+    model.predict(frames)
+    for l in cfg["config"]["layers"]:
+        if l["class_name"] in ("InputLayer", "SpatialDropout3D"):
+            continue
+        want = vals[l["name"]]
+        got = model.fetch(l["name"], 2, want.shape[1:])
+        scale = max(1.0, float(np.abs(want).max()))
+        assert np.abs(got - want).max() <= 2e-5 * scale, l["name"]
+
+
+def test_full_size_properties(gpu):
+    """BASELINE config sizes without an oracle run: rows sum to 1, permutation equivariance,
+    determinism, and agreement of the fused MFMA path with the direct (VALU) path."""
+    cfg, weights = synth.timed_synth(20)
+    frames = synth.synthetic_frames(96, seed=4242)
+    fast = engine.HipFrameModel.from_keras(cfg, weights, device=gpu)
+    slow = engine.HipFrameModel.from_keras(cfg, weights, device=gpu, flags=_lib.TH_LOAD_NO_MFMA)
+    fast.set_chunk(40)
+    a = fast.predict(frames)
+    b = slow.predict(frames)
+    np.testing.assert_allclose(a.sum(1), 1.0, atol=1e-5)
+    np.testing.assert_allclose(a, b, atol=TOL, rtol=0)
+    assert np.array_equal(a.argmax(1), b.argmax(1))
+    perm = np.random.default_rng(0).permutation(96)
+    assert np.array_equal(fast.predict(frames[perm]), a[perm])
+    assert np.array_equal(fast.predict(frames), a)

@@ -1,0 +1,156 @@
+// Multi-GPU reassembly of per-chain probability maps: one process per GPU, contiguous frame shards,
+// one exchange step — an RCCL gather of [n_i, n_classes] fp32 row blocks to the root over xGMI
+// (SURVEY.md §8e).  The reference is single-process (it has no collective at all); this is the
+// piece that lets rank 0 write the .csv/.fasta exactly as reference predict.py:161-185 does.
+//
+// xGMI is point-to-point (7 direct links per GPU), so the gather is issued as grouped
+// ncclSend/ncclRecv pairs: every peer -> root transfer rides its own direct link concurrently;
+// a ring all-gather would serialise on per-link bandwidth for no benefit here.
+//
+// librccl.so is opened lazily with dlopen so that the single-GPU product (and CPU-only symbol
+// checks) never depend on it.
+#include "common.h"
+
+#include <dlfcn.h>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+typedef struct ncclComm* ncclComm_t;
+struct NcclUniqueId { char internal[128]; };
+enum { kNcclFloat32 = 7 };
+
+struct Rccl {
+    void* h = nullptr;
+    int (*GetUniqueId)(NcclUniqueId*) = nullptr;
+    int (*CommInitRank)(ncclComm_t*, int, NcclUniqueId, int) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+
+Rccl* rccl() {
+    static Rccl r;
+    static bool tried = false;
+    if (tried) return r.h ? &r : nullptr;
+    tried = true;
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* n : names) {
+        r.h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (r.h) break;
+    }
+    if (!r.h) { th_set_error("cannot dlopen librccl.so: %s", dlerror()); return nullptr; }
+#define SYM(field, name)                                                       \
+    *(void**)(&r.field) = dlsym(r.h, name);                                    \
+    if (!r.field) { th_set_error("librccl.so lacks %s", name); r.h = nullptr; return nullptr; }
+    SYM(GetUniqueId, "ncclGetUniqueId");
+    SYM(CommInitRank, "ncclCommInitRank");
+    SYM(CommDestroy, "ncclCommDestroy");
+    SYM(Send, "ncclSend");
+    SYM(Recv, "ncclRecv");
+    SYM(AllReduce, "ncclAllReduce");
+    SYM(GroupStart, "ncclGroupStart");
+    SYM(GroupEnd, "ncclGroupEnd");
+    SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    return &r;
+}
+
+#define NCCL_TRY(expr)                                                                             \
+    do {                                                                                           \
+        int _r = (expr);                                                                           \
+        if (_r != 0) { th_set_error("%s failed: %s", #expr, R->GetErrorString(_r)); return TH_ECOMM; } \
+    } while (0)
+
+}  // namespace
+
+struct th_comm {
+    ncclComm_t comm = nullptr;
+    int n_ranks = 0, rank = 0, device = 0;
+    hipStream_t stream = nullptr;
+    float* d_token = nullptr;
+};
+
+extern "C" {
+
+int th_comm_unique_id(char id[TH_COMM_ID_BYTES]) {
+    Rccl* R = rccl();
+    if (!R) return TH_ECOMM;
+    NcclUniqueId u;
+    NCCL_TRY(R->GetUniqueId(&u));
+    static_assert(sizeof u.internal == TH_COMM_ID_BYTES, "id size");
+    std::memcpy(id, u.internal, TH_COMM_ID_BYTES);
+    return TH_OK;
+}
+
+int th_comm_init(const char id[TH_COMM_ID_BYTES], int n_ranks, int rank, int device, th_comm** out) {
+    if (!id || !out || n_ranks <= 0 || rank < 0 || rank >= n_ranks) TH_FAIL(TH_EINVAL, "th_comm_init: bad argument");
+    Rccl* R = rccl();
+    if (!R) return TH_ECOMM;
+    HIP_TRY(hipSetDevice(device));
+    th_comm* c = new th_comm;
+    c->n_ranks = n_ranks; c->rank = rank; c->device = device;
+    NcclUniqueId u;
+    std::memcpy(u.internal, id, TH_COMM_ID_BYTES);
+    int r = R->CommInitRank(&c->comm, n_ranks, u, rank);
+    if (r != 0) { th_set_error("ncclCommInitRank failed: %s", R->GetErrorString(r)); delete c; return TH_ECOMM; }
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc(&c->d_token, sizeof(float));
+    if (e != hipSuccess) { th_set_error("th_comm_init: %s", hipGetErrorString(e)); th_comm_free(c); return TH_EHIP; }
+    *out = c;
+    return TH_OK;
+}
+
+void th_comm_free(th_comm* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    Rccl* R = rccl();
+    if (R && c->comm) (void)R->CommDestroy(c->comm);
+    if (c->d_token) (void)hipFree(c->d_token);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int th_comm_gather_rows(th_comm* c, const float* d_local, const int64_t* counts, int width, int root, float* d_out) {
+    if (!c || !counts || width <= 0 || root < 0 || root >= c->n_ranks) TH_FAIL(TH_EINVAL, "th_comm_gather_rows: bad argument");
+    Rccl* R = rccl();
+    if (!R) return TH_ECOMM;
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->rank == root && !d_out) TH_FAIL(TH_EINVAL, "root needs an output buffer");
+    NCCL_TRY(R->GroupStart());
+    if (c->rank == root) {
+        int64_t row = 0;
+        for (int r = 0; r < c->n_ranks; ++r) {
+            float* dst = d_out + (size_t)row * width;
+            if (r == root) {
+                if (counts[r] > 0)
+                    HIP_TRY(hipMemcpyAsync(dst, d_local, (size_t)counts[r] * width * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+            } else if (counts[r] > 0) {
+                NCCL_TRY(R->Recv(dst, (size_t)counts[r] * width, kNcclFloat32, r, c->comm, c->stream));
+            }
+            row += counts[r];
+        }
+    } else if (counts[c->rank] > 0) {
+        NCCL_TRY(R->Send(d_local, (size_t)counts[c->rank] * width, kNcclFloat32, root, c->comm, c->stream));
+    }
+    NCCL_TRY(R->GroupEnd());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return TH_OK;
+}
+
+int th_comm_barrier(th_comm* c) {
+    if (!c) TH_FAIL(TH_EINVAL, "null comm");
+    Rccl* R = rccl();
+    if (!R) return TH_ECOMM;
+    HIP_TRY(hipSetDevice(c->device));
+    NCCL_TRY(R->AllReduce(c->d_token, c->d_token, 1, kNcclFloat32, /*ncclSum*/ 0, c->comm, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return TH_OK;
+}
+
+}  // extern "C"

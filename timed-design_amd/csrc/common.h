@@ -1,0 +1,115 @@
+// Shared declarations for the timed_hip runtime (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/timed_hip.h"
+
+// ---- op / activation codes: keep in sync with timed_hip/keras_config.py ------------------
+enum : int {
+    OP_INPUT = 0, OP_CONV3D, OP_DENSE, OP_BN, OP_ACT, OP_MAXPOOL, OP_AVGPOOL, OP_GAP, OP_GMP,
+    OP_FLATTEN, OP_CONCAT, OP_ADD, OP_IDENTITY
+};
+enum : int { ACT_LINEAR = 0, ACT_RELU, ACT_ELU, ACT_SOFTMAX, ACT_SIGMOID, ACT_TANH, ACT_LEAKY };
+
+// ---- error plumbing ---------------------------------------------------------------------
+void th_set_error(const char* fmt, ...);
+#define TH_FAIL(code, ...)          \
+    do {                            \
+        th_set_error(__VA_ARGS__);  \
+        return (code);              \
+    } while (0)
+#define HIP_TRY(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) {                                                                  \
+            th_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return TH_EHIP;                                                                      \
+        }                                                                                        \
+    } while (0)
+
+// ---- device-side views --------------------------------------------------------------------
+// A channels-last activation tensor, possibly a channel slice of a wider (concat) buffer.
+// element (f, v, c) lives at p[f*fs + v*cs + coff + c], v = (z*H + y)*W + x.
+struct TView {
+    float* p = nullptr;
+    int D = 1, H = 1, W = 1, C = 0;
+    int cs = 0;      // floats between consecutive voxels (>= C)
+    int coff = 0;    // first channel of this view inside the buffer
+    int64_t fs = 0;  // floats between consecutive frames
+    int V() const { return D * H * W; }
+};
+
+#define TH_MAX_POST 4
+enum : int { POP_ACT = 1, POP_AFFINE = 2 };
+// elementwise epilogue applied to a conv/dense accumulator (after the bias), in order.
+struct PostOps {
+    int n = 0;
+    int type[TH_MAX_POST] = {0, 0, 0, 0};
+    int act[TH_MAX_POST] = {0, 0, 0, 0};
+    float alpha[TH_MAX_POST] = {0, 0, 0, 0};
+    const float* scale[TH_MAX_POST] = {nullptr, nullptr, nullptr, nullptr};  // per output channel
+    const float* shift[TH_MAX_POST] = {nullptr, nullptr, nullptr, nullptr};
+};
+// elementwise prologue applied to the conv input when it is staged (BN->ReLU->Conv chains)
+struct PreOp {
+    const float* scale = nullptr;  // per input channel (nullptr: no affine)
+    const float* shift = nullptr;
+    int act = ACT_LINEAR;
+    float alpha = 0.f;
+};
+
+// ---- generic kernels (kernels_generic.hip) -------------------------------------------------
+struct ConvGeom {
+    int kd, kh, kw, sd, sh, sw, dd, dh, dw;  // kernel, stride, dilation
+    int pz, py, px;                          // padding before (Keras 'same' rule) or 0
+};
+int launch_convert_frames(hipStream_t s, const void* src, int dtype, int64_t n, int V, int C, TView dst);
+// weights in Keras layout [kd,kh,kw,Cin,Cout]
+int launch_conv3d_direct(hipStream_t s, int64_t n, TView in, TView out, ConvGeom g, const float* w, const float* bias,
+                         PreOp pre, PostOps post);
+int launch_pool3d(hipStream_t s, int64_t n, TView in, TView out, ConvGeom g, int is_max);
+int launch_eltwise(hipStream_t s, int64_t n, TView in, TView out, PostOps ops);
+int launch_global_pool(hipStream_t s, int64_t n, TView in, TView out, int is_max);
+// dense on a contiguous [n, F] input (in.C = F, V = 1); weights [F, out]
+int launch_dense(hipStream_t s, int64_t n, TView in, TView out, const float* w, const float* bias, PostOps post);
+int launch_softmax(hipStream_t s, int64_t n, TView in, TView out);
+int launch_copy(hipStream_t s, int64_t n, TView in, TView out);
+int launch_add(hipStream_t s, int64_t n, TView a, TView b, TView out);
+int launch_synth_frames(hipStream_t s, float* d, int64_t n, int side, int channels, int atoms, uint64_t seed);
+
+// ---- MFMA implicit-GEMM convolution (conv_mfma.hip) ---------------------------------------
+struct ConvMfmaPlan {
+    int cfg = -1;            // index into the instantiated tile configurations
+    int CI = 0, CS = 0;      // input channels per staged chunk, LDS channel stride (floats)
+    int BN = 0;              // output channels per workgroup
+    int nnb = 0;             // workgroups along Cout
+    int nchunks = 0;
+    int pool = 0;            // 0 none, 1 max 2x2x2, 2 avg 2x2x2 (stride 2, valid)
+    int Dc = 0, Hc = 0, Wc = 0;   // conv-output extent that is computed (even-trimmed when pooled)
+    int FB = 1, ZB = 0, nzb = 1;  // frames / conv z-planes per workgroup, z bricks per frame
+    int Zp = 0, Hp = 0, Wp = 0;   // staged (haloed) brick extent
+    int rows_pf = 0;              // GEMM rows per frame-brick (multiple of 32)
+    int bres = 0;                 // all taps' weights resident in LDS
+    size_t lds_bytes = 0;
+    size_t tab_off = 0;           // byte offset of the row tables inside the LDS allocation
+    size_t wpk_floats = 0;        // size of the prepacked weight image
+    double exec_flops = 0;        // MFMA FLOPs actually issued per frame
+    std::string label;
+};
+// choose a tiling for this convolution; returns false when the MFMA kernel does not apply
+// (stride/dilation != 1, nothing fits in LDS, ...)
+bool conv_mfma_plan(const TView& in, const TView& out_conv, const ConvGeom& g, int Cin, int Cout, int pool,
+                    ConvMfmaPlan* plan);
+// host-side weight re-layout: Keras [kd,kh,kw,Cin,Cout] -> [nb][chunk][tap][BN][CS]
+void conv_mfma_pack_weights(const ConvMfmaPlan& p, const ConvGeom& g, int Cin, int Cout, const float* w_keras,
+                            float* dst);
+int launch_conv_mfma(hipStream_t s, int64_t n, const ConvMfmaPlan& p, TView in, TView out, ConvGeom g, int Cin,
+                     int Cout, const float* wpk, const float* bias, PreOp pre, PostOps post);
+
+// ---- sampler (sampler.hip) -----------------------------------------------------------------
+int sampler_run(int device, const double* h_probs, int64_t n_res, int n_cls, int64_t n_samples, double temperature,
+                int rng_mode, uint64_t seed, uint64_t rng_offset, const double* h_uniforms, int32_t* h_idx, double* h_r_out,
+                const char* cat_letters, char* h_letters, double* h_q_out);

@@ -1,0 +1,507 @@
+// Fused Conv3D for gfx950: implicit GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32),
+// with the Keras block around it folded in:
+//     [BN-affine -> act on the input]  ->  Conv3D(stride 1, any k, 'same'/'valid')  -> +bias
+//     -> [act / BN-affine ...]  ->  [Max/AveragePooling3D 2x2x2]  -> store at a channel offset
+// i.e. one launch per "Conv3D -> ELU -> BatchNorm (-> MaxPool)" block of TIMED (reference
+// README.md:254) and per "BN -> ReLU -> Conv -> (Concat)" step of a DenseCPD dense layer.
+//
+// GEMM view (per workgroup):  M = output voxels of a brick (FB whole frames, or ZB z-planes of one
+// frame), N = BN output channels, K = taps x Cin.  The brick's *input* voxels (+halo, zero padded =
+// Keras 'same') are staged ONCE per Cin-chunk in LDS as [voxel][CS] fp32; every tap then reads the
+// same LDS image at a wave-uniform voxel offset, so HBM/L2 sees each activation once per chunk
+// instead of k^3 times.  Weights are pre-packed on the host as [nb][chunk][tap][BN][CS] so that a
+// tap slab is one linear, coalesced copy into LDS (double buffered across taps, or fully resident
+// when small).  Both MFMA operands are fetched with ds_read_b128:
+//     lane l = (j = l&31, h = l>>5) reads 4 consecutive input channels  c = 8*kk + 4*h + t
+//     A[i=j][k=h] = act[voxel(row j)][c],  B[k=h][j] = W[co j][c]   for MFMA t = 0..3
+// (the K order inside a chunk is permuted, identically for A and B — a sum does not care).
+// fp32 MFMA is an exact fmaf chain (cdna_hip_programming.md §3), so results match a scalar
+// fp32 convolution to accumulation-order rounding.
+//
+// Row order inside a 32-row MFMA tile is chosen so the epilogue never leaves registers:
+// for pooled layers rows are grouped 8 pool-mates at a time (row = 8*pooled + mate); in the
+// 32x32 C layout (row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) a lane then holds mates 0-3 or 4-7 of
+// 4 pooled voxels, so a 2x2x2 pool is 3 max ops + one cross-half exchange.
+#include "common.h"
+#include "device_math.h"
+
+#include <algorithm>
+#include <cstring>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr size_t kLdsLimit = 160 * 1024;
+
+struct ConvMfmaArgs {
+    const float* in; int64_t in_fs; int in_cs, in_coff, Din, Hin, Win, Cin, vec_ok;
+    int kd, kh, kw, pz, py, px, ntaps;
+    int Dc, Hc, Wc;
+    int FB, ZB, nzb, Zp, Hp, Wp, rows_pf, nrows, n_mtiles;
+    int CS, nchunks, nnb, tab_off;
+    const float* wpk;
+    int Cout;
+    const float* bias;
+    PreOp pre;
+    PostOps post;
+    float* out; int64_t out_fs; int out_cs, out_coff, Ho, Wo;
+    int64_t nframes;
+};
+
+template <int WAVES, int TM, int TN, int NT, int CI, int BRES, int POOL>
+__global__ void __launch_bounds__(WAVES * 64) k_conv_mfma(const ConvMfmaArgs a) {
+    constexpr int NTHREADS = WAVES * 64;
+    constexpr int BN = NT * 32;
+    constexpr int CI4 = CI / 4;
+    constexpr int KK = CI / 8;
+    static_assert(NT % TN == 0, "NT must be a multiple of TN");
+    extern __shared__ __attribute__((aligned(16))) float4 smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int CS4 = a.CS >> 2;
+
+    // ---- workgroup -> (frame group, z brick, channel block) ---------------------------------
+    int bid = blockIdx.x;
+    const int nb = bid % a.nnb; bid /= a.nnb;
+    const int zb = bid % a.nzb; bid /= a.nzb;
+    const int64_t f0 = (int64_t)bid * a.FB;
+    const int z0 = zb * a.ZB;
+
+    // ---- LDS carve-up ---------------------------------------------------------------------------
+    const int nvox = a.FB * a.Zp * a.Hp * a.Wp;
+    float4* A4 = smem;
+    float4* B4 = A4 + (size_t)nvox * CS4;
+    const int bslab4 = BN * CS4;  // one tap's weights
+    const int nbslabs = BRES ? a.ntaps : 2;
+    int* rowvox = (int*)(reinterpret_cast<char*>(smem) + a.tab_off);
+    int* rowout = rowvox + a.nrows;
+
+    // ---- row tables: GEMM row -> staged voxel index, and -> output offset -----------------------
+    {
+        const int ZBv = min(a.ZB, a.Dc - z0);
+        for (int r = tid; r < a.nrows; r += NTHREADS) {
+            const int f = r / a.rows_pf, q = r - f * a.rows_pf;
+            const bool fok = (f0 + f) < a.nframes;
+            int vox = 0, oo = -1;
+            if (POOL == 0) {
+                const int hw = a.Hc * a.Wc;
+                if (fok && q < ZBv * hw) {
+                    const int zl = q / hw, rem = q - zl * hw, y = rem / a.Wc, x = rem - y * a.Wc;
+                    vox = ((f * a.Zp + zl) * a.Hp + y) * a.Wp + x;
+                    oo = f * (int)a.out_fs + (((z0 + zl) * a.Ho + y) * a.Wo + x) * a.out_cs;
+                }
+                rowout[r] = oo;
+            } else {
+                const int pq = q >> 3, mate = q & 7;
+                const int PH = a.Hc >> 1, PW = a.Wc >> 1;
+                if (fok && pq < (ZBv >> 1) * PH * PW) {
+                    const int pzz = pq / (PH * PW), rem = pq - pzz * (PH * PW), pyy = rem / PW, pxx = rem - pyy * PW;
+                    const int zl = 2 * pzz + (mate >> 2), y = 2 * pyy + ((mate >> 1) & 1), x = 2 * pxx + (mate & 1);
+                    vox = ((f * a.Zp + zl) * a.Hp + y) * a.Wp + x;
+                    oo = f * (int)a.out_fs + ((((z0 >> 1) + pzz) * a.Ho + pyy) * a.Wo + pxx) * a.out_cs;
+                }
+                if (mate == 0) rowout[r >> 3] = oo;
+            }
+            rowvox[r] = vox;
+        }
+    }
+
+    const int nblocks_n = NT / TN;
+    const int total_blocks = ((a.n_mtiles + TM - 1) / TM) * nblocks_n;
+    const int rounds = (total_blocks + WAVES - 1) / WAVES;
+    const float* wbase = a.wpk + (size_t)nb * a.nchunks * a.ntaps * BN * a.CS;
+    const float4* wbase4 = reinterpret_cast<const float4*>(wbase);
+
+    for (int rd = 0; rd < rounds; ++rd) {
+        const int blk = rd * WAVES + wave;
+        const bool active = blk < total_blocks;
+        const int mb = active ? blk / nblocks_n : 0;
+        const int nbw = active ? blk - mb * nblocks_n : 0;
+
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[tm][tn][i] = 0.f;
+
+        if (rd == 0) __syncthreads();  // row tables visible
+        int aidx[TM], bidx[TN];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const int mt = mb * TM + tm;
+            aidx[tm] = (mt < a.n_mtiles ? rowvox[mt * 32 + j] : 0) * CS4 + h;
+        }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) bidx[tn] = ((nbw * TN + tn) * 32 + j) * CS4 + h;
+
+        for (int ch = 0; ch < a.nchunks; ++ch) {
+            constexpr bool kLdsEpi = (TM * TN > 2);  // the LDS epilogue clobbers the staging area
+            const bool need_a = kLdsEpi || !(a.nchunks == 1 && rd > 0);
+            const bool need_b = BRES ? need_a : true;
+            __syncthreads();  // everyone is done reading the previous A image / B slabs
+            if (need_a) {
+                // ---- stage the haloed input brick for channels [ch*CI, ch*CI+CI) ------------------
+                const int nvec = nvox * CI4;
+                for (int i = tid; i < nvec; i += NTHREADS) {
+                    const int v = i / CI4, g = i - v * CI4;
+                    const int xl = v % a.Wp; int t = v / a.Wp;
+                    const int yl = t % a.Hp; t /= a.Hp;
+                    const int zl = t % a.Zp; const int f = t / a.Zp;
+                    const int zi = z0 + zl - a.pz, yi = yl - a.py, xi = xl - a.px;
+                    const int c0 = ch * CI + g * 4;
+                    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if ((f0 + f) < a.nframes && zi >= 0 && zi < a.Din && yi >= 0 && yi < a.Hin && xi >= 0 && xi < a.Win &&
+                        c0 < a.Cin) {
+                        const float* src = a.in + (f0 + f) * a.in_fs + ((int64_t)(zi * a.Hin + yi) * a.Win + xi) * a.in_cs +
+                                           a.in_coff + c0;
+                        float e[4];
+                        if (a.vec_ok && c0 + 4 <= a.Cin) {
+                            const float4 q4 = *reinterpret_cast<const float4*>(src);
+                            e[0] = q4.x; e[1] = q4.y; e[2] = q4.z; e[3] = q4.w;
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) e[k] = (c0 + k < a.Cin) ? src[k] : 0.f;
+                        }
+                        if (a.pre.scale || a.pre.act != ACT_LINEAR) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                if (c0 + k < a.Cin) {
+                                    float x = e[k];
+                                    if (a.pre.scale) x = fmaf(x, a.pre.scale[c0 + k], a.pre.shift[c0 + k]);
+                                    e[k] = th_act(x, a.pre.act, a.pre.alpha);
+                                }
+                            }
+                        }
+                        val = make_float4(e[0], e[1], e[2], e[3]);
+                    }
+                    A4[(size_t)v * CS4 + g] = val;
+                }
+            }
+            const float4* wch4 = wbase4 + (size_t)ch * a.ntaps * bslab4;
+            if (need_b) {
+                const int n4 = BRES ? a.ntaps * bslab4 : bslab4;
+                for (int i = tid; i < n4; i += NTHREADS) B4[i] = wch4[i];
+            }
+            __syncthreads();
+
+            if (BRES) {
+                if (active) {
+                    int tap = 0;
+                    for (int dz = 0; dz < a.kd; ++dz)
+                        for (int dy = 0; dy < a.kh; ++dy)
+                            for (int dx = 0; dx < a.kw; ++dx, ++tap) {
+                                const int toff = ((dz * a.Hp + dy) * a.Wp + dx) * CS4;
+                                const float4* Bt = B4 + (size_t)tap * bslab4;
+#pragma unroll
+                                for (int kk = 0; kk < KK; ++kk) {
+                                    float4 av[TM], bv[TN];
+#pragma unroll
+                                    for (int tm = 0; tm < TM; ++tm) av[tm] = A4[aidx[tm] + toff + kk * 2];
+#pragma unroll
+                                    for (int tn = 0; tn < TN; ++tn) bv[tn] = Bt[bidx[tn] + kk * 2];
+#pragma unroll
+                                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                                        for (int tn = 0; tn < TN; ++tn) {
+                                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm].x, bv[tn].x, acc[tm][tn], 0, 0, 0);
+                                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm].y, bv[tn].y, acc[tm][tn], 0, 0, 0);
+                                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm].z, bv[tn].z, acc[tm][tn], 0, 0, 0);
+                                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm].w, bv[tn].w, acc[tm][tn], 0, 0, 0);
+                                        }
+                                }
+                            }
+                }
+            } else {
+                // per-tap weight slabs, double buffered: prefetch tap+1 into registers while tap computes
+                constexpr int BPF = (BN * ((CI + 4) / 4) + NTHREADS - 1) / NTHREADS;  // float4 per thread per slab
+                int tap = 0;
+                for (int dz = 0; dz < a.kd; ++dz)
+                    for (int dy = 0; dy < a.kh; ++dy)
+                        for (int dx = 0; dx < a.kw; ++dx, ++tap) {
+                            const bool more = tap + 1 < a.ntaps;
+                            // unconditional (clamped) loads keep the prefetch registers out of scratch and
+                            // let the loads fly under this tap's MFMAs
+                            float4 pf[BPF];
+                            {
+                                const float4* nxt = wch4 + (size_t)(more ? tap + 1 : tap) * bslab4;
+#pragma unroll
+                                for (int u = 0; u < BPF; ++u) pf[u] = nxt[min(tid + u * NTHREADS, bslab4 - 1)];
+                            }
+                            if (active) {
+                                const int toff = ((dz * a.Hp + dy) * a.Wp + dx) * CS4;
+                                const float4* Bt = B4 + (size_t)(tap & 1) * bslab4;
+#pragma unroll
+                                for (int kk = 0; kk < KK; ++kk) {
+                                    float4 av[TM], bv[TN];
+#pragma unroll
+                                    for (int tm = 0; tm < TM; ++tm) av[tm] = A4[aidx[tm] + toff + kk * 2];
+#pragma unroll
+                                    for (int tn = 0; tn < TN; ++tn) bv[tn] = Bt[bidx[tn] + kk * 2];
+#pragma unroll
+                                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                                        for (int tn = 0; tn < TN; ++tn) {
+                                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm].x, bv[tn].x, acc[tm][tn], 0, 0, 0);
+                                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm].y, bv[tn].y, acc[tm][tn], 0, 0, 0);
+                                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm].z, bv[tn].z, acc[tm][tn], 0, 0, 0);
+                                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm].w, bv[tn].w, acc[tm][tn], 0, 0, 0);
+                                        }
+                                }
+                            }
+                            if (more) {
+                                float4* dstb = B4 + (size_t)((tap + 1) & 1) * bslab4;
+#pragma unroll
+                                for (int u = 0; u < BPF; ++u) {
+                                    const int i = tid + u * NTHREADS;
+                                    if (i < bslab4) dstb[i] = pf[u];
+                                }
+                                __syncthreads();
+                            }
+                        }
+            }
+        }  // chunks
+
+        // ---- epilogue: bias, activation / BN-affine chain, optional 2x2x2 pool, store ------------
+        constexpr bool REG_EPI = (TM * TN <= 2);
+        if (REG_EPI) {
+            // small per-wave tiles: finish in registers.  In the 32x32 C layout a lane holds rows
+            // (i&3) + 8*(i>>2) + 4*h, i.e. pool-mates 0-3 (h=0) or 4-7 (h=1) of 4 pooled voxels.
+            if (active) {
+                float* outb = a.out + f0 * a.out_fs + a.out_coff;
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    const int mt = mb * TM + tm;
+                    const bool mt_ok = mt < a.n_mtiles;
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) {
+                        const int co = nb * BN + (nbw * TN + tn) * 32 + j;
+                        const bool cok = co < a.Cout && mt_ok;
+                        const int cc = co < a.Cout ? co : 0;
+                        const float bv = a.bias ? a.bias[cc] : 0.f;
+                        float x[16];
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) x[i] = th_post(acc[tm][tn][i] + bv, cc, a.post);
+                        if (POOL == 0) {
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) {
+                                const int oo = cok ? rowout[mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h] : -1;
+                                if (oo >= 0) outb[oo + co] = x[i];
+                            }
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                float m;
+                                if (POOL == 1) m = fmaxf(fmaxf(x[4 * q], x[4 * q + 1]), fmaxf(x[4 * q + 2], x[4 * q + 3]));
+                                else m = (x[4 * q] + x[4 * q + 1]) + (x[4 * q + 2] + x[4 * q + 3]);
+                                const float o2 = __shfl_xor(m, 32);
+                                m = (POOL == 1) ? fmaxf(m, o2) : (m + o2) * 0.125f;
+                                const int oo = cok ? rowout[mt * 4 + q] : -1;
+                                if (oo >= 0 && (q >> 1) == h) outb[oo + co] = m;
+                            }
+                        }
+                    }
+                }
+            }
+        } else {
+            // big per-wave tiles: each 32x32 accumulator tile goes registers -> a per-wave LDS scratch
+            // tile -> a compact runtime loop (keeps the activation switch out of a 128-way unroll, so
+            // the accumulators stay in VGPRs).  The scratch aliases the A/B staging area (hence the
+            // barrier, and hence A is re-staged every round in this mode).
+            __syncthreads();
+            if (active) {
+                float* outb = a.out + f0 * a.out_fs + a.out_coff;
+                float* T = reinterpret_cast<float*>(smem) + wave * (32 * 33);
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) {
+                        const int mt = mb * TM + tm;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) T[((i & 3) + 8 * (i >> 2) + 4 * h) * 33 + j] = acc[tm][tn][i];
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        const int co = nb * BN + (nbw * TN + tn) * 32 + j;
+                        const bool cok = co < a.Cout && mt < a.n_mtiles;
+                        const int cc = co < a.Cout ? co : 0;
+                        const float bv = a.bias ? a.bias[cc] : 0.f;
+                        if (POOL == 0) {
+#pragma unroll 1
+                            for (int k = 0; k < 16; ++k) {
+                                const int row = 2 * k + h;
+                                const int oo = cok ? rowout[mt * 32 + row] : -1;
+                                const float x = th_post(T[row * 33 + j] + bv, cc, a.post);
+                                if (oo >= 0) outb[oo + co] = x;
+                            }
+                        } else {
+#pragma unroll 1
+                            for (int k = 0; k < 2; ++k) {
+                                const int q = 2 * k + h;
+                                const int oo = cok ? rowout[mt * 4 + q] : -1;
+                                float m = (POOL == 1) ? -INFINITY : 0.f;
+#pragma unroll 1
+                                for (int e = 0; e < 8; ++e) {
+                                    const float x = th_post(T[(8 * q + e) * 33 + j] + bv, cc, a.post);
+                                    m = (POOL == 1) ? fmaxf(m, x) : m + x;
+                                }
+                                if (POOL == 2) m *= 0.125f;
+                                if (oo >= 0) outb[oo + co] = m;
+                            }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+            }
+        }
+    }  // rounds
+}
+
+// ---- tile configurations ------------------------------------------------------------------------
+struct CfgDesc { int WAVES, TM, TN, NT, CI, BRES; };
+const CfgDesc kCfgs[] = {
+    {8, 1, 1, 1, 8, 1},   // 0: Cin<=8,  Cout<=32  (first layer: everything resident, many rounds)
+    {8, 4, 2, 2, 16, 0},  // 1: BN=64
+    {8, 4, 2, 4, 16, 0},  // 2: BN=128
+    {8, 2, 1, 1, 16, 0},  // 3: BN=32
+    {8, 2, 2, 2, 8, 1},   // 4: Cin<=8, BN=64
+};
+constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+
+typedef void (*ConvKernel)(const ConvMfmaArgs);
+#define CFG_ROW(W, TM, TN, NT, CI, BR) \
+    { k_conv_mfma<W, TM, TN, NT, CI, BR, 0>, k_conv_mfma<W, TM, TN, NT, CI, BR, 1>, k_conv_mfma<W, TM, TN, NT, CI, BR, 2> }
+const ConvKernel kKernels[kNumCfgs][3] = {
+    CFG_ROW(8, 1, 1, 1, 8, 1), CFG_ROW(8, 4, 2, 2, 16, 0), CFG_ROW(8, 4, 2, 4, 16, 0),
+    CFG_ROW(8, 2, 1, 1, 16, 0), CFG_ROW(8, 2, 2, 2, 8, 1),
+};
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+}  // namespace
+
+bool conv_mfma_plan(const TView& in, const TView& oc, const ConvGeom& g, int Cin, int Cout, int pool, ConvMfmaPlan* p) {
+    if (g.sd != 1 || g.sh != 1 || g.sw != 1 || g.dd != 1 || g.dh != 1 || g.dw != 1) return false;
+    if (pool && (oc.D < 2 || oc.H < 2 || oc.W < 2)) return false;
+    int cfg;
+    if (Cin <= 8) cfg = Cout <= 32 ? 0 : (Cout <= 64 ? 4 : 2);
+    else cfg = Cout <= 32 ? 3 : (Cout <= 64 ? 1 : 2);
+    const CfgDesc& c = kCfgs[cfg];
+    p->cfg = cfg;
+    p->CI = c.CI;
+    p->CS = c.CI == 8 ? 8 : c.CI + 4;  // CI=8: unpadded (2-way ds_read_b128 conflict, but the brick fits)
+    p->BN = c.NT * 32;
+    p->nnb = (Cout + p->BN - 1) / p->BN;
+    p->nchunks = (Cin + c.CI - 1) / c.CI;
+    p->pool = pool;
+    p->bres = c.BRES;
+    p->Dc = pool ? (oc.D / 2) * 2 : oc.D;
+    p->Hc = pool ? (oc.H / 2) * 2 : oc.H;
+    p->Wc = pool ? (oc.W / 2) * 2 : oc.W;
+    p->Hp = p->Hc + g.kh - 1;
+    p->Wp = p->Wc + g.kw - 1;
+    const int ntaps = g.kd * g.kh * g.kw;
+    const size_t bbytes = (size_t)(c.BRES ? ntaps : 2) * p->BN * p->CS * 4;
+    auto rows_for = [&](int zb) {
+        const int r = pool ? 8 * ((zb / 2) * (p->Hc / 2) * (p->Wc / 2)) : zb * p->Hc * p->Wc;
+        return round_up(r, 32);
+    };
+    auto lds_for = [&](int fb, int zb) {
+        const size_t nvox = (size_t)fb * (zb + g.kd - 1) * p->Hp * p->Wp;
+        const int nrows = fb * rows_for(zb);
+        return std::max(nvox * p->CS * 4 + bbytes, (size_t)c.WAVES * 32 * 33 * 4) + (size_t)nrows * 4 +
+               (size_t)(pool ? nrows / 8 : nrows) * 4;
+    };
+    const int max_mt = c.WAVES * c.TM * c.TN / c.NT;  // m-tiles one round covers
+    int FB = 0, ZB = 0;
+    if (lds_for(1, p->Dc) <= kLdsLimit) {
+        ZB = p->Dc;
+        FB = 1;
+        while (FB < 16 && lds_for(FB + 1, ZB) <= kLdsLimit &&
+               (p->nchunks == 1 || (FB + 1) * rows_for(ZB) / 32 <= max_mt))
+            ++FB;
+    } else {
+        FB = 1;
+        const int step = pool ? 2 : 1;
+        for (int zb = p->Dc - step; zb >= step; zb -= step)
+            if (lds_for(1, zb) <= kLdsLimit) { ZB = zb; break; }
+        if (ZB == 0) return false;
+        // prefer a brick height that divides the extent evenly if one exists at >= 60% of the max
+        for (int zb = ZB; zb >= step && zb * 10 >= ZB * 6; zb -= step)
+            if (p->Dc % zb == 0) { ZB = zb; break; }
+    }
+    p->FB = FB;
+    p->ZB = ZB;
+    p->nzb = (p->Dc + ZB - 1) / ZB;
+    p->Zp = ZB + g.kd - 1;
+    p->rows_pf = rows_for(ZB);
+    p->lds_bytes = lds_for(FB, ZB);
+    p->tab_off = p->lds_bytes - ((size_t)FB * p->rows_pf * 4 + (size_t)(pool ? FB * p->rows_pf / 8 : FB * p->rows_pf) * 4);
+    p->wpk_floats = (size_t)p->nnb * p->nchunks * ntaps * p->BN * p->CS;
+    const double rows_exec = (double)p->nzb * p->rows_pf;  // per frame
+    p->exec_flops = 2.0 * rows_exec * (double)(p->nnb * p->BN) * (double)(p->nchunks * c.CI) * ntaps;
+    if ((int64_t)FB * oc.fs > 0x7fffffffLL) return false;
+    char buf[160];
+    snprintf(buf, sizeof buf, "conv_mfma<w%d,%dx%d,nt%d,ci%d,%s,pool%d> FB%d ZB%d/%d rows%d lds%zuK", c.WAVES, c.TM,
+             c.TN, c.NT, c.CI, c.BRES ? "res" : "dbuf", pool, FB, ZB, p->Dc, p->rows_pf, p->lds_bytes / 1024);
+    p->label = buf;
+    return true;
+}
+
+void conv_mfma_pack_weights(const ConvMfmaPlan& p, const ConvGeom& g, int Cin, int Cout, const float* w, float* dst) {
+    const int ntaps = g.kd * g.kh * g.kw;
+    std::memset(dst, 0, p.wpk_floats * sizeof(float));
+    for (int nb = 0; nb < p.nnb; ++nb)
+        for (int ch = 0; ch < p.nchunks; ++ch)
+            for (int t = 0; t < ntaps; ++t) {
+                float* slab = dst + (((size_t)nb * p.nchunks + ch) * ntaps + t) * p.BN * p.CS;
+                for (int n = 0; n < p.BN; ++n) {
+                    const int co = nb * p.BN + n;
+                    if (co >= Cout) break;
+                    for (int c = 0; c < p.CI; ++c) {
+                        const int ci = ch * p.CI + c;
+                        if (ci >= Cin) break;
+                        slab[(size_t)n * p.CS + c] = w[((size_t)t * Cin + ci) * Cout + co];
+                    }
+                }
+            }
+}
+
+int launch_conv_mfma(hipStream_t s, int64_t n, const ConvMfmaPlan& p, TView in, TView out, ConvGeom g, int Cin, int Cout,
+                     const float* wpk, const float* bias, PreOp pre, PostOps post) {
+    if (p.cfg < 0 || p.cfg >= kNumCfgs) TH_FAIL(TH_EINVAL, "conv_mfma: bad plan");
+    const CfgDesc& c = kCfgs[p.cfg];
+    ConvMfmaArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.in = in.p; a.in_fs = in.fs; a.in_cs = in.cs; a.in_coff = in.coff;
+    a.Din = in.D; a.Hin = in.H; a.Win = in.W; a.Cin = Cin;
+    a.vec_ok = (in.cs % 4 == 0 && in.coff % 4 == 0 && in.fs % 4 == 0 && ((uintptr_t)in.p % 16) == 0) ? 1 : 0;
+    a.kd = g.kd; a.kh = g.kh; a.kw = g.kw; a.pz = g.pz; a.py = g.py; a.px = g.px; a.ntaps = g.kd * g.kh * g.kw;
+    a.Dc = p.Dc; a.Hc = p.Hc; a.Wc = p.Wc;
+    a.FB = p.FB; a.ZB = p.ZB; a.nzb = p.nzb; a.Zp = p.Zp; a.Hp = p.Hp; a.Wp = p.Wp;
+    a.rows_pf = p.rows_pf; a.nrows = p.FB * p.rows_pf; a.n_mtiles = a.nrows / 32;
+    a.CS = p.CS; a.nchunks = p.nchunks; a.nnb = p.nnb;
+    a.tab_off = (int)p.tab_off;
+    a.wpk = wpk; a.Cout = Cout; a.bias = bias; a.pre = pre; a.post = post;
+    a.out = out.p; a.out_fs = out.fs; a.out_cs = out.cs; a.out_coff = out.coff; a.Ho = out.H; a.Wo = out.W;
+    a.nframes = n;
+    const int64_t groups = (n + p.FB - 1) / p.FB;
+    const int64_t grid = groups * p.nzb * p.nnb;
+    if (grid > 0x7fffffffLL) TH_FAIL(TH_EINVAL, "conv_mfma: grid too large");
+    ConvKernel k = kKernels[p.cfg][p.pool];
+    static bool attr_set[kNumCfgs][3] = {};
+    if (!attr_set[p.cfg][p.pool]) {
+        HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+        attr_set[p.cfg][p.pool] = true;
+    }
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(c.WAVES * 64), p.lds_bytes, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) TH_FAIL(TH_EHIP, "conv_mfma launch failed: %s (%s)", hipGetErrorString(e), p.label.c_str());
+    return TH_OK;
+}

@@ -1,0 +1,28 @@
+// Elementwise device helpers shared by every kernel: Keras activations and the fused epilogue.
+#pragma once
+#include "common.h"
+
+// Keras semantics: ELU x>0 ? x : alpha*(exp(x)-1); LeakyReLU x>0 ? x : alpha*x.
+__device__ __forceinline__ float th_act(float x, int act, float alpha) {
+    switch (act) {
+        case ACT_RELU: return fmaxf(x, 0.f);
+        case ACT_ELU: return x > 0.f ? x : alpha * expm1f(x);
+        case ACT_LEAKY: return x > 0.f ? x : alpha * x;
+        case ACT_SIGMOID: return 1.f / (1.f + expf(-x));
+        case ACT_TANH: return tanhf(x);
+        default: return x;
+    }
+}
+
+// epilogue: ordered list of activation / per-channel affine (folded BatchNormalization:
+// scale = gamma*rsqrt(var+eps), shift = beta - mean*scale — the form tf.nn.batch_normalization uses)
+__device__ __forceinline__ float th_post(float x, int c, const PostOps& ops) {
+#pragma unroll
+    for (int i = 0; i < TH_MAX_POST; ++i) {
+        if (i < ops.n) {
+            if (ops.type[i] == POP_ACT) x = th_act(x, ops.act[i], ops.alpha[i]);
+            else x = fmaf(x, ops.scale[i][c], ops.shift[i][c]);
+        }
+    }
+    return x;
+}

@@ -1,0 +1,915 @@
+// Model runtime: pack loader, layer-graph planner (fusion + zero-copy concat), executor, C ABI.
+//
+// Replaces, behind include/timed_hip.h:
+//   tf.keras.models.load_model(path)      reference predict.py:121  -> th_model_load
+//   frame_model.predict(X_batch)          reference predict.py:142  -> th_predict / th_predict_device
+// The reference hands the network to TensorFlow as an opaque graph; here the graph is planned once
+// at load time into a short list of launches:
+//   * Conv3D + bias + {ELU/ReLU, BatchNorm}* + MaxPool/AvgPool(2) -> ONE fused MFMA kernel
+//     (conv_mfma.hip); a BN->ReLU in FRONT of a conv (DenseNet/DenseCPD pre-activation) becomes the
+//     kernel's staging prologue;
+//   * Concatenate is zero-copy: producers write straight into a channel slice of the concat
+//     buffer (nested concats collapse into one buffer per dense block);
+//   * everything else runs on the generic kernels (kernels_generic.hip).
+// Activations live in HBM as channels-last fp32, one arena per tensor sized for `chunk` frames.
+#include "common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+
+// ---- errors ---------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+void th_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+namespace {
+
+// ---- pack (mirrors timed_hip/pack.py) -----------------------------------------------------------
+constexpr int kMaxIn = 8, kNIp = 24, kNFp = 8, kNW = 8, kNameBytes = 56;
+struct PackNode {
+    uint32_t op, n_in;
+    int32_t in[kMaxIn];
+    int32_t ip[kNIp];
+    float fp[kNFp];
+    int32_t w[kNW];
+    char name[kNameBytes];
+};
+static_assert(sizeof(PackNode) == 256, "pack node record must be 256 bytes");
+struct PackHeader {
+    char magic[8];
+    uint32_t n_nodes, n_blobs, output_node, reserved;
+};
+
+struct Node {
+    int op = 0;
+    std::vector<int> in;
+    int ip[kNIp] = {0};
+    float fp[kNFp] = {0};
+    int w[kNW] = {-1, -1, -1, -1, -1, -1, -1, -1};
+    std::string name;
+    int D = 1, H = 1, W = 1, C = 0;  // output shape (rank-1 outputs: D=H=W=1, C=F)
+    int rank = 0;
+    std::vector<int> consumers;
+    // planning state
+    int absorbed_by = -1;  // node index of the step that computes this node as part of its chain
+    int buf = -1, cs = 0, coff = 0;  // storage of this node's output (if materialised)
+    bool materialised = false;
+};
+
+struct Buffer {
+    int64_t floats_per_frame = 0;
+    float* dev = nullptr;
+};
+
+struct Step {
+    std::string label;
+    std::function<int(hipStream_t, int64_t)> run;
+    double flops = 0, exec_flops = 0, bytes = 0;  // per frame
+    double ms = 0;
+    int64_t launches = 0;
+    int out_node = -1;
+    bool is_final_softmax = false;
+};
+
+inline void keras_same_pad(int n, int k, int s, int d, int* before) {
+    const int ke = (k - 1) * d + 1;
+    const int out = (n + s - 1) / s;
+    int total = (out - 1) * s + ke - n;
+    if (total < 0) total = 0;
+    *before = total / 2;
+}
+
+}  // namespace
+
+struct th_model {
+    int device = 0;
+    unsigned flags = 0;
+    hipStream_t stream = nullptr;
+    std::vector<Node> nodes;
+    std::vector<const float*> blob_host;  // into `pack`
+    std::vector<size_t> blob_count;
+    std::vector<char> pack;
+    std::vector<float*> dev_allocs;  // weights & derived tensors (freed at th_model_free)
+    std::vector<Buffer> bufs;
+    std::vector<Step> steps;
+    int input_node = -1, output_node = -1, logits_node = -1;
+    int in_dims[4] = {0, 0, 0, 0};
+    int n_classes = 0;
+    int chunk = 1024;
+    int chunk_alloc = 0;
+    bool profiling = false;
+    double algo_flops = 0, exec_flops = 0;
+    void* d_in_stage = nullptr;   // host->device staging for th_predict
+    size_t in_stage_bytes = 0;
+    float* d_out_stage = nullptr;
+    size_t out_stage_floats = 0;
+    int64_t last_n = 0;
+
+    TView view(int node) const {
+        const Node& nd = nodes[node];
+        TView v;
+        const Buffer& b = bufs[nd.buf];
+        v.p = b.dev;
+        v.D = nd.D; v.H = nd.H; v.W = nd.W; v.C = nd.C;
+        v.cs = nd.cs; v.coff = nd.coff; v.fs = b.floats_per_frame;
+        return v;
+    }
+};
+
+namespace {
+
+int upload(th_model* m, const float* h, size_t count, float** out) {
+    float* d = nullptr;
+    HIP_TRY(hipMalloc(&d, (count ? count : 1) * sizeof(float)));
+    m->dev_allocs.push_back(d);
+    if (count) HIP_TRY(hipMemcpy(d, h, count * sizeof(float), hipMemcpyHostToDevice));
+    *out = d;
+    return TH_OK;
+}
+
+int parse_pack(th_model* m) {
+    const std::vector<char>& p = m->pack;
+    if (p.size() < sizeof(PackHeader)) TH_FAIL(TH_EIO, "pack too small (%zu bytes)", p.size());
+    PackHeader h;
+    std::memcpy(&h, p.data(), sizeof h);
+    if (std::memcmp(h.magic, "THPK0001", 8) != 0) TH_FAIL(TH_EIO, "bad pack magic");
+    size_t pos = sizeof(PackHeader);
+    if (p.size() < pos + (size_t)h.n_nodes * sizeof(PackNode) + (size_t)h.n_blobs * 16) TH_FAIL(TH_EIO, "truncated pack");
+    m->nodes.resize(h.n_nodes);
+    for (uint32_t i = 0; i < h.n_nodes; ++i) {
+        PackNode pn;
+        std::memcpy(&pn, p.data() + pos, sizeof pn);
+        pos += sizeof pn;
+        Node& n = m->nodes[i];
+        n.op = (int)pn.op;
+        if (pn.n_in > (uint32_t)kMaxIn) TH_FAIL(TH_EIO, "node %u: too many inputs", i);
+        for (uint32_t k = 0; k < pn.n_in; ++k) {
+            if (pn.in[k] < 0 || pn.in[k] >= (int)i) TH_FAIL(TH_EIO, "node %u: input %d is not topologically earlier", i, pn.in[k]);
+            n.in.push_back(pn.in[k]);
+        }
+        std::memcpy(n.ip, pn.ip, sizeof n.ip);
+        std::memcpy(n.fp, pn.fp, sizeof n.fp);
+        std::memcpy(n.w, pn.w, sizeof n.w);
+        pn.name[kNameBytes - 1] = 0;
+        n.name = pn.name;
+        n.rank = pn.ip[kNIp - 5];
+        const int* shp = &pn.ip[kNIp - 4];
+        if (n.rank == 4) { n.D = shp[0]; n.H = shp[1]; n.W = shp[2]; n.C = shp[3]; }
+        else if (n.rank == 1) { n.D = n.H = n.W = 1; n.C = shp[0]; }
+        else TH_FAIL(TH_EUNSUP, "node %s: output rank %d not supported", n.name.c_str(), n.rank);
+        if (n.C <= 0 || n.D <= 0 || n.H <= 0 || n.W <= 0) TH_FAIL(TH_EIO, "node %s: bad shape", n.name.c_str());
+    }
+    std::vector<std::pair<uint64_t, uint64_t>> table(h.n_blobs);
+    for (uint32_t i = 0; i < h.n_blobs; ++i) {
+        std::memcpy(&table[i].first, p.data() + pos, 8);
+        std::memcpy(&table[i].second, p.data() + pos + 8, 8);
+        pos += 16;
+    }
+    pos = (pos + 15) / 16 * 16;
+    const size_t data_floats = (p.size() - pos) / 4;
+    for (auto& t : table) {
+        if (t.first + t.second > data_floats) TH_FAIL(TH_EIO, "blob outside pack data");
+        m->blob_host.push_back(reinterpret_cast<const float*>(p.data() + pos) + t.first);
+        m->blob_count.push_back((size_t)t.second);
+    }
+    if (h.output_node >= h.n_nodes) TH_FAIL(TH_EIO, "bad output node");
+    m->output_node = (int)h.output_node;
+    for (size_t i = 0; i < m->nodes.size(); ++i) {
+        for (int s : m->nodes[i].in) m->nodes[s].consumers.push_back((int)i);
+        for (int k = 0; k < kNW; ++k)
+            if (m->nodes[i].w[k] >= (int)m->blob_host.size()) TH_FAIL(TH_EIO, "node %zu: blob index out of range", i);
+        if (m->nodes[i].op == OP_INPUT) {
+            if (m->input_node >= 0) TH_FAIL(TH_EUNSUP, "more than one model input");
+            m->input_node = (int)i;
+        }
+    }
+    if (m->input_node < 0) TH_FAIL(TH_EIO, "no input node");
+    const Node& in = m->nodes[m->input_node];
+    if (in.rank != 4) TH_FAIL(TH_EUNSUP, "input must be rank 4 (D,H,W,C)");
+    m->in_dims[0] = in.D; m->in_dims[1] = in.H; m->in_dims[2] = in.W; m->in_dims[3] = in.C;
+    const Node& on = m->nodes[m->output_node];
+    if (on.rank != 1) TH_FAIL(TH_EUNSUP, "model output must be a vector per frame (got rank %d)", on.rank);
+    m->n_classes = on.C;
+    return TH_OK;
+}
+
+bool is_elementwise(const Node& n) {
+    return (n.op == OP_ACT && n.ip[0] != ACT_SOFTMAX) || n.op == OP_BN;
+}
+
+// fold BatchNormalization into scale/shift device vectors
+int bn_affine(th_model* m, const Node& bn, const float** scale, const float** shift) {
+    const int C = bn.ip[0];
+    const float eps = bn.fp[0];
+    auto blob = [&](int k) -> const float* { return bn.w[k] >= 0 ? m->blob_host[bn.w[k]] : nullptr; };
+    const float *g = blob(0), *b = blob(1), *mu = blob(2), *var = blob(3);
+    if (!mu || !var) TH_FAIL(TH_EIO, "%s: missing moving statistics", bn.name.c_str());
+    for (int k = 0; k < 4; ++k)
+        if (bn.w[k] >= 0 && (int)m->blob_count[bn.w[k]] != C) TH_FAIL(TH_EIO, "%s: BN vector length", bn.name.c_str());
+    std::vector<float> sc(C), sh(C);
+    for (int c = 0; c < C; ++c) {
+        const float inv = (g ? g[c] : 1.f) / std::sqrt(var[c] + eps);
+        sc[c] = inv;
+        sh[c] = (b ? b[c] : 0.f) - mu[c] * inv;
+    }
+    float *dsc, *dsh;
+    int rc;
+    if ((rc = upload(m, sc.data(), C, &dsc)) || (rc = upload(m, sh.data(), C, &dsh))) return rc;
+    *scale = dsc;
+    *shift = dsh;
+    return TH_OK;
+}
+
+int add_post(th_model* m, PostOps* po, const Node& n) {
+    if (po->n >= TH_MAX_POST) return 1;
+    const int i = po->n;
+    if (n.op == OP_BN) {
+        po->type[i] = POP_AFFINE;
+        int rc = bn_affine(m, n, &po->scale[i], &po->shift[i]);
+        if (rc) return rc;
+    } else {
+        po->type[i] = POP_ACT;
+        po->act[i] = n.ip[0];
+        po->alpha[i] = n.fp[0];
+    }
+    po->n++;
+    return TH_OK;
+}
+
+struct ConvFusion {
+    int src = -1;            // node whose output the conv reads (after absorbing a BN/act prologue)
+    std::vector<int> pre;    // prologue nodes absorbed (in graph order)
+    std::vector<int> post;   // epilogue nodes absorbed (in graph order)
+    int pool = -1;           // pool node absorbed
+    int last = -1;           // node whose tensor the step produces
+};
+
+int plan(th_model* m) {
+    std::vector<Node>& N = m->nodes;
+    const bool fuse = !(m->flags & (TH_LOAD_NO_FUSE | TH_LOAD_KEEP_ALL));
+    const bool use_mfma = !(m->flags & TH_LOAD_NO_MFMA);
+    const int nn = (int)N.size();
+
+    // ---------------- pass 1: fusion decisions (symbolic) ----------------------------------------
+    std::map<int, ConvFusion> fus;
+    std::map<int, ConvMfmaPlan> mplans;
+    auto geom_of = [&](const Node& c, const Node& in) {
+        ConvGeom g{};
+        g.kd = c.ip[0]; g.kh = c.ip[1]; g.kw = c.ip[2]; g.sd = c.ip[3]; g.sh = c.ip[4]; g.sw = c.ip[5];
+        g.dd = c.ip[6]; g.dh = c.ip[7]; g.dw = c.ip[8];
+        g.pz = g.py = g.px = 0;
+        if (c.ip[9]) {
+            keras_same_pad(in.D, g.kd, g.sd, g.dd, &g.pz);
+            keras_same_pad(in.H, g.kh, g.sh, g.dh, &g.py);
+            keras_same_pad(in.W, g.kw, g.sw, g.dw, &g.px);
+        }
+        return g;
+    };
+    for (int i = 0; i < nn; ++i) {
+        Node& n = N[i];
+        if (n.absorbed_by >= 0) continue;
+        if (n.op != OP_CONV3D && n.op != OP_DENSE) continue;
+        ConvFusion f;
+        f.src = n.in[0];
+        f.last = i;
+        if (fuse) {
+            if (n.op == OP_CONV3D) {
+                // prologue: [BN] -> [act] directly in front, each consumed only by this chain
+                int x = f.src;
+                std::vector<int> pre;
+                if (N[x].absorbed_by < 0 && N[x].op == OP_ACT && N[x].ip[0] != ACT_SOFTMAX && N[x].consumers.size() == 1) {
+                    pre.push_back(x);
+                    x = N[x].in[0];
+                }
+                if (N[x].absorbed_by < 0 && N[x].op == OP_BN && N[x].consumers.size() == 1 &&
+                    (pre.empty() || N[pre.back()].in[0] == x)) {
+                    pre.push_back(x);
+                    x = N[x].in[0];
+                }
+                if (!pre.empty()) {
+                    std::reverse(pre.begin(), pre.end());
+                    f.pre = pre;
+                    f.src = x;
+                }
+            }
+            // epilogue: elementwise chain with single consumers
+            int cur = i;
+            int npost = (n.op == OP_CONV3D ? n.ip[13] : n.ip[3]) != ACT_LINEAR ? 1 : 0;
+            while (N[cur].consumers.size() == 1 && cur != m->output_node) {
+                const int nx = N[cur].consumers[0];
+                if (!is_elementwise(N[nx]) || npost >= TH_MAX_POST) break;
+                f.post.push_back(nx);
+                ++npost;
+                cur = nx;
+            }
+            f.last = cur;
+            if (n.op == OP_CONV3D && N[cur].consumers.size() == 1 && cur != m->output_node) {
+                const Node& pl = N[N[cur].consumers[0]];
+                if ((pl.op == OP_MAXPOOL || pl.op == OP_AVGPOOL) && pl.ip[0] == 2 && pl.ip[1] == 2 && pl.ip[2] == 2 &&
+                    pl.ip[3] == 2 && pl.ip[4] == 2 && pl.ip[5] == 2 && pl.ip[6] == 0)
+                    f.pool = N[cur].consumers[0];
+            }
+        }
+        if (n.op == OP_CONV3D) {
+            const Node& src = N[f.src];
+            ConvGeom g = geom_of(n, src);
+            TView iv; iv.D = src.D; iv.H = src.H; iv.W = src.W; iv.C = src.C;
+            TView ov; ov.D = n.D; ov.H = n.H; ov.W = n.W; ov.C = n.C; ov.fs = (int64_t)n.D * n.H * n.W * n.C;
+            ConvMfmaPlan mp;
+            bool ok = false;
+            if (use_mfma) {
+                if (f.pool >= 0) {
+                    ok = conv_mfma_plan(iv, ov, g, src.C, n.C, N[f.pool].op == OP_MAXPOOL ? 1 : 2, &mp);
+                    if (!ok) f.pool = -1;
+                }
+                if (!ok) ok = conv_mfma_plan(iv, ov, g, src.C, n.C, 0, &mp);
+            } else {
+                f.pool = -1;
+            }
+            if (ok) mplans[i] = mp;
+            else f.pool = -1;
+        }
+        if (f.pool >= 0) f.last = f.pool;
+        for (int x : f.pre) N[x].absorbed_by = i;
+        for (int x : f.post) N[x].absorbed_by = i;
+        if (f.pool >= 0) N[f.pool].absorbed_by = i;
+        if (f.last != i) n.absorbed_by = i;  // the conv's own raw output is never materialised
+        fus[i] = f;
+    }
+    // which node outputs exist in memory
+    for (int i = 0; i < nn; ++i) N[i].materialised = N[i].absorbed_by < 0;
+    for (auto& kv : fus) N[kv.second.last].materialised = true;
+
+    // ---------------- pass 2: storage (zero-copy concat, flatten aliasing) -----------------------
+    auto new_buffer = [&](int64_t fpf) {
+        Buffer b;
+        b.floats_per_frame = fpf;
+        m->bufs.push_back(b);
+        return (int)m->bufs.size() - 1;
+    };
+    std::vector<char> concat_copy(nn * kMaxIn, 0);  // input k of concat i needs an explicit copy
+    for (int i = nn - 1; i >= 0; --i) {
+        Node& n = N[i];
+        if (n.op != OP_CONCAT) continue;
+        if (n.buf < 0) {
+            n.cs = n.C; n.coff = 0;
+            n.buf = new_buffer((int64_t)n.D * n.H * n.W * n.cs);
+        }
+        int off = 0;
+        for (size_t k = 0; k < n.in.size(); ++k) {
+            Node& a = N[n.in[k]];
+            const bool can_alias = fuse && a.buf < 0 && a.materialised && a.op != OP_INPUT && a.op != OP_FLATTEN &&
+                                   a.op != OP_IDENTITY;
+            if (can_alias) {
+                a.buf = n.buf; a.cs = n.cs; a.coff = n.coff + off;
+            } else {
+                concat_copy[i * kMaxIn + k] = 1;
+            }
+            off += a.C;
+        }
+    }
+    for (int i = 0; i < nn; ++i) {
+        Node& n = N[i];
+        if (!n.materialised || n.buf >= 0) continue;
+        if ((n.op == OP_FLATTEN || n.op == OP_IDENTITY)) {
+            const Node& a = N[n.in[0]];
+            if (a.cs == a.C && a.coff == 0) {  // contiguous: pure reinterpretation
+                n.buf = a.buf; n.cs = n.C; n.coff = 0;
+                if (n.op == OP_IDENTITY) { n.cs = a.cs; }
+                continue;
+            }
+        }
+        n.cs = n.C; n.coff = 0;
+        if (n.op == OP_INPUT) {
+            bool all_conv = !n.consumers.empty();
+            for (int c : n.consumers) if (N[c].op != OP_CONV3D) all_conv = false;
+            if (all_conv && fuse) n.cs = (n.C + 3) / 4 * 4;  // 16-byte voxel rows for the conv staging loads
+        }
+        n.buf = new_buffer((int64_t)n.D * n.H * n.W * n.cs);
+    }
+
+    // ---------------- pass 3: emit steps ----------------------------------------------------------
+    auto V = [&](int node) { return m->view(node); };  // NOTE: device pointers are bound at run time
+    auto add_step = [&](Step s) { m->steps.push_back(std::move(s)); };
+    th_model* M = m;
+    for (int i = 0; i < nn; ++i) {
+        Node& n = N[i];
+        const bool emits = fus.count(i) || n.absorbed_by < 0;
+        if (!emits) continue;
+        Step st;
+        st.out_node = i;
+        switch (n.op) {
+            case OP_INPUT: {
+                // the convert step is issued by predict() itself (it needs the caller's pointer/dtype)
+                continue;
+            }
+            case OP_CONV3D:
+            case OP_DENSE: {
+                const ConvFusion& f = fus[i];
+                st.out_node = f.last;
+                PostOps po;
+                PreOp pre;
+                int rc;
+                const int own_act = n.op == OP_CONV3D ? n.ip[13] : n.ip[3];
+                bool split_softmax = false;
+                if (own_act == ACT_SOFTMAX) split_softmax = true;
+                else if (own_act != ACT_LINEAR) { po.type[0] = POP_ACT; po.act[0] = own_act; po.alpha[0] = n.fp[0]; po.n = 1; }
+                for (int x : f.post) if ((rc = add_post(M, &po, N[x]))) return rc < 0 ? rc : TH_EUNSUP;
+                for (int x : f.pre) {
+                    if (N[x].op == OP_BN) { if ((rc = bn_affine(M, N[x], &pre.scale, &pre.shift))) return rc; }
+                    else { pre.act = N[x].ip[0]; pre.alpha = N[x].fp[0]; }
+                }
+                const float* hw = n.w[0] >= 0 ? M->blob_host[n.w[0]] : nullptr;
+                if (!hw) TH_FAIL(TH_EIO, "%s: missing kernel", n.name.c_str());
+                float* dbias = nullptr;
+                const bool use_bias = (n.op == OP_CONV3D ? n.ip[12] : n.ip[2]) != 0;
+                if (use_bias) {
+                    if (n.w[1] < 0) TH_FAIL(TH_EIO, "%s: missing bias", n.name.c_str());
+                    if ((rc = upload(M, M->blob_host[n.w[1]], M->blob_count[n.w[1]], &dbias))) return rc;
+                }
+                const int src = f.src, dst = f.last;
+                if (n.op == OP_CONV3D) {
+                    const Node& sn = N[src];
+                    const ConvGeom g = geom_of(n, sn);
+                    const int Cin = sn.C, Cout = n.C;
+                    const size_t wcount = (size_t)g.kd * g.kh * g.kw * Cin * Cout;
+                    if (M->blob_count[n.w[0]] != wcount) TH_FAIL(TH_EIO, "%s: kernel size mismatch", n.name.c_str());
+                    st.flops = 2.0 * n.D * n.H * n.W * (double)g.kd * g.kh * g.kw * Cin * Cout;
+                    st.bytes = 4.0 * ((double)sn.D * sn.H * sn.W * Cin + (double)N[dst].D * N[dst].H * N[dst].W * N[dst].C);
+                    if (mplans.count(i)) {
+                        const ConvMfmaPlan mp = mplans[i];
+                        std::vector<float> packed(mp.wpk_floats);
+                        conv_mfma_pack_weights(mp, g, Cin, Cout, hw, packed.data());
+                        float* dw;
+                        if ((rc = upload(M, packed.data(), packed.size(), &dw))) return rc;
+                        st.exec_flops = mp.exec_flops;
+                        st.label = n.name + ": " + mp.label;
+                        st.run = [=](hipStream_t s, int64_t cnt) {
+                            return launch_conv_mfma(s, cnt, mp, M->view(src), M->view(dst), g, Cin, Cout, dw, dbias, pre, po);
+                        };
+                    } else {
+                        float* dw;
+                        if ((rc = upload(M, hw, wcount, &dw))) return rc;
+                        st.exec_flops = st.flops;
+                        st.label = n.name + ": conv3d_direct";
+                        st.run = [=](hipStream_t s, int64_t cnt) {
+                            TView iv = M->view(src);
+                            return launch_conv3d_direct(s, cnt, iv, M->view(dst), g, dw, dbias, pre, po);
+                        };
+                    }
+                } else {
+                    const Node& sn = N[src];
+                    if (sn.cs != sn.C || sn.coff != 0 || sn.D * sn.H * sn.W != 1)
+                        TH_FAIL(TH_EUNSUP, "%s: Dense needs a contiguous vector input", n.name.c_str());
+                    const int F = sn.C, O = n.C;
+                    if (M->blob_count[n.w[0]] != (size_t)F * O) TH_FAIL(TH_EIO, "%s: kernel size mismatch", n.name.c_str());
+                    float* dw;
+                    if ((rc = upload(M, hw, (size_t)F * O, &dw))) return rc;
+                    st.flops = st.exec_flops = 2.0 * F * O;
+                    st.bytes = 4.0 * (F + O);
+                    st.label = n.name + ": dense";
+                    st.run = [=](hipStream_t s, int64_t cnt) { return launch_dense(s, cnt, M->view(src), M->view(dst), dw, dbias, po); };
+                }
+                add_step(st);
+                if (split_softmax) {
+                    Step sm;
+                    sm.out_node = dst;
+                    sm.label = n.name + ": softmax (layer activation)";
+                    sm.is_final_softmax = dst == M->output_node;
+                    sm.run = [=](hipStream_t s, int64_t cnt) { return launch_softmax(s, cnt, M->view(dst), M->view(dst)); };
+                    add_step(sm);
+                    if (sm.is_final_softmax) M->logits_node = dst;
+                }
+                continue;
+            }
+            case OP_BN:
+            case OP_ACT: {
+                const int src = n.in[0];
+                if (n.op == OP_ACT && n.ip[0] == ACT_SOFTMAX) {
+                    st.label = n.name + ": softmax";
+                    st.is_final_softmax = i == M->output_node;
+                    if (st.is_final_softmax) M->logits_node = src;
+                    st.run = [=](hipStream_t s, int64_t cnt) { return launch_softmax(s, cnt, M->view(src), M->view(i)); };
+                } else {
+                    PostOps po;
+                    int rc = add_post(M, &po, n);
+                    if (rc) return rc < 0 ? rc : TH_EUNSUP;
+                    st.label = n.name + (n.op == OP_BN ? ": batchnorm" : ": activation");
+                    st.run = [=](hipStream_t s, int64_t cnt) { return launch_eltwise(s, cnt, M->view(src), M->view(i), po); };
+                }
+                st.bytes = 8.0 * n.D * n.H * n.W * n.C;
+                break;
+            }
+            case OP_MAXPOOL:
+            case OP_AVGPOOL: {
+                const int src = n.in[0];
+                const Node& sn = N[src];
+                ConvGeom g{};
+                g.kd = n.ip[0]; g.kh = n.ip[1]; g.kw = n.ip[2]; g.sd = n.ip[3]; g.sh = n.ip[4]; g.sw = n.ip[5];
+                g.dd = g.dh = g.dw = 1;
+                if (n.ip[6]) {
+                    keras_same_pad(sn.D, g.kd, g.sd, 1, &g.pz);
+                    keras_same_pad(sn.H, g.kh, g.sh, 1, &g.py);
+                    keras_same_pad(sn.W, g.kw, g.sw, 1, &g.px);
+                }
+                const int is_max = n.op == OP_MAXPOOL;
+                st.label = n.name + (is_max ? ": maxpool3d" : ": avgpool3d");
+                st.bytes = 4.0 * ((double)sn.D * sn.H * sn.W * sn.C + (double)n.D * n.H * n.W * n.C);
+                st.run = [=](hipStream_t s, int64_t cnt) { return launch_pool3d(s, cnt, M->view(src), M->view(i), g, is_max); };
+                break;
+            }
+            case OP_GAP:
+            case OP_GMP: {
+                const int src = n.in[0];
+                const int is_max = n.op == OP_GMP;
+                st.label = n.name + (is_max ? ": global_max_pool" : ": global_avg_pool");
+                st.bytes = 4.0 * N[src].D * N[src].H * N[src].W * N[src].C;
+                st.run = [=](hipStream_t s, int64_t cnt) { return launch_global_pool(s, cnt, M->view(src), M->view(i), is_max); };
+                break;
+            }
+            case OP_FLATTEN:
+            case OP_IDENTITY: {
+                const int src = n.in[0];
+                if (n.buf == N[src].buf && n.coff == 0) continue;  // alias, nothing to do
+                // gather a channel-sliced tensor into a dense [V*C] vector
+                st.label = n.name + ": flatten(copy)";
+                st.run = [=](hipStream_t s, int64_t cnt) {
+                    TView o = M->view(src);  // same shape, destination is dense
+                    o.p = M->bufs[M->nodes[i].buf].dev; o.cs = o.C; o.coff = 0; o.fs = M->bufs[M->nodes[i].buf].floats_per_frame;
+                    return launch_copy(s, cnt, M->view(src), o);
+                };
+                break;
+            }
+            case OP_CONCAT: {
+                int off = 0;
+                bool any = false;
+                for (size_t k = 0; k < n.in.size(); ++k) {
+                    const int src = n.in[k];
+                    const int o = off;
+                    off += N[src].C;
+                    if (!concat_copy[i * kMaxIn + k]) continue;
+                    any = true;
+                    Step cs;
+                    cs.out_node = i;
+                    cs.label = n.name + ": concat(copy " + N[src].name + ")";
+                    cs.bytes = 8.0 * N[src].D * N[src].H * N[src].W * N[src].C;
+                    cs.run = [=](hipStream_t s, int64_t cnt) {
+                        TView d = M->view(i);
+                        d.coff += o;
+                        d.C = M->nodes[src].C;
+                        return launch_copy(s, cnt, M->view(src), d);
+                    };
+                    add_step(cs);
+                }
+                (void)any;
+                continue;
+            }
+            case OP_ADD: {
+                if (n.in.size() < 2) TH_FAIL(TH_EUNSUP, "%s: Add needs >= 2 inputs", n.name.c_str());
+                for (size_t k = 1; k < n.in.size(); ++k) {
+                    Step as;
+                    as.out_node = i;
+                    as.label = n.name + ": add";
+                    const int a = k == 1 ? n.in[0] : i, b = n.in[k];
+                    as.bytes = 12.0 * n.D * n.H * n.W * n.C;
+                    as.run = [=](hipStream_t s, int64_t cnt) { return launch_add(s, cnt, M->view(a), M->view(b), M->view(i)); };
+                    add_step(as);
+                }
+                continue;
+            }
+            default:
+                TH_FAIL(TH_EUNSUP, "node %s: op %d not supported", n.name.c_str(), n.op);
+        }
+        add_step(st);
+    }
+    for (const Step& s : m->steps) { m->algo_flops += s.flops; m->exec_flops += s.exec_flops; }
+    (void)V;
+    return TH_OK;
+}
+
+int ensure_buffers(th_model* m) {
+    if (m->chunk_alloc >= m->chunk) return TH_OK;
+    for (Buffer& b : m->bufs) {
+        if (b.dev) { HIP_TRY(hipFree(b.dev)); b.dev = nullptr; }
+    }
+    for (Buffer& b : m->bufs) {
+        const size_t bytes = (size_t)b.floats_per_frame * m->chunk * sizeof(float) + 256;
+        HIP_TRY(hipMalloc(&b.dev, bytes));
+        // channel-padding lanes of the input arena and unused concat lanes must hold finite values
+        HIP_TRY(hipMemsetAsync(b.dev, 0, bytes, m->stream));
+    }
+    m->chunk_alloc = m->chunk;
+    return TH_OK;
+}
+
+size_t dtype_size(int dt) {
+    switch (dt) {
+        case TH_F32: return 4;
+        case TH_F64: return 8;
+        case TH_U8: case TH_BOOL: return 1;
+        case TH_F16: return 2;
+        default: return 0;
+    }
+}
+
+int run_device(th_model* m, const void* d_frames, int dtype, int64_t n, float* d_probs, unsigned flags) {
+    const size_t esz = dtype_size(dtype);
+    if (!esz) TH_FAIL(TH_EINVAL, "unknown frame dtype %d", dtype);
+    if (n < 0) TH_FAIL(TH_EINVAL, "negative frame count");
+    HIP_TRY(hipSetDevice(m->device));
+    int rc = ensure_buffers(m);
+    if (rc) return rc;
+    const bool logits = (flags & TH_PREDICT_LOGITS) != 0;
+    if (logits && m->logits_node < 0) TH_FAIL(TH_EINVAL, "model does not end in a Softmax: no logits to return");
+    const Node& in = m->nodes[m->input_node];
+    const int Vin = in.D * in.H * in.W;
+    const size_t frame_bytes = (size_t)Vin * in.C * esz;
+    const int out_node = logits ? m->logits_node : m->output_node;
+    std::vector<hipEvent_t> evs;
+    std::vector<int> ev_step;
+    for (int64_t off = 0; off < n; off += m->chunk) {
+        const int64_t cnt = std::min<int64_t>(m->chunk, n - off);
+        rc = launch_convert_frames(m->stream, (const char*)d_frames + (size_t)off * frame_bytes, dtype, cnt, Vin, in.C,
+                                   m->view(m->input_node));
+        if (rc) return rc;
+        for (size_t si = 0; si < m->steps.size(); ++si) {
+            Step& st = m->steps[si];
+            if (logits && st.is_final_softmax) continue;
+            if (m->profiling) {
+                hipEvent_t e0;
+                HIP_TRY(hipEventCreate(&e0));
+                HIP_TRY(hipEventRecord(e0, m->stream));
+                evs.push_back(e0);
+            }
+            rc = st.run(m->stream, cnt);
+            if (rc) return rc;
+            if (m->profiling) {
+                hipEvent_t e1;
+                HIP_TRY(hipEventCreate(&e1));
+                HIP_TRY(hipEventRecord(e1, m->stream));
+                evs.push_back(e1);
+                ev_step.push_back((int)si);
+            }
+        }
+        TView o;
+        o.p = d_probs + (size_t)off * m->nodes[out_node].C;
+        o.C = o.cs = m->nodes[out_node].C;
+        o.fs = o.C;
+        rc = launch_copy(m->stream, cnt, m->view(out_node), o);
+        if (rc) return rc;
+        m->last_n = cnt;
+    }
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    for (size_t k = 0; k < ev_step.size(); ++k) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, evs[2 * k], evs[2 * k + 1]));
+        m->steps[ev_step[k]].ms += ms;
+        m->steps[ev_step[k]].launches += 1;
+    }
+    for (hipEvent_t e : evs) (void)hipEventDestroy(e);
+    return TH_OK;
+}
+
+int load_common(th_model* m) {
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    int rc = parse_pack(m);
+    if (rc) return rc;
+    return plan(m);
+}
+
+}  // namespace
+
+// =================================== C ABI =======================================================
+extern "C" {
+
+int th_version(void) { return 1; }
+const char* th_last_error(void) { return g_err; }
+
+int th_device_count(int* n_out) {
+    if (!n_out) TH_FAIL(TH_EINVAL, "null argument");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *n_out = 0; TH_FAIL(TH_EHIP, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *n_out = n;
+    return TH_OK;
+}
+
+int th_device_info(int device, char* name, size_t name_len, char* arch, size_t arch_len, int* cus) {
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, device));
+    if (name && name_len) snprintf(name, name_len, "%s", p.name);
+    if (arch && arch_len) snprintf(arch, arch_len, "%s", p.gcnArchName);
+    if (cus) *cus = p.multiProcessorCount;
+    return TH_OK;
+}
+
+int th_model_load_mem(const void* pack, size_t nbytes, int device, unsigned flags, th_model** out) {
+    if (!pack || !out) TH_FAIL(TH_EINVAL, "null argument");
+    std::unique_ptr<th_model> m(new th_model);
+    m->device = device;
+    m->flags = flags;
+    m->pack.assign((const char*)pack, (const char*)pack + nbytes);
+    int rc = load_common(m.get());
+    if (rc) { th_model_free(m.release()); return rc; }
+    *out = m.release();
+    return TH_OK;
+}
+
+int th_model_load(const char* pack_path, int device, unsigned flags, th_model** out) {
+    if (!pack_path || !out) TH_FAIL(TH_EINVAL, "null argument");
+    FILE* f = fopen(pack_path, "rb");
+    if (!f) TH_FAIL(TH_EIO, "cannot open %s", pack_path);
+    fseek(f, 0, SEEK_END);
+    long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    std::vector<char> buf(sz > 0 ? (size_t)sz : 0);
+    const size_t got = sz > 0 ? fread(buf.data(), 1, (size_t)sz, f) : 0;
+    fclose(f);
+    if ((long)got != sz) TH_FAIL(TH_EIO, "short read on %s", pack_path);
+    return th_model_load_mem(buf.data(), buf.size(), device, flags, out);
+}
+
+void th_model_free(th_model* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    for (float* p : m->dev_allocs) (void)hipFree(p);
+    for (Buffer& b : m->bufs) if (b.dev) (void)hipFree(b.dev);
+    if (m->d_in_stage) (void)hipFree(m->d_in_stage);
+    if (m->d_out_stage) (void)hipFree(m->d_out_stage);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+}
+
+int th_model_info(const th_model* m, int dims[4], int* n_classes) {
+    if (!m) TH_FAIL(TH_EINVAL, "null model");
+    if (dims) std::memcpy(dims, m->in_dims, sizeof m->in_dims);
+    if (n_classes) *n_classes = m->n_classes;
+    return TH_OK;
+}
+
+int th_model_cost(const th_model* m, double* algo_flops, double* exec_flops, int* n_steps) {
+    if (!m) TH_FAIL(TH_EINVAL, "null model");
+    if (algo_flops) *algo_flops = m->algo_flops;
+    if (exec_flops) *exec_flops = m->exec_flops;
+    if (n_steps) *n_steps = (int)m->steps.size();
+    return TH_OK;
+}
+
+int th_model_set_chunk(th_model* m, int frames_per_chunk) {
+    if (!m || frames_per_chunk <= 0) TH_FAIL(TH_EINVAL, "bad chunk size");
+    m->chunk = frames_per_chunk;
+    return TH_OK;
+}
+
+int th_predict_device(th_model* m, const void* d_frames, int dtype, int64_t n, float* d_probs, unsigned flags) {
+    if (!m || (n > 0 && (!d_frames || !d_probs))) TH_FAIL(TH_EINVAL, "null argument");
+    return run_device(m, d_frames, dtype, n, d_probs, flags);
+}
+
+int th_predict(th_model* m, const void* frames, int dtype, int64_t n, float* probs_out, unsigned flags) {
+    if (!m || (n > 0 && (!frames || !probs_out))) TH_FAIL(TH_EINVAL, "null argument");
+    const size_t esz = dtype_size(dtype);
+    if (!esz) TH_FAIL(TH_EINVAL, "unknown frame dtype %d", dtype);
+    HIP_TRY(hipSetDevice(m->device));
+    const Node& in = m->nodes[m->input_node];
+    const size_t frame_bytes = (size_t)in.D * in.H * in.W * in.C * esz;
+    const bool logits = (flags & TH_PREDICT_LOGITS) != 0;
+    if (logits && m->logits_node < 0) TH_FAIL(TH_EINVAL, "model does not end in a Softmax: no logits to return");
+    const int width = logits ? m->nodes[m->logits_node].C : m->n_classes;
+    // stage one chunk at a time so host memory of any size streams through a bounded device buffer
+    const size_t need_in = frame_bytes * (size_t)m->chunk;
+    if (m->in_stage_bytes < need_in) {
+        if (m->d_in_stage) HIP_TRY(hipFree(m->d_in_stage));
+        HIP_TRY(hipMalloc(&m->d_in_stage, need_in));
+        m->in_stage_bytes = need_in;
+    }
+    const size_t need_out = (size_t)width * m->chunk;
+    if (m->out_stage_floats < need_out) {
+        if (m->d_out_stage) HIP_TRY(hipFree(m->d_out_stage));
+        HIP_TRY(hipMalloc(&m->d_out_stage, need_out * sizeof(float)));
+        m->out_stage_floats = need_out;
+    }
+    for (int64_t off = 0; off < n; off += m->chunk) {
+        const int64_t cnt = std::min<int64_t>(m->chunk, n - off);
+        HIP_TRY(hipMemcpy(m->d_in_stage, (const char*)frames + (size_t)off * frame_bytes, (size_t)cnt * frame_bytes,
+                          hipMemcpyHostToDevice));
+        int rc = run_device(m, m->d_in_stage, dtype, cnt, m->d_out_stage, flags);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpy(probs_out + (size_t)off * width, m->d_out_stage, (size_t)cnt * width * sizeof(float),
+                          hipMemcpyDeviceToHost));
+    }
+    return TH_OK;
+}
+
+int th_model_fetch(th_model* m, const char* layer_name, int64_t n, float* out, int64_t out_floats) {
+    if (!m || !layer_name || !out) TH_FAIL(TH_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(m->device));
+    for (size_t i = 0; i < m->nodes.size(); ++i) {
+        const Node& nd = m->nodes[i];
+        if (nd.name != layer_name) continue;
+        if (!nd.materialised || nd.buf < 0) TH_FAIL(TH_EINVAL, "layer %s is fused away (load with TH_LOAD_KEEP_ALL)", layer_name);
+        if (n > m->last_n) TH_FAIL(TH_EINVAL, "only %lld frames in the last chunk", (long long)m->last_n);
+        const int64_t per = (int64_t)nd.D * nd.H * nd.W * nd.C;
+        if (out_floats < n * per) TH_FAIL(TH_EINVAL, "output buffer too small (%lld < %lld)", (long long)out_floats, (long long)(n * per));
+        float* d = nullptr;
+        HIP_TRY(hipMalloc(&d, (size_t)(n * per) * sizeof(float) + 16));
+        TView o;
+        o.p = d; o.D = nd.D; o.H = nd.H; o.W = nd.W; o.C = o.cs = nd.C; o.fs = per;
+        int rc = launch_copy(m->stream, n, m->view((int)i), o);
+        if (!rc) {
+            hipError_t e = hipStreamSynchronize(m->stream);
+            if (e == hipSuccess) e = hipMemcpy(out, d, (size_t)(n * per) * sizeof(float), hipMemcpyDeviceToHost);
+            if (e != hipSuccess) { th_set_error("fetch copy failed: %s", hipGetErrorString(e)); rc = TH_EHIP; }
+        }
+        (void)hipFree(d);
+        return rc;
+    }
+    TH_FAIL(TH_EINVAL, "no layer named %s", layer_name);
+}
+
+int th_model_profile(th_model* m, int enable) {
+    if (!m) TH_FAIL(TH_EINVAL, "null model");
+    m->profiling = enable != 0;
+    for (Step& s : m->steps) { s.ms = 0; s.launches = 0; }
+    return TH_OK;
+}
+
+int th_model_step_info(const th_model* m, int i, char* label, size_t label_len, double* ms, int64_t* launches,
+                       double* flops_per_frame, double* exec_flops_per_frame, double* bytes_per_frame) {
+    if (!m || i < 0 || i >= (int)m->steps.size()) TH_FAIL(TH_EINVAL, "bad step index");
+    const Step& s = m->steps[i];
+    if (label && label_len) snprintf(label, label_len, "%s", s.label.c_str());
+    if (ms) *ms = s.ms;
+    if (launches) *launches = s.launches;
+    if (flops_per_frame) *flops_per_frame = s.flops;
+    if (exec_flops_per_frame) *exec_flops_per_frame = s.exec_flops;
+    if (bytes_per_frame) *bytes_per_frame = s.bytes;
+    return TH_OK;
+}
+
+// ---- device memory helpers ---------------------------------------------------------------------
+int th_dev_alloc(int device, size_t bytes, void** d_out) {
+    if (!d_out) TH_FAIL(TH_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMalloc(d_out, bytes ? bytes : 1));
+    return TH_OK;
+}
+int th_dev_free(int device, void* d) {
+    HIP_TRY(hipSetDevice(device));
+    if (d) HIP_TRY(hipFree(d));
+    return TH_OK;
+}
+int th_dev_upload(int device, void* d_dst, const void* h_src, size_t bytes) {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+    return TH_OK;
+}
+int th_dev_download(int device, void* h_dst, const void* d_src, size_t bytes) {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return TH_OK;
+}
+int th_dev_sync(int device) {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipDeviceSynchronize());
+    return TH_OK;
+}
+int th_dev_synth_frames(int device, float* d_frames, int64_t n, int side, int channels, int atoms, uint64_t seed) {
+    if (!d_frames || n < 0 || side <= 0 || channels <= 0 || atoms < 0) TH_FAIL(TH_EINVAL, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    int rc = launch_synth_frames(nullptr, d_frames, n, side, channels, atoms, seed);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    return TH_OK;
+}
+
+// ---- sampler -----------------------------------------------------------------------------------
+int th_apply_temp(const double* probs, int64_t n_res, int n_cls, double t, double* out) {
+    if (!out) TH_FAIL(TH_EINVAL, "null argument");
+    return sampler_run(0, probs, n_res, n_cls, 0, t, TH_RNG_PHILOX, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, out);
+}
+int th_sample(const double* probs, int64_t n_res, int n_cls, int64_t n_samples, double temperature, int rng_mode,
+              uint64_t seed, const double* uniforms, int32_t* idx_out) {
+    if (!idx_out) TH_FAIL(TH_EINVAL, "null argument");
+    return sampler_run(0, probs, n_res, n_cls, n_samples, temperature, rng_mode, seed, 0, uniforms, idx_out, nullptr,
+                       nullptr, nullptr, nullptr);
+}
+int th_sample_ex(const double* probs, int64_t n_res, int n_cls, int64_t n_samples, double temperature, int rng_mode,
+                 uint64_t seed, uint64_t rng_offset, const double* uniforms, int32_t* idx_out, double* r_out,
+                 const char* cat_letters, char* letters_out, double* q_out, int device) {
+    return sampler_run(device, probs, n_res, n_cls, n_samples, temperature, rng_mode, seed, rng_offset, uniforms, idx_out,
+                       r_out, cat_letters, letters_out, q_out);
+}
+
+}  // extern "C"

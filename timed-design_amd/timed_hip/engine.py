@@ -1,0 +1,171 @@
+"""HipFrameModel — drop-in for the Keras model object at the reference's CNN seam.
+
+    reference predict.py:121   frame_model = tf.keras.models.load_model(Path(m))
+    reference predict.py:142   y_pred_batch = frame_model.predict(X_batch)
+
+``HipFrameModel.load(path)`` accepts a ``.pack`` (THPK0001) or, when an HDF5 reader is available,
+a Keras ``.h5``; ``predict(X)`` takes the same ``X[B,D,H,W,C]`` ndarray ``load_batch`` builds
+(float64 when voxels_as_gaussian, bool otherwise — reference design_utils/utils.py:518-521; any of
+float32/float64/float16/uint8/bool is accepted) and returns a NEW float32 ``[B, n_classes]`` array,
+exactly like Keras.  Errors surface as Python exceptions.  All arithmetic happens in the HIP
+library; there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, List, Optional
+
+import numpy as np
+
+from . import _lib, keras_config, pack
+
+_DTYPES = {
+    np.dtype(np.float32): _lib.TH_F32, np.dtype(np.float64): _lib.TH_F64, np.dtype(np.uint8): _lib.TH_U8,
+    np.dtype(np.bool_): _lib.TH_BOOL, np.dtype(np.float16): _lib.TH_F16,
+}
+
+
+class HipFrameModel:
+    def __init__(self, pack_bytes: bytes, device: int = 0, flags: int = _lib.TH_LOAD_DEFAULT, name: str = "model"):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        self.device = device
+        self.name = name
+        buf = (C.c_char * len(pack_bytes)).from_buffer_copy(pack_bytes)
+        _lib.check(self._lib.th_model_load_mem(buf, len(pack_bytes), device, flags, C.byref(self._h)))
+        dims = (C.c_int * 4)()
+        ncls = C.c_int()
+        _lib.check(self._lib.th_model_info(self._h, C.byref(dims), C.byref(ncls)))
+        self.input_shape = tuple(dims)
+        self.n_classes = ncls.value
+        self.device_name, self.device_arch, self.device_cus = _lib.device_info(device)
+
+    # ---- constructors -----------------------------------------------------------------------
+    @classmethod
+    def from_keras(cls, model_config, weights: Dict[str, list], device: int = 0, flags: int = 0, name: str = "model"):
+        return cls(pack.keras_to_pack(model_config, weights), device=device, flags=flags, name=name)
+
+    @classmethod
+    def load(cls, path, device: int = 0, flags: int = 0):
+        path = os.fspath(path)
+        stem = os.path.splitext(os.path.basename(path))[0]
+        with open(path, "rb") as f:
+            head = f.read(8)
+        if head == pack.MAGIC:
+            with open(path, "rb") as f:
+                return cls(f.read(), device=device, flags=flags, name=stem)
+        if head == b"\x89HDF\r\n\x1a\n":
+            from . import h5model  # Keras .h5 -> (model_config, weights); pure-Python HDF5 reader
+            cfg, weights = h5model.read_keras_h5(path)
+            return cls.from_keras(cfg, weights, device=device, flags=flags, name=stem)
+        raise ValueError(f"{path}: neither a THPK0001 pack nor an HDF5 (.h5) Keras model")
+
+    # ---- Keras-compatible surface --------------------------------------------------------------
+    def predict(self, X, batch_size: Optional[int] = None, verbose=0, logits: bool = False, **_ignored) -> np.ndarray:
+        """X[B,D,H,W,C] -> float32 [B,n_classes].  ``batch_size``/``verbose`` are accepted for
+        signature compatibility with ``Model.predict``; chunking is internal."""
+        X = np.asarray(X)
+        if X.ndim != 5 or tuple(X.shape[1:]) != self.input_shape:
+            raise ValueError(f"expected frames of shape (B, {', '.join(map(str, self.input_shape))}), got {X.shape}")
+        dt = _DTYPES.get(X.dtype)
+        if dt is None:
+            X = X.astype(np.float32)
+            dt = _lib.TH_F32
+        X = np.ascontiguousarray(X)
+        n = X.shape[0]
+        width = self.logits_width if logits else self.n_classes
+        out = np.empty((n, width), dtype=np.float32)
+        if n:
+            _lib.check(self._lib.th_predict(self._h, X.ctypes.data, dt, n, out.ctypes.data,
+                                            _lib.TH_PREDICT_LOGITS if logits else 0))
+        return out
+
+    __call__ = predict
+
+    @property
+    def logits_width(self) -> int:
+        return self.n_classes
+
+    def predict_device(self, d_frames: int, n: int, d_probs: int, dtype: int = _lib.TH_F32, logits: bool = False):
+        """Frames and outputs already resident in device memory (raw device addresses as ints)."""
+        _lib.check(self._lib.th_predict_device(self._h, C.c_void_p(d_frames), dtype, n, C.c_void_p(d_probs),
+                                               _lib.TH_PREDICT_LOGITS if logits else 0))
+
+    # ---- introspection / tuning ----------------------------------------------------------------
+    def set_chunk(self, frames: int):
+        _lib.check(self._lib.th_model_set_chunk(self._h, int(frames)))
+
+    def cost(self):
+        a, e, n = C.c_double(), C.c_double(), C.c_int()
+        _lib.check(self._lib.th_model_cost(self._h, C.byref(a), C.byref(e), C.byref(n)))
+        return dict(algo_flops=a.value, exec_flops=e.value, n_steps=n.value)
+
+    def profile(self, enable: bool = True):
+        _lib.check(self._lib.th_model_profile(self._h, int(enable)))
+
+    def steps(self) -> List[dict]:
+        out = []
+        for i in range(self.cost()["n_steps"]):
+            label = C.create_string_buffer(256)
+            ms, fl, ef, by = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+            ln = C.c_int64()
+            _lib.check(self._lib.th_model_step_info(self._h, i, label, 256, C.byref(ms), C.byref(ln), C.byref(fl),
+                                                    C.byref(ef), C.byref(by)))
+            out.append(dict(label=label.value.decode(), ms=ms.value, launches=ln.value, flops=fl.value,
+                            exec_flops=ef.value, bytes=by.value))
+        return out
+
+    def fetch(self, layer_name: str, n: int, shape) -> np.ndarray:
+        out = np.empty((n, *shape), dtype=np.float32)
+        _lib.check(self._lib.th_model_fetch(self._h, layer_name.encode(), n, out.ctypes.data, out.size))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.th_model_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceBuffer:
+    """Raw device allocation through the C ABI (bench / multi-GPU plumbing; no torch needed)."""
+
+    def __init__(self, nbytes: int, device: int = 0):
+        self._lib = _lib.load()
+        self.device, self.nbytes = device, int(nbytes)
+        p = C.c_void_p()
+        _lib.check(self._lib.th_dev_alloc(device, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, arr: np.ndarray, offset: int = 0):
+        arr = np.ascontiguousarray(arr)
+        assert offset + arr.nbytes <= self.nbytes
+        _lib.check(self._lib.th_dev_upload(self.device, C.c_void_p(self.ptr + offset), arr.ctypes.data, arr.nbytes))
+
+    def download(self, shape, dtype, offset: int = 0) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        assert offset + out.nbytes <= self.nbytes
+        _lib.check(self._lib.th_dev_download(self.device, out.ctypes.data, C.c_void_p(self.ptr + offset), out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            self._lib.th_dev_free(self.device, C.c_void_p(self.ptr))
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def load_model(path, device: int = 0) -> HipFrameModel:
+    """Name-compatible with ``tf.keras.models.load_model`` (reference predict.py:121)."""
+    return HipFrameModel.load(path, device=device)
