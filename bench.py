@@ -1,0 +1,204 @@
+#!/usr/bin/env python
+"""bench.py — residue frames/s of the TIMED forward pass on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A *step* is one pass of the hot path over the whole per-GPU job: BASELINE.json configs[1],
+"TIMED 21x21x21x6, 100k synthetic frames, 1x MI355X" — 100 000 fp32 frames already resident in HBM
+(generated on the device, 22.2 GB), through th_predict_device (include/timed_hip.h), probabilities
+left in HBM.  With N > 1 every rank runs the same job on its own GPU (weak scaling, frames are
+independent) and each step ends with the one real exchange of the path: an RCCL gather of the
+[100k, n_classes] fp32 shards to rank 0 (th_comm_gather_rows).  torch is used only for the
+process-group barrier / max-reduce the driver contract asks for (gloo, CPU tensors).
+
+The JSON line carries, besides the contract fields:
+  roofline      the dominant kernel (largest share of device time), timed live with HIP events on the
+                model's stream inside the timed region: algorithmic FLOPs per launch / mean launch
+                duration vs the dense fp32 MFMA peak (157.3 TFLOP/s).  The path is compute-bound
+                (~2800 FLOP/B), so the binding roofline is "mfma"; the HBM view of the
+                whole job is reported beside it in "hbm".
+  cpu_baseline  the NumPy/BLAS oracle (a port, not TensorFlow) timed on this host's cores on a bounded
+                sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "timed-design_amd"))
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 MFMA = vector peak
+PEAK_HBM_GBS = 8000.0           # HBM3E spec
+
+
+def cpu_baseline(cfg, weights, topology: str, budget_s: float = 15.0):
+    """Time the oracle (NumPy + multithreaded BLAS) on a bounded sample of the same workload."""
+    from oracle import cnn_oracle
+    from timed_hip import synth
+    frames = synth.synthetic_frames(4, seed=999)
+    cnn_oracle.forward(cfg, weights, frames[:1])  # warm up BLAS threads
+    t0 = time.perf_counter()
+    cnn_oracle.forward(cfg, weights, frames)
+    rate = 4 / (time.perf_counter() - t0)
+    n = int(min(max(budget_s * rate, 8), 512))
+    frames = synth.synthetic_frames(n, seed=1000)
+    t0 = time.perf_counter()
+    cnn_oracle.forward(cfg, weights, frames)
+    dt = time.perf_counter() - t0
+    return dict(value=n / dt, unit="frames/s", cores=os.cpu_count(), kind="port",
+                sample=f"{n} synthetic frames of {topology} through oracle/cnn_oracle.py (NumPy im2col + BLAS sgemm, "
+                       f"fp32), {dt:.1f} s wall")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=100_000, help="frames per GPU per step (BASELINE config: 100k)")
+    ap.add_argument("--topology", default="timed", choices=["timed", "timed_rotamer", "densecpd"])
+    ap.add_argument("--chunk", type=int, default=2048)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP events (roofline omitted)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+
+    from timed_hip import _lib, engine, synth
+    import ctypes as C
+
+    lib = _lib.load()
+    ndev = _lib.device_count()
+    if ndev < 1:
+        sys.exit("no HIP device visible; bench.py measures the GPU path only")
+    device = local_rank % ndev
+
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    cfg, weights = synth.TOPOLOGIES[args.topology]()
+    model = engine.HipFrameModel.from_keras(cfg, weights, device=device, name=args.topology)
+    model.set_chunk(args.chunk)
+    D, H, W, Cc = model.input_shape
+    n = args.frames
+    frame_floats = D * H * W * Cc
+    d_frames = engine.DeviceBuffer(n * frame_floats * 4, device)
+    d_probs = engine.DeviceBuffer(n * model.n_classes * 4, device)
+    _lib.check(lib.th_dev_synth_frames(device, C.c_void_p(d_frames.ptr), n, D, Cc, 200, 1234 + rank))
+
+    # multi-GPU exchange: RCCL gather of the probability shards to rank 0
+    comm = None
+    d_gather = None
+    counts = (C.c_int64 * world)(*([n] * world))
+    if world > 1:
+        import torch
+        idbuf = C.create_string_buffer(_lib.TH_COMM_ID_BYTES)
+        if rank == 0:
+            _lib.check(lib.th_comm_unique_id(idbuf))
+        t = torch.frombuffer(bytearray(idbuf.raw), dtype=torch.uint8).clone()
+        dist.broadcast(t, src=0)
+        idbytes = bytes(t.numpy().tobytes())
+        h = C.c_void_p()
+        _lib.check(lib.th_comm_init(idbytes, world, rank, device, C.byref(h)))
+        comm = h
+        if rank == 0:
+            d_gather = engine.DeviceBuffer(world * n * model.n_classes * 4, device)
+
+    def step():
+        model.predict_device(d_frames.ptr, n, d_probs.ptr)
+        if comm is not None:
+            _lib.check(lib.th_comm_gather_rows(comm, C.c_void_p(d_probs.ptr), counts, model.n_classes, 0,
+                                               C.c_void_p(d_gather.ptr if d_gather else 0)))
+
+    for _ in range(args.warmup):
+        step()
+    _lib.check(lib.th_dev_sync(device))
+    if not args.no_profile:
+        model.profile(True)
+    barrier()
+    _lib.check(lib.th_dev_sync(device))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    _lib.check(lib.th_dev_sync(device))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # sanity: the output of the timed work is a probability matrix
+    probe = d_probs.download((min(n, 256), model.n_classes), np.float32)
+    assert np.all(np.isfinite(probe)) and np.allclose(probe.sum(1), 1.0, atol=1e-4), "bench output is not a probability matrix"
+
+    if rank == 0:
+        cost = model.cost()
+        total_frames = n * world * args.steps
+        fps = total_frames / elapsed
+        algo_bytes = frame_floats * 4 + 4 * model.n_classes
+        line = {
+            "metric": "residue_frames_per_sec", "value": fps, "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{model.name}-synth forward, {D}x{H}x{W}x{Cc} fp32 frames resident in HBM, "
+                                   f"{n} frames per GPU per step, {model.n_classes} classes, random-init weights",
+                       "frames_per_gpu": n, "chunk": args.chunk, "parallelism": f"frame-shard x{world}",
+                       "exchange": "rccl gather to rank 0" if world > 1 else "none",
+                       "algo_mflop_per_frame": cost["algo_flops"] / 1e6, "exec_mflop_per_frame": cost["exec_flops"] / 1e6,
+                       "device": f"{model.device_arch} {model.device_cus} CUs"},
+            "model_tflops": fps / world * cost["algo_flops"] / 1e12,
+            "model_frac_of_fp32_mfma_peak": fps / world * cost["algo_flops"] / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+            "hbm": {"algo_bytes_per_frame": algo_bytes, "achieved_GBps": fps / world * algo_bytes / 1e9,
+                    "frac": fps / world * algo_bytes / 1e9 / PEAK_HBM_GBS},
+        }
+        if not args.no_profile:
+            steps = [s for s in model.steps() if s["launches"]]
+            tot_ms = sum(s["ms"] for s in steps)
+            dom = max(steps, key=lambda s: s["ms"])
+            avg_ms = dom["ms"] / dom["launches"]
+            frames_per_launch = n * args.steps / dom["launches"]
+            achieved = dom["flops"] * frames_per_launch / (avg_ms * 1e-3) / 1e12
+            line["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                                "kernel": dom["label"], "avg_launch_ms": avg_ms, "launches": dom["launches"],
+                                "share_of_device_time": dom["ms"] / tot_ms,
+                                "exec_tflops": dom["exec_flops"] * frames_per_launch / (avg_ms * 1e-3) / 1e12}
+            line["kernels"] = [{"label": s["label"], "ms_total": round(s["ms"], 3), "launches": s["launches"],
+                                "tflops_algo": (s["flops"] * n * args.steps / (s["ms"] * 1e-3) / 1e12) if s["ms"] else 0.0}
+                               for s in steps]
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(cfg, weights, f"{model.name}-synth")
+        print(json.dumps(line))
+    if comm is not None:
+        lib.th_comm_free(comm)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

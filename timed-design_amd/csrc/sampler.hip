@@ -45,18 +45,20 @@ __device__ double np_pairwise_sum(const double* a, int n) {
 }
 
 // one thread per residue row: temper, normalise, running sum
-__global__ void k_temper_cumsum(const double* __restrict__ p, int64_t n_res, int n_cls, double t, double* __restrict__ q,
-                                double* __restrict__ c) {
+__global__ void k_temper_cumsum(const double* __restrict__ p, int64_t n_res, int n_cls, double t, int force_norm,
+                                double* __restrict__ q, double* __restrict__ c) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n_res) return;
     const double* pr = p + i * n_cls;
     double* qr = q + i * n_cls;
     double* cr = c + i * n_cls;
-    if (t != 1.0) {
+    // sample.py:40 skips apply_temp_to_probs when t == 1 (rows stay un-normalised); the function
+    // itself (force_norm) always renormalises, also at t == 1 where x**1.0 is x.
+    if (t != 1.0 || force_norm) {
         const double e = 1.0 / t;
         for (int j = 0; j < n_cls; ++j) {
             const double x = pr[j];
-            qr[j] = (e == 2.0) ? x * x : (e == 0.5) ? sqrt(x) : pow(x, e);
+            qr[j] = (e == 1.0) ? x : (e == 2.0) ? x * x : (e == 0.5) ? sqrt(x) : pow(x, e);
         }
         const double s = np_pairwise_sum<8>(qr, n_cls);
         for (int j = 0; j < n_cls; ++j) qr[j] = qr[j] / s;
@@ -177,7 +179,7 @@ int sampler_run(int device, const double* h_probs, int64_t n_res, int n_cls, int
     if ((rc = dp.alloc(pbytes)) || (rc = dq.alloc(pbytes)) || (rc = dc.alloc(pbytes))) return rc;
     HIP_TRY(hipMemcpy(dp.p, h_probs, pbytes, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_temper_cumsum, dim3((unsigned)((n_res + 63) / 64)), dim3(64), 0, 0, (const double*)dp.p, n_res,
-                       n_cls, temperature, (double*)dq.p, (double*)dc.p);
+                       n_cls, temperature, (n_samples == 0 && h_q_out) ? 1 : 0, (double*)dq.p, (double*)dc.p);
     HIP_TRY(hipGetLastError());
     if (h_q_out) HIP_TRY(hipMemcpy(h_q_out, dq.p, pbytes, hipMemcpyDeviceToHost));
     if (total == 0) { HIP_TRY(hipDeviceSynchronize()); return TH_OK; }
