@@ -1,0 +1,300 @@
+"""design_utils.utils — the dataset / codec / writer functions either side of the CNN kernels.
+
+Same names, argument meaning and output formats as the reference's ``design_utils/utils.py`` for the
+functions on the hot path; each function cites the lines it mirrors.
+Written from scratch: HDF5 access goes through h5py when importable and the bundled pure-Python
+reader otherwise, amino-acid tables are local (design_utils/amino_acids.py), and the per-residue
+Python loops of the reference are vectorised where that cannot change the output.
+
+Out of scope here (UI helpers of the reference module): PDB property editing, BLOSUM lookup,
+alphanumeric map codes, rm_tree.
+"""
+from __future__ import annotations
+
+import typing as t
+import warnings
+from itertools import product
+from pathlib import Path
+
+import numpy as np
+
+from .amino_acids import UNCOMMON_RESIDUE_DICT, side_chain_dihedrals, standard_amino_acids
+
+
+# ---- dataset access -----------------------------------------------------------------------------------
+def open_frame_dataset(path):
+    """h5py.File when h5py is importable, timed_hip.h5lite.File otherwise (same read surface)."""
+    try:
+        import h5py  # type: ignore
+        return h5py.File(str(path), "r")
+    except ImportError:
+        from timed_hip import h5lite
+        return h5lite.File(str(path))
+
+
+def _as_str(v) -> str:
+    if isinstance(v, bytes):
+        return v.decode()
+    if isinstance(v, np.ndarray) and v.shape == ():
+        return _as_str(v[()])
+    return str(v)
+
+
+# ---- dataset map ----------------------------------------------------------------------------------------
+def load_datasetmap(path_to_datasetmap: Path, is_old: bool = False) -> np.ndarray:
+    """reference utils.py:190-227.  New (PDBench) maps: three header lines then "<pdb> <count>";
+    old maps: csv of (pdb, chain, residue_id, label)."""
+    path_to_datasetmap = Path(path_to_datasetmap)
+    assert (
+        path_to_datasetmap.suffix == ".txt"
+    ), f"Expected Path {path_to_datasetmap} to be a .txt file but got {path_to_datasetmap.suffix}."
+    if is_old:
+        dataset_map = np.genfromtxt(path_to_datasetmap, delimiter=",", dtype=str)
+    else:
+        dataset_map = np.genfromtxt(path_to_datasetmap, delimiter=" ", dtype=str, skip_header=3)
+    dataset_map = np.asarray(dataset_map)
+    # a single-pdb map parses to a 1-D array: wrap it so callers can iterate rows (reference :223-225)
+    if isinstance(dataset_map[0], str):
+        dataset_map = [dataset_map]
+    return dataset_map
+
+
+def get_pdb_keys_to_filter(pdb_key_path: Path, file_extension: str = ".txt") -> t.List[str]:
+    """reference utils.py:284-315: first four characters of every key in every list file."""
+    pdb_key_files = list(Path(pdb_key_path).glob(f"**/*{file_extension}"))
+    assert len(pdb_key_files) >= 1, "Expected at least 1 pdb key file."
+    keys: t.List[str] = []
+    for fpath in pdb_key_files:
+        for pdb in np.atleast_1d(np.genfromtxt(fpath, dtype=str)):
+            keys.append(str(pdb)[:4])
+    return keys
+
+
+def create_flat_dataset_map(
+    frame_dataset: Path,
+    filter_list: t.List[str] = [],
+    remove_blacklist_silently: bool = False,
+    uncommon_residue_dict: t.Optional[dict] = None,
+) -> (t.List[t.Tuple[str, str, str, str]], t.Set[str]):
+    """reference utils.py:318-407.  Flattens pdb/chain/residue into the deterministic frame order the
+    whole pipeline relies on: pdb groups in HDF5 name order, chains in name order, residues sorted
+    NUMERICALLY (the reference's ``np.int`` at :368 only runs on NumPy < 1.24; plain ``int`` here).
+    Uncommon residue labels are mapped through aposteriori's table (:381-385)."""
+    standard_residues = list(standard_amino_acids.values())
+    uncommon = UNCOMMON_RESIDUE_DICT if uncommon_residue_dict is None else uncommon_residue_dict
+    training_set_pdbs = set()
+    flat_dataset_map = []
+    with open_frame_dataset(frame_dataset) as dataset_file:
+        for pdb_code in dataset_file:
+            if pdb_code[:4] in filter_list:
+                if remove_blacklist_silently:
+                    warnings.warn(f"PDB code {pdb_code} was found in benchmark dataset. It was automatically removed.")
+                    continue
+                raise ValueError(
+                    f"PDB code {pdb_code} was found in benchmark dataset. "
+                    f"Turn on remove_blacklist_silently=True if you want to ignore these structures for training.")
+            pdb_group = dataset_file[pdb_code]
+            for chain_id in pdb_group.keys():
+                chain_group = pdb_group[chain_id]
+                residue_n = np.array(list(chain_group.keys()), dtype=int)
+                residue_n.sort()
+                for residue_id in residue_n.astype(str):
+                    residue_label = _as_str(chain_group[str(residue_id)].attrs["label"])
+                    if residue_label not in standard_residues:
+                        if residue_label in uncommon:
+                            warnings.warn(f"{residue_label} is not a standard residue.")
+                            residue_label = uncommon[residue_label]
+                            warnings.warn(f"Residue converted to {residue_label}.")
+                        else:
+                            raise AssertionError(f"Expected natural amino acid, but got {residue_label}.")
+                    flat_dataset_map.append((pdb_code, chain_id, str(residue_id), residue_label))
+                    training_set_pdbs.add(pdb_code)
+    return flat_dataset_map, training_set_pdbs
+
+
+def load_batch(dataset_path: Path, data_point_batch: t.List[t.Tuple]) -> (np.ndarray, np.ndarray):
+    """reference utils.py:487-530: X[batch, *frame_dims] (float64 when voxels_as_gaussian, else bool —
+    :518-521) and y[batch, 20] one-hot labels from the ``encoded_residue`` attribute."""
+    batch_size = len(data_point_batch)
+    with open_frame_dataset(dataset_path) as dataset:
+        dims = tuple(int(d) for d in np.asarray(dataset.attrs["frame_dims"]).ravel())
+        voxels_as_gaussian = bool(dataset.attrs["voxels_as_gaussian"])
+        X = np.zeros((batch_size, *dims), dtype=float if voxels_as_gaussian else bool)
+        y = np.zeros((batch_size, 20), dtype=float)
+        for i, (pdb_code, chain_id, residue_id, _) in enumerate(data_point_batch):
+            ds = dataset[str(pdb_code)][str(chain_id)][str(residue_id)]
+            X[i] = np.asarray(ds[()])
+            y[i] = np.asarray(ds.attrs["encoded_residue"])
+    return X, y
+
+
+# ---- rotamer codec ------------------------------------------------------------------------------------
+def get_rotamer_codec(return_reduction_guide: bool = False):
+    """reference utils.py:410-465.  338 categories: per residue (alphabetical one-letter order) all
+    3**n_chi rotamer combinations ("ARG_1123" ...), "_0" for residues without side-chain dihedrals.
+    Returns ({rotamer_index: one-hot(20)}, [338 names]) and optionally the first index of each residue
+    ([0, 1, 4, 13, 40, ...], the guide printed at reference :425)."""
+    flat_categories: t.List[str] = []
+    rot_to_20res = {}
+    reduction_guide = []
+    r_count = 0
+    for i, (_a, res) in enumerate(standard_amino_acids.items()):
+        reduction_guide.append(r_count)
+        if res in side_chain_dihedrals:
+            combos = list(product([1, 2, 3], repeat=len(side_chain_dihedrals[res])))
+            for r, rota in enumerate(combos):
+                flat_categories.append(f"{res}_{''.join(str(x) for x in rota)}")
+                onehot = np.array([0] * 20)
+                onehot[i] = 1
+                rot_to_20res[r_count + r] = onehot
+            r_count += len(combos)
+        else:
+            flat_categories.append(f"{res}_0")
+            onehot = np.array([0] * 20)
+            onehot[i] = 1
+            rot_to_20res[r_count] = onehot
+            r_count += 1
+    if return_reduction_guide:
+        return rot_to_20res, flat_categories, reduction_guide
+    return rot_to_20res, flat_categories
+
+
+def compress_rotamer_predictions_to_20(prediction_matrix: np.ndarray) -> np.ndarray:
+    """reference utils.py:468-484: (n, 338) -> (n, 20) by summing each residue's rotamer columns."""
+    _, _, reduction_guide = get_rotamer_codec(return_reduction_guide=True)
+    return np.add.reduceat(prediction_matrix, reduction_guide, axis=1)
+
+
+# ---- prediction matrix -> sequences ----------------------------------------------------------------------
+def extract_sequence_from_pred_matrix(
+    flat_dataset_map: t.List[t.Tuple],
+    prediction_matrix: np.ndarray,
+    rotamers_categories: t.Optional[t.List[str]],
+    old_datasetmap: bool = False,
+    is_consensus: bool = False,
+) -> (dict, dict, dict, dict, dict):
+    """reference utils.py:616-723.  argmax (first maximum) -> one-letter sequence per key; key =
+    pdb+chain for 4-column maps, the map's own key for "<pdb> <count>" maps.  ``old_datasetmap`` is
+    re-derived from the map width exactly as the reference does (:662).  With ``is_consensus`` the
+    states "<pdb>_<n>" of an NMR ensemble are merged by the reference's RUNNING PAIRWISE average
+    (acc+new)/2 (:699-705) — not an arithmetic mean."""
+    res_to_r_dic = dict(zip(standard_amino_acids.values(), standard_amino_acids.keys()))
+    if rotamers_categories:
+        if len(rotamers_categories[0]) == 1:
+            res_dic = list(rotamers_categories)
+        else:
+            res_dic = [res_to_r_dic[res.split("_")[0]] for res in rotamers_categories]
+    else:
+        res_dic = list(standard_amino_acids.keys())
+    res_arr = np.array(res_dic)
+    prediction_matrix = np.asarray(prediction_matrix)
+    max_idx = np.argmax(prediction_matrix, axis=1)
+    letters = res_arr[max_idx]
+
+    pdb_to_sequence: dict = {}
+    pdb_to_probability: dict = {}
+    pdb_to_real_sequence: dict = {}
+    old_datasetmap = True if len(flat_dataset_map[0]) == 4 else False
+    if old_datasetmap:
+        # rows are consumed one-to-one; group consecutive (and repeated) keys in first-seen order
+        rows: dict = {}
+        for i in range(len(flat_dataset_map)):
+            pdb_chain, chain, _, res = flat_dataset_map[i]
+            key = str(pdb_chain) + str(chain)
+            rows.setdefault(key, []).append(i)
+        for key, idxs in rows.items():
+            ii = np.asarray(idxs)
+            pdb_to_sequence[key] = "".join(letters[ii])
+            pdb_to_probability[key] = [list(prediction_matrix[k]) for k in ii]
+            pdb_to_real_sequence[key] = "".join(res_to_r_dic[str(flat_dataset_map[k][3])] for k in ii)
+    else:
+        previous_count = 0
+        for i in range(len(flat_dataset_map)):
+            key, count = flat_dataset_map[i]
+            key, count = str(key), int(count)
+            if key not in pdb_to_sequence:
+                pdb_to_sequence[key] = ""
+                pdb_to_real_sequence[key] = ""
+                pdb_to_probability[key] = []
+            sl = slice(previous_count, previous_count + count)
+            pdb_to_sequence[key] += "".join(letters[sl])
+            pdb_to_probability[key].extend(list(row) for row in prediction_matrix[sl])
+            previous_count += count
+
+    if not is_consensus:
+        return pdb_to_sequence, pdb_to_probability, pdb_to_real_sequence, None, None
+    pdb_to_consensus: dict = {}
+    pdb_to_consensus_prob: dict = {}
+    last_pdb = ""
+    for pdb_chain in pdb_to_sequence.keys():
+        curr_pdb = pdb_chain.split("_")[0]
+        if last_pdb != curr_pdb:
+            pdb_to_consensus_prob[curr_pdb] = np.array(pdb_to_probability[pdb_chain])
+            last_pdb = curr_pdb
+        else:
+            pdb_to_consensus_prob[curr_pdb] = (pdb_to_consensus_prob[curr_pdb] + np.array(pdb_to_probability[pdb_chain])) / 2
+    for pdb_chain, curr_prob in pdb_to_consensus_prob.items():
+        pdb_to_consensus[pdb_chain] = "".join(res_arr[np.argmax(curr_prob, axis=1)])
+    return pdb_to_sequence, pdb_to_probability, pdb_to_real_sequence, pdb_to_consensus, pdb_to_consensus_prob
+
+
+# ---- writers ---------------------------------------------------------------------------------------------
+def save_outputs_to_file(
+    y_true: np.ndarray,
+    y_pred: t.Dict[int, list],
+    flat_dataset_map: t.List[t.Tuple],
+    model: int,
+    model_name: str,
+    path_to_output: Path = Path.cwd(),
+):
+    """reference utils.py:726-771.  APPENDS: encoded_labels.csv ('%i', first model only), datasetmap.txt
+    (written once, only if absent), <model>.csv — probabilities cast to float16 then written with
+    np.savetxt's default '%.18e' (so the file holds float16-rounded values)."""
+    path_to_output = Path(path_to_output)
+    if model == 0:
+        with open(path_to_output / "encoded_labels.csv", "a") as f:
+            np.savetxt(f, np.asarray(y_true), delimiter=",", fmt="%i")
+    path_to_datasetmap = path_to_output / "datasetmap.txt"
+    if not path_to_datasetmap.exists():
+        with open(path_to_datasetmap, "a") as f:
+            np.savetxt(f, np.asarray(flat_dataset_map), delimiter=",", fmt="%s")
+    predictions = np.array(y_pred[model], dtype=np.float16)
+    with open(path_to_output / f"{model_name}.csv", "a") as f:
+        np.savetxt(f, predictions, delimiter=",")
+
+
+def convert_dataset_map_for_srb(flat_dataset_map: list, model_name: str, path_to_output: Path = Path.cwd()):
+    """reference utils.py:533-566: PDBench map "<pdb> <count>" (chain appended to 4-letter codes,
+    "_0..." state suffix stripped) after three header lines."""
+    count_dict: dict = {}
+    for pdb, chain, _res_idx, _ in flat_dataset_map:
+        pdb, chain = str(pdb), str(chain)
+        if "_0" in pdb:
+            pdb = pdb.split("_0")[0]
+        if len(pdb) == 4:
+            pdb += chain
+        count_dict[pdb] = count_dict.get(pdb, 0) + 1
+    with open(Path(path_to_output) / f"{model_name}.txt", "w") as d:
+        d.write("ignore_uncommon False\ninclude_pdbs\n##########\n")
+        for pdb, count in count_dict.items():
+            d.write(f"{pdb} {count}\n")
+
+
+def save_dict_to_fasta(pdb_to_sequence: dict, model_name: str, path_to_output: Path = Path.cwd()):
+    """reference utils.py:595-613."""
+    with open(Path(path_to_output) / f"{model_name}.fasta", "w") as f:
+        for pdb, seq in pdb_to_sequence.items():
+            f.write(f">{pdb}\n{seq}\n")
+
+
+def save_consensus_probs(pdb_to_consensus_prob: dict, model_name: str, path_to_output: Path = Path.cwd()):
+    """reference utils.py:569-592.  (The reference writes the .csv to the CWD regardless of
+    ``path_to_output`` — Appendix C-8; here both files go to ``path_to_output``.)"""
+    path_to_output = Path(path_to_output)
+    with open(path_to_output / f"{model_name}_consensus.txt", "w") as d, open(
+        path_to_output / f"{model_name}_consensus.csv", "a"
+    ) as p:
+        d.write("ignore_uncommon False\ninclude_pdbs\n##########\n")
+        for pdb, predictions in pdb_to_consensus_prob.items():
+            d.write(f"{pdb} {len(predictions)}\n")
+            np.savetxt(p, predictions, delimiter=",")

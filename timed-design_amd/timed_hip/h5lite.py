@@ -1,0 +1,575 @@
+"""h5lite — a minimal, read-only, pure-Python/NumPy HDF5 reader.
+
+Why: the two files either side of the hot path are HDF5 — the Keras legacy ``.h5`` model
+(reference predict.py:121) and the aposteriori frame dataset (reference
+design_utils/utils.py:238-251, read at :359-393 and :514-529) — and h5py is not installable on the
+target interpreter.  Scope is exactly what h5py/HDF5-1.10 writes for those two producers with default
+settings (``libver='earliest'``):
+
+  superblock v0 (and v2/v3), object headers v1 (and v2), old-style groups (symbol table: B-tree v1 +
+  local heap + SNOD) and compact new-style link messages, datasets with compact / contiguous /
+  chunked (B-tree v1) layout, deflate + shuffle + fletcher32 filters, fixed-point / IEEE float /
+  fixed string / variable-length string / enum(bool) / array datatypes, attributes v1-v3.
+
+Anything else (dense link/attribute storage, layout v4, compound types, external links, ...) raises
+``H5Unsupported`` rather than guessing.  The interface mirrors the slice of h5py the reference uses:
+``File(path)``, ``obj.attrs`` (dict), ``group.keys()``, ``group[name]``, iteration, ``dataset[()]``,
+``dataset.shape/dtype``.
+"""
+from __future__ import annotations
+
+import mmap
+import struct
+import zlib
+from typing import Dict, Iterator, List, Optional, Tuple
+
+import numpy as np
+
+UNDEF = 0xFFFFFFFFFFFFFFFF
+SIGNATURE = b"\x89HDF\r\n\x1a\n"
+
+
+class H5Unsupported(NotImplementedError):
+    pass
+
+
+class H5FormatError(ValueError):
+    pass
+
+
+# ---- datatype ---------------------------------------------------------------------------------------
+class _DType:
+    """Decoded datatype message."""
+    __slots__ = ("cls", "size", "np", "vlen_str", "enum_bool", "str_pad", "base", "dims")
+
+    def __init__(self):
+        self.cls = -1; self.size = 0; self.np = None; self.vlen_str = False; self.enum_bool = False
+        self.str_pad = 0; self.base = None; self.dims = ()
+
+
+def _parse_dtype(buf: bytes, off: int) -> Tuple[_DType, int]:
+    """Returns (dtype, bytes consumed)."""
+    b0, bf0, bf1, bf2, size = struct.unpack_from("<BBBBI", buf, off)
+    cls, ver = b0 & 0x0F, b0 >> 4
+    dt = _DType(); dt.cls = cls; dt.size = size
+    p = off + 8
+    if cls == 0:  # fixed point
+        order = ">" if bf0 & 1 else "<"
+        signed = bool(bf0 & 8)
+        dt.np = np.dtype(f"{order}{'i' if signed else 'u'}{size}")
+        p += 4
+    elif cls == 1:  # float
+        order = ">" if bf0 & 1 else "<"
+        if size not in (2, 4, 8):
+            raise H5Unsupported(f"float of {size} bytes")
+        dt.np = np.dtype(f"{order}f{size}")
+        p += 12
+    elif cls == 3:  # fixed-length string
+        dt.str_pad = bf0 & 0x0F
+        dt.np = np.dtype(f"S{size}")
+    elif cls == 9:  # variable length
+        vtype = bf0 & 0x0F
+        base, used = _parse_dtype(buf, p)
+        p += used
+        if vtype == 1:
+            dt.vlen_str = True
+        else:
+            raise H5Unsupported("variable-length sequences (non-string)")
+        dt.base = base
+    elif cls == 8:  # enum: h5py stores numpy bool as ENUM{FALSE=0,TRUE=1} over int8
+        nmemb = bf0 | (bf1 << 8)
+        base, used = _parse_dtype(buf, p)
+        p += used
+        names = []
+        for _ in range(nmemb):
+            e = buf.index(b"\0", p)
+            names.append(buf[p:e])
+            n = e - p + 1
+            p += n if ver >= 3 else (n + 7) // 8 * 8
+        p += nmemb * base.size
+        dt.base = base
+        dt.np = base.np
+        dt.enum_bool = sorted(names) == [b"FALSE", b"TRUE"]
+    elif cls == 10:  # array
+        if ver < 3:
+            rank = buf[p]; p += 4
+            dims = struct.unpack_from(f"<{rank}I", buf, p); p += 4 * rank
+            p += 4 * rank  # permutation indices
+        else:
+            rank = buf[p]; p += 1
+            dims = struct.unpack_from(f"<{rank}I", buf, p); p += 4 * rank
+        base, used = _parse_dtype(buf, p)
+        p += used
+        dt.base = base; dt.dims = tuple(dims)
+        dt.np = np.dtype((base.np, tuple(dims)))
+    elif cls == 6:
+        raise H5Unsupported("compound datatypes")
+    elif cls == 7:
+        raise H5Unsupported("reference datatypes")
+    else:
+        raise H5Unsupported(f"datatype class {cls}")
+    return dt, p - off
+
+
+def _parse_dataspace(buf: bytes, off: int) -> Tuple[Optional[Tuple[int, ...]], int]:
+    ver = buf[off]
+    if ver == 1:
+        rank, flags = buf[off + 1], buf[off + 2]
+        p = off + 8
+    elif ver == 2:
+        rank, flags, stype = buf[off + 1], buf[off + 2], buf[off + 3]
+        p = off + 4
+        if stype == 2:
+            return None, 4  # null dataspace
+    else:
+        raise H5Unsupported(f"dataspace version {ver}")
+    dims = struct.unpack_from(f"<{rank}Q", buf, p)
+    p += 8 * rank
+    if flags & 1:
+        p += 8 * rank
+    return tuple(dims), p - off
+
+
+# ---- file ---------------------------------------------------------------------------------------------
+class File:
+    def __init__(self, path, mode: str = "r"):
+        if mode != "r":
+            raise H5Unsupported("h5lite is read-only")
+        self._f = open(path, "rb")
+        try:
+            self._m = mmap.mmap(self._f.fileno(), 0, access=mmap.ACCESS_READ)
+        except ValueError:
+            self._f.close()
+            raise H5FormatError(f"{path}: empty file")
+        self.filename = str(path)
+        self._gheap: Dict[int, Dict[int, bytes]] = {}
+        base = self._find_superblock()
+        self._base = base
+        m = self._m
+        ver = m[base + 8]
+        if ver in (0, 1):
+            so, sl = m[base + 13], m[base + 14]
+            if (so, sl) != (8, 8):
+                raise H5Unsupported("offset/length sizes other than 8")
+            p = base + 24 + (4 if ver == 1 else 0)
+            p += 32  # base addr, free-space addr, eof addr, driver info addr
+            # root group symbol table entry
+            _link_off, ohdr, cache, _r = struct.unpack_from("<QQII", m, p)
+            self._root_addr = ohdr
+        elif ver in (2, 3):
+            so, sl = m[base + 9], m[base + 10]
+            if (so, sl) != (8, 8):
+                raise H5Unsupported("offset/length sizes other than 8")
+            _baseaddr, _ext, _eof, root = struct.unpack_from("<QQQQ", m, base + 12)
+            self._root_addr = root
+        else:
+            raise H5Unsupported(f"superblock version {ver}")
+        self._root = Group(self, self._root_addr, "/")
+
+    def _find_superblock(self) -> int:
+        off = 0
+        while off + 8 <= len(self._m):
+            if self._m[off:off + 8] == SIGNATURE:
+                return off
+            off = 512 if off == 0 else off * 2
+        raise H5FormatError("not an HDF5 file")
+
+    # h5py-like surface, delegated to the root group
+    @property
+    def attrs(self): return self._root.attrs
+    def keys(self): return self._root.keys()
+    def __iter__(self): return iter(self._root)
+    def __getitem__(self, k): return self._root[k]
+    def __contains__(self, k): return k in self._root
+    def __len__(self): return len(self._root)
+    def __enter__(self): return self
+    def __exit__(self, *a): self.close()
+
+    def close(self):
+        if self._m is not None:
+            self._m.close(); self._f.close(); self._m = None
+
+    # ---- low level ----------------------------------------------------------------------------------
+    def _messages(self, addr: int) -> List[Tuple[int, int, bytes]]:
+        """All header messages of the object at addr as (type, flags, payload)."""
+        m = self._m
+        a = self._base + addr
+        out: List[Tuple[int, int, bytes]] = []
+        if m[a:a + 4] == b"OHDR":  # version 2
+            if m[a + 4] != 2:
+                raise H5Unsupported("object header version")
+            flags = m[a + 5]
+            p = a + 6
+            if flags & 0x20:
+                p += 16
+            if flags & 0x10:
+                p += 4
+            szbytes = 1 << (flags & 3)
+            chunk0 = int.from_bytes(m[p:p + szbytes], "little")
+            p += szbytes
+            track_order = bool(flags & 4)
+            blocks = [(p, chunk0)]
+            while blocks:
+                bp, bl = blocks.pop(0)
+                end = bp + bl
+                q = bp
+                while q + 4 <= end:
+                    mtype = m[q]; msize = struct.unpack_from("<H", m, q + 1)[0]; mflags = m[q + 3]
+                    q += 4 + (2 if track_order else 0)
+                    data = bytes(m[q:q + msize])
+                    q += msize
+                    if mtype == 0x10:
+                        co, cl = struct.unpack_from("<QQ", data, 0)
+                        blocks.append((self._base + co + 4, cl - 8))  # skip "OCHK", drop checksum
+                    elif mtype != 0:
+                        out.append((mtype, mflags, data))
+            return out
+        ver = m[a]
+        if ver != 1:
+            raise H5FormatError(f"bad object header at {addr:#x}")
+        nmsg, _ref, hsize = struct.unpack_from("<HII", m, a + 2)
+        blocks = [(a + 16, hsize)]
+        while blocks and len(out) < 100000:
+            bp, bl = blocks.pop(0)
+            q, end = bp, bp + bl
+            while q + 8 <= end:
+                mtype, msize, mflags = struct.unpack_from("<HHB", m, q)
+                q += 8
+                data = bytes(m[q:q + msize])
+                q += msize
+                if mtype == 0x10:
+                    co, cl = struct.unpack_from("<QQ", data, 0)
+                    blocks.append((self._base + co, cl))
+                elif mtype != 0:
+                    out.append((mtype, mflags, data))
+        return out
+
+    def _global_heap_object(self, addr: int, index: int) -> bytes:
+        col = self._gheap.get(addr)
+        if col is None:
+            m = self._m
+            a = self._base + addr
+            if m[a:a + 4] != b"GCOL":
+                raise H5FormatError("bad global heap collection")
+            size = struct.unpack_from("<Q", m, a + 8)[0]
+            col = {}
+            p, end = a + 16, a + size
+            while p + 16 <= end:
+                idx, _rc, _r, osz = struct.unpack_from("<HHIQ", m, p)
+                if idx == 0:
+                    break
+                col[idx] = bytes(m[p + 16:p + 16 + osz])
+                p += 16 + (osz + 7) // 8 * 8
+            self._gheap[addr] = col
+        return col[index]
+
+    def _decode(self, dt: _DType, shape, raw: bytes):
+        """raw bytes of `shape` elements -> numpy array / python value, h5py-style."""
+        n = int(np.prod(shape)) if shape else 1
+        if dt.vlen_str:
+            vals = []
+            for i in range(n):
+                ln, addr, idx = struct.unpack_from("<IQI", raw, 16 * i)
+                vals.append(self._global_heap_object(addr, idx)[:ln].decode("utf-8", "replace") if ln or addr else "")
+            if not shape:
+                return vals[0]
+            return np.array(vals, dtype=object).reshape(shape)
+        if dt.cls == 3:
+            arr = np.frombuffer(raw, dtype=dt.np, count=n)
+            if not shape:
+                return bytes(arr[0]).rstrip(b"\0 ").decode("utf-8", "replace") if dt.str_pad != 2 else bytes(arr[0]).decode()
+            return arr.reshape(shape).copy()
+        arr = np.frombuffer(raw, dtype=dt.np, count=n)
+        if dt.enum_bool:
+            arr = arr.astype(bool)
+        arr = arr.reshape(tuple(shape) + tuple(dt.dims) if dt.cls == 10 else shape)
+        if not shape and dt.cls != 10:
+            return arr[()] if arr.dtype != bool else bool(arr[()])
+        return arr.copy()
+
+
+class _Object:
+    def __init__(self, f: File, addr: int, name: str):
+        self._f, self._addr, self.name = f, addr, name
+        self._msgs = None
+        self._attrs = None
+
+    def _messages(self):
+        if self._msgs is None:
+            self._msgs = self._f._messages(self._addr)
+        return self._msgs
+
+    @property
+    def attrs(self) -> dict:
+        if self._attrs is None:
+            out = {}
+            for mtype, _fl, d in self._messages():
+                if mtype == 0x15:
+                    fheap = struct.unpack_from("<Q", d, 2 + (2 if d[1] & 1 else 0))[0]
+                    if fheap != UNDEF:
+                        raise H5Unsupported(f"{self.name}: dense attribute storage")
+                if mtype != 0x0C:
+                    continue
+                ver = d[0]
+                if ver == 1:
+                    nsz, dsz, ssz = struct.unpack_from("<HHH", d, 2)
+                    p = 8
+                    name = d[p:p + nsz].split(b"\0")[0].decode(); p += (nsz + 7) // 8 * 8
+                    dt, _ = _parse_dtype(d, p); p += (dsz + 7) // 8 * 8
+                    shape, _ = _parse_dataspace(d, p); p += (ssz + 7) // 8 * 8
+                elif ver in (2, 3):
+                    nsz, dsz, ssz = struct.unpack_from("<HHH", d, 2)
+                    p = 8 + (1 if ver == 3 else 0)
+                    name = d[p:p + nsz].split(b"\0")[0].decode(); p += nsz
+                    dt, _ = _parse_dtype(d, p); p += dsz
+                    shape, _ = _parse_dataspace(d, p); p += ssz
+                else:
+                    raise H5Unsupported(f"attribute message version {ver}")
+                if shape is None:
+                    out[name] = None
+                    continue
+                out[name] = self._f._decode(dt, shape, d[p:])
+            self._attrs = out
+        return self._attrs
+
+
+class Group(_Object):
+    def __init__(self, f, addr, name):
+        super().__init__(f, addr, name)
+        self._links: Optional[Dict[str, int]] = None
+
+    def _load(self) -> Dict[str, int]:
+        if self._links is not None:
+            return self._links
+        links: Dict[str, int] = {}
+        f = self._f
+        for mtype, _fl, d in self._messages():
+            if mtype == 0x11:  # symbol table
+                btree, heap = struct.unpack_from("<QQ", d, 0)
+                heap_data = self._local_heap(heap)
+                self._walk_btree(btree, heap_data, links)
+            elif mtype == 0x06:  # link message
+                ver, flags = d[0], d[1]
+                p = 2
+                ltype = 0
+                if flags & 8:
+                    ltype = d[p]; p += 1
+                if flags & 4:
+                    p += 8
+                if flags & 16:
+                    p += 1
+                lsz = 1 << (flags & 3)
+                nlen = int.from_bytes(d[p:p + lsz], "little"); p += lsz
+                name = d[p:p + nlen].decode(); p += nlen
+                if ltype != 0:
+                    continue  # soft/external links are not followed
+                links[name] = struct.unpack_from("<Q", d, p)[0]
+            elif mtype == 0x02:  # link info
+                flags = d[1]
+                p = 2 + (8 if flags & 1 else 0)
+                fheap = struct.unpack_from("<Q", d, p)[0]
+                if fheap != UNDEF:
+                    raise H5Unsupported(f"{self.name}: dense link storage (file written with libver='latest')")
+        self._links = links
+        return links
+
+    def _local_heap(self, addr: int) -> Tuple[int, int]:
+        m = self._f._m
+        a = self._f._base + addr
+        if m[a:a + 4] != b"HEAP":
+            raise H5FormatError("bad local heap")
+        dsize, _free, daddr = struct.unpack_from("<QQQ", m, a + 8)
+        return self._f._base + daddr, dsize
+
+    def _walk_btree(self, addr: int, heap: Tuple[int, int], links: Dict[str, int]):
+        m = self._f._m
+        a = self._f._base + addr
+        if m[a:a + 4] != b"TREE":
+            raise H5FormatError("bad B-tree node")
+        ntype, level, used = struct.unpack_from("<BBH", m, a + 4)
+        if ntype != 0:
+            raise H5FormatError("expected a group B-tree")
+        p = a + 24
+        for i in range(used):
+            child = struct.unpack_from("<Q", m, p + 8)[0]  # key_i (8), child_i (8)
+            p += 16
+            if level > 0:
+                self._walk_btree(child, heap, links)
+            else:
+                s = self._f._base + child
+                if m[s:s + 4] != b"SNOD":
+                    raise H5FormatError("bad symbol table node")
+                nsym = struct.unpack_from("<H", m, s + 6)[0]
+                q = s + 8
+                for _ in range(nsym):
+                    noff, ohdr = struct.unpack_from("<QQ", m, q)
+                    q += 40
+                    e = m.find(b"\0", heap[0] + noff)
+                    links[bytes(m[heap[0] + noff:e]).decode()] = ohdr
+
+    # ---- h5py-like surface --------------------------------------------------------------------------
+    def keys(self):
+        return sorted(self._load().keys())  # h5py iterates old-style groups in name order
+
+    def __iter__(self) -> Iterator[str]:
+        return iter(self.keys())
+
+    def __len__(self):
+        return len(self._load())
+
+    def __contains__(self, name):
+        try:
+            self[name]
+            return True
+        except KeyError:
+            return False
+
+    def __getitem__(self, name: str):
+        obj = self
+        for part in str(name).strip("/").split("/"):
+            if not isinstance(obj, Group):
+                raise KeyError(name)
+            links = obj._load()
+            if part not in links:
+                raise KeyError(f"{name!r} not found in {self.name}")
+            addr = links[part]
+            child_name = (obj.name.rstrip("/") + "/" + part)
+            kinds = {t for t, _f, _d in self._f._messages(addr)}
+            obj = Dataset(self._f, addr, child_name) if 0x08 in kinds else Group(self._f, addr, child_name)
+        return obj
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+
+class Dataset(_Object):
+    def __init__(self, f, addr, name):
+        super().__init__(f, addr, name)
+        self._dt = None; self._shape = None; self._layout = None; self._filters = []
+        for mtype, _fl, d in self._messages():
+            if mtype == 0x03:
+                self._dt, _ = _parse_dtype(d, 0)
+            elif mtype == 0x01:
+                self._shape, _ = _parse_dataspace(d, 0)
+            elif mtype == 0x08:
+                self._layout = d
+            elif mtype == 0x0B:
+                self._filters = self._parse_filters(d)
+        if self._dt is None or self._layout is None:
+            raise H5FormatError(f"{name}: incomplete dataset header")
+
+    @staticmethod
+    def _parse_filters(d: bytes):
+        ver, n = d[0], d[1]
+        out = []
+        p = 8 if ver == 1 else 2
+        for _ in range(n):
+            fid = struct.unpack_from("<H", d, p)[0]
+            if ver == 1 or fid >= 256:
+                nlen = struct.unpack_from("<H", d, p + 2)[0]
+                _flags, ncd = struct.unpack_from("<HH", d, p + 4)
+                p += 8
+                p += (nlen + 7) // 8 * 8 if ver == 1 else nlen
+            else:
+                _flags, ncd = struct.unpack_from("<HH", d, p + 2)
+                p += 6
+            cd = struct.unpack_from(f"<{ncd}I", d, p)
+            p += 4 * ncd
+            if ver == 1 and ncd % 2:
+                p += 4
+            out.append((fid, cd))
+        return out
+
+    @property
+    def shape(self): return self._shape
+    @property
+    def dtype(self): return np.dtype(bool) if self._dt.enum_bool else self._dt.np
+    @property
+    def ndim(self): return len(self._shape or ())
+
+    def _unfilter(self, raw: bytes, mask: int, elsize: int) -> bytes:
+        for i in reversed(range(len(self._filters))):
+            if mask & (1 << i):
+                continue
+            fid, cd = self._filters[i]
+            if fid == 1:
+                raw = zlib.decompress(raw)
+            elif fid == 2:
+                n = len(raw) // elsize
+                raw = np.frombuffer(raw[:n * elsize], dtype=np.uint8).reshape(elsize, n).T.tobytes() + raw[n * elsize:]
+            elif fid == 3:
+                raw = raw[:-4]
+            else:
+                raise H5Unsupported(f"{self.name}: filter id {fid}")
+        return raw
+
+    def _read_raw(self) -> bytes:
+        f, m, d = self._f, self._f._m, self._layout
+        ver = d[0]
+        shape = self._shape or ()
+        n = int(np.prod(shape)) if shape else 1
+        esz = self._dt.size if not self._dt.vlen_str else 16
+        if ver != 3:
+            raise H5Unsupported(f"{self.name}: data layout version {ver}")
+        cls = d[1]
+        if cls == 0:
+            size = struct.unpack_from("<H", d, 2)[0]
+            return d[4:4 + size]
+        if cls == 1:
+            addr, size = struct.unpack_from("<QQ", d, 2)
+            if addr == UNDEF:
+                return bytes(n * esz)
+            return bytes(m[f._base + addr:f._base + addr + size])
+        if cls == 2:
+            rank = d[2]
+            btree = struct.unpack_from("<Q", d, 3)[0]
+            cdims = struct.unpack_from(f"<{rank}I", d, 11)
+            chunk = cdims[:-1]
+            if cdims[-1] != esz:
+                raise H5FormatError(f"{self.name}: chunk element size")
+            out = np.zeros(shape, dtype=np.dtype(f"V{esz}"))
+            if btree != UNDEF:
+                self._walk_chunks(btree, rank, chunk, esz, out)
+            return out.tobytes()
+        raise H5Unsupported(f"{self.name}: layout class {cls}")
+
+    def _walk_chunks(self, addr, rank, chunk, esz, out):
+        f, m = self._f, self._f._m
+        a = f._base + addr
+        if m[a:a + 4] != b"TREE":
+            raise H5FormatError("bad chunk B-tree")
+        ntype, level, used = struct.unpack_from("<BBH", m, a + 4)
+        if ntype != 1:
+            raise H5FormatError("expected a chunk B-tree")
+        ksz = 8 + 8 * rank
+        p = a + 24
+        for _ in range(used):
+            csize, mask = struct.unpack_from("<II", m, p)
+            offs = struct.unpack_from(f"<{rank}Q", m, p + 8)
+            child = struct.unpack_from("<Q", m, p + ksz)[0]
+            p += ksz + 8
+            if level > 0:
+                self._walk_chunks(child, rank, chunk, esz, out)
+                continue
+            raw = self._unfilter(bytes(m[f._base + child:f._base + child + csize]), mask, esz)
+            block = np.frombuffer(raw, dtype=out.dtype, count=int(np.prod(chunk))).reshape(chunk)
+            sl_out, sl_in = [], []
+            for o, c, s in zip(offs[:-1], chunk, out.shape):
+                hi = min(o + c, s)
+                sl_out.append(slice(o, hi)); sl_in.append(slice(0, hi - o))
+            out[tuple(sl_out)] = block[tuple(sl_in)]
+
+    def __getitem__(self, key):
+        if self._shape is None:
+            return None
+        arr = self._f._decode(self._dt, self._shape, self._read_raw())
+        if key == () or key is Ellipsis:
+            return arr
+        return arr[key]
+
+    def __array__(self, dtype=None, copy=None):
+        a = self[()]
+        return a.astype(dtype) if dtype is not None else a
+
+    def __len__(self):
+        return self._shape[0]

@@ -1,0 +1,54 @@
+"""Keras legacy ``.h5`` model file -> (model_config dict, {layer: [weights]}).
+
+This is the file half of ``tf.keras.models.load_model(path)`` (reference predict.py:121): root
+attribute ``model_config`` (JSON) and group ``model_weights`` whose attr ``layer_names`` lists the
+layers, each layer group carrying ``weight_names`` and the datasets (``conv3d/kernel:0`` ...).
+``training_config`` (which references the custom metric ``top_3_cat_acc``, reference
+predict.py:24-25,88) is irrelevant for inference and ignored.  Uses h5py when importable, else the
+bundled pure-Python reader.
+"""
+from __future__ import annotations
+
+import json
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+
+def _open(path):
+    try:
+        import h5py  # type: ignore
+        return h5py.File(str(path), "r")
+    except ImportError:
+        from . import h5lite
+        return h5lite.File(path)
+
+
+def _text(v) -> str:
+    if isinstance(v, bytes):
+        return v.decode("utf-8")
+    if isinstance(v, np.ndarray) and v.shape == ():
+        return _text(v[()])
+    if isinstance(v, (np.bytes_, np.str_)):
+        return v.decode("utf-8") if isinstance(v, np.bytes_) else str(v)
+    return str(v)
+
+
+def _names(v) -> List[str]:
+    return [_text(x).rstrip("\0") for x in np.asarray(v).ravel()]
+
+
+def read_keras_h5(path) -> Tuple[dict, Dict[str, List[np.ndarray]]]:
+    with _open(path) as f:
+        if "model_config" not in f.attrs:
+            raise ValueError(f"{path}: no model_config attribute (weights-only file?)")
+        cfg = json.loads(_text(f.attrs["model_config"]))
+        if "model_weights" not in f:
+            raise ValueError(f"{path}: no model_weights group")
+        g = f["model_weights"]
+        weights: Dict[str, List[np.ndarray]] = {}
+        for lname in _names(g.attrs["layer_names"]):
+            lg = g[lname]
+            wn = _names(lg.attrs["weight_names"]) if "weight_names" in lg.attrs else []
+            weights[lname] = [np.asarray(lg[w][()], dtype=np.float32) for w in wn]
+    return cfg, weights
