@@ -44,18 +44,18 @@ def test_predict_end_to_end_from_h5_and_hdf5(gpu, tmp_path):
     want_seq = "".join(letters[csv.argmax(1)])
     assert got_seq == want_seq
     assert np.array_equal(np.genfromtxt(tmp_path / "encoded_labels.csv", delimiter=","), y)
-    assert (tmp_path / "keras_tiny.txt").read_text() == "ignore_uncommon False\ninclude_pdbs\n##########\n1ubqA 12\n2xyz 14\n"
+    assert (tmp_path / "keras_tiny.txt").read_text() == "ignore_uncommon False\ninclude_pdbs\n##########\n1ubqA 12\n2xyzA 3\n2xyzB 11\n"
     real = (tmp_path / "dataset.fasta").read_text().split("\n")
     three_to_one = dict(zip(["ALA", "CYS", "ASP", "GLU", "PHE", "GLY", "HIS", "ILE", "LYS", "LEU", "MET", "ASN", "PRO",
                              "GLN", "ARG", "SER", "THR", "VAL", "TRP", "TYR"], "ACDEFGHIKLMNPQRSTVWY"))
     assert real[1] + real[3] + real[5] == "".join(three_to_one[r[3]] for r in flat_ref)
     # resume semantics (reference predict.py:32,54-57): restart at batch 2 appends only the tail
-    out2 = tmp_path / "resume"
-    out2.mkdir()
+    # simulate a crash after two batches: keep the first 14 rows, then restart from batch 2 in the same directory
+    full_csv = (tmp_path / "keras_tiny.csv").read_text()
+    (tmp_path / "keras_tiny.csv").write_text("".join(full_csv.splitlines(True)[:14]))
     predict.load_dataset_and_predict([__import__("pathlib").Path(model_path)], data_path, batch_size=7, start_batch=2,
-                                     dataset_map_path=out2 / "datasetmap.txt", path_to_output=out2)
-    tail = np.genfromtxt(out2 / "keras_tiny.csv", delimiter=",")
-    assert np.array_equal(tail, csv[14:])
+                                     dataset_map_path=tmp_path / "datasetmap.txt", path_to_output=tmp_path)
+    assert (tmp_path / "keras_tiny.csv").read_text() == full_csv
 
 
 def test_predict_cli_parser_matches_reference_flags():

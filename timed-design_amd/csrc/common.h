@@ -109,6 +109,13 @@ void conv_mfma_pack_weights(const ConvMfmaPlan& p, const ConvGeom& g, int Cin, i
 int launch_conv_mfma(hipStream_t s, int64_t n, const ConvMfmaPlan& p, TView in, TView out, ConvGeom g, int Cin,
                      int Cout, const float* wpk, const float* bias, PreOp pre, PostOps post);
 
+// ---- first-layer convolution (conv_first.hip): Cin <= 8, Cout <= 32, 3x3x3, reads the caller's frames ----
+bool conv_first_plan(int Din, int Hin, int Win, int Cin, const TView& out_conv, const ConvGeom& g, int Cout, int pool,
+                     ConvMfmaPlan* plan);
+void conv_first_pack_weights(int Cin, int Cout, const float* w_keras, float* dst);
+int launch_conv_first(hipStream_t s, int64_t n, const ConvMfmaPlan& p, const void* frames, int dtype, int Din, int Hin,
+                      int Win, int Cin, TView out, ConvGeom g, int Cout, const float* wpk, const float* bias, PostOps post);
+
 // ---- sampler (sampler.hip) -----------------------------------------------------------------
 int sampler_run(int device, const double* h_probs, int64_t n_res, int n_cls, int64_t n_samples, double temperature,
                 int rng_mode, uint64_t seed, uint64_t rng_offset, const double* h_uniforms, int32_t* h_idx, double* h_r_out,

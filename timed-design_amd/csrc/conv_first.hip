@@ -1,0 +1,307 @@
+// First-layer fused Conv3D for gfx950: Conv3D(3x3x3, stride 1, Cin <= 8, Cout <= 32) + bias +
+// {act | BN-affine}* + optional 2x2x2 max/avg pool, reading the CALLER'S frames directly
+// (fp32 / fp64 / uint8 / bool / fp16 channels-last, exactly what load_batch builds — reference
+// design_utils/utils.py:518-527 — and what Keras' predict() casts to fp32 first).
+//
+// Why a separate kernel: the first TIMED block (6 -> 32 channels on 21^3 voxels) is 15 % of the
+// FLOPs but has a tiny K (27 taps x 6 channels), so the generic kernel's costs dominate it.  Here:
+//   * the whole weight tensor (27 x 32 x 8 floats) lives in REGISTERS: lane (j = l&31, h = l>>5)
+//     keeps, per tap, the 4 weights of output channel j that multiply the 4 channels the lane's MFMA
+//     k-slot covers -> no weight traffic and no barrier inside the K loop;
+//   * channel c sits in LDS slot (h = c&1, t = c>>1) of an 8-float voxel record, so MFMA step t
+//     contracts channels (2t, 2t+1): Cin = 5..6 needs 3 steps per tap, not 4 (no zero-padded MFMA);
+//   * no conversion pass: the staging loop reads the user's dtype and writes fp32 into LDS;
+//   * bricks of ZB output planes keep the LDS image under 80 KiB -> 2 workgroups per CU, whose
+//     staging / epilogue / ragged last round overlap each other's MFMA stream.
+// GEMM view per workgroup: M = ZB x Hc x Wc output voxels (rows grouped 8 pool-mates at a time when
+// pooled), N = 32, K = 27 x 2*NST.  v_mfma_f32_32x32x2_f32, exact fp32.
+#include "common.h"
+#include "device_math.h"
+
+#include <hip/hip_fp16.h>
+
+#include <algorithm>
+#include <cstring>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int kTaps = 27;
+
+struct ConvFirstArgs {
+    const void* in; int dtype; int Din, Hin, Win, Cin;
+    int pz, py, px;
+    int Dc, Hc, Wc;
+    int ZB, nzb, Zp, Hp, Wp, rows, n_mtiles, tab_off, vec8;
+    const float* wpk;
+    int Cout;
+    const float* bias;
+    PostOps post;
+    float* out; int64_t out_fs; int out_cs, out_coff, Ho, Wo;
+    int64_t nframes;
+};
+
+__device__ __forceinline__ float load_elem(const void* base, int dtype, int64_t i) {
+    switch (dtype) {
+        case TH_F32: return ((const float*)base)[i];
+        case TH_F64: return (float)((const double*)base)[i];
+        case TH_U8: return (float)((const unsigned char*)base)[i];
+        case TH_BOOL: return ((const unsigned char*)base)[i] ? 1.f : 0.f;
+        default: return __half2float(((const __half*)base)[i]);
+    }
+}
+
+template <int WAVES, int NST, int POOL>
+__global__ void __launch_bounds__(WAVES * 64, 3) k_conv_first(const ConvFirstArgs a) {
+    constexpr int NTHREADS = WAVES * 64;
+    extern __shared__ __attribute__((aligned(16))) float4 smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+
+    const int zb = blockIdx.x % a.nzb;
+    const int64_t f = blockIdx.x / a.nzb;
+    const int z0 = zb * a.ZB;
+    const int nvox = a.Zp * a.Hp * a.Wp;
+    // voxel record of REC = 2*NST floats; MFMA step t contracts channels (2t, 2t+1), lane half h supplies 2t+h.
+    //   NST=4: [c0 c2 c4 c6 | c1 c3 c5 c7]  one ds_read_b128 at 4h
+    //   NST=3: [c0 c2 | c1 c3 | c4 | c5]    ds_read_b64 at 2h + ds_read_b32 at 4+h   (24-byte records)
+    //   NST=2: [c0 c2 | c1 c3]              ds_read_b64 at 2h
+    //   NST=1: [c0 | c1]                    ds_read_b32 at h
+    constexpr int REC = 2 * NST;
+    float* A = reinterpret_cast<float*>(smem);
+    int* rowvox = (int*)(reinterpret_cast<char*>(smem) + a.tab_off);
+    int* rowout = rowvox + a.rows;
+
+    // ---- weights -> registers ------------------------------------------------------------------------
+    float4 breg[kTaps];
+    {
+        const float4* w4 = reinterpret_cast<const float4*>(a.wpk);
+#pragma unroll
+        for (int t = 0; t < kTaps; ++t) breg[t] = w4[(t * 2 + h) * 32 + j];
+    }
+
+    // ---- row tables ------------------------------------------------------------------------------------
+    {
+        const int ZBv = min(a.ZB, a.Dc - z0);
+        for (int r = tid; r < a.rows; r += NTHREADS) {
+            int vox = 0, oo = -1;
+            if (POOL == 0) {
+                const int hw = a.Hc * a.Wc;
+                if (r < ZBv * hw) {
+                    const int zl = r / hw, rem = r - zl * hw, y = rem / a.Wc, x = rem - y * a.Wc;
+                    vox = (zl * a.Hp + y) * a.Wp + x;
+                    oo = (((z0 + zl) * a.Ho + y) * a.Wo + x) * a.out_cs;
+                }
+                rowout[r] = oo;
+            } else {
+                const int pq = r >> 3, mate = r & 7;
+                const int PH = a.Hc >> 1, PW = a.Wc >> 1;
+                if (pq < (ZBv >> 1) * PH * PW) {
+                    const int pzz = pq / (PH * PW), rem = pq - pzz * (PH * PW), pyy = rem / PW, pxx = rem - pyy * PW;
+                    const int zl = 2 * pzz + (mate >> 2), y = 2 * pyy + ((mate >> 1) & 1), x = 2 * pxx + (mate & 1);
+                    vox = (zl * a.Hp + y) * a.Wp + x;
+                    oo = ((((z0 >> 1) + pzz) * a.Ho + pyy) * a.Wo + pxx) * a.out_cs;
+                }
+                if (mate == 0) rowout[r >> 3] = oo;
+            }
+            rowvox[r] = vox;
+        }
+    }
+
+    // ---- stage the haloed input brick straight from the caller's frames ------------------------------
+    {
+        const int64_t fbase = f * (int64_t)a.Din * a.Hin * a.Win * a.Cin;
+        const bool fast6 = (a.vec8 && NST == 3);  // 24-byte voxels: three 8-byte loads
+        for (int v = tid; v < nvox; v += NTHREADS) {
+            const int xl = v % a.Wp; int t = v / a.Wp;
+            const int yl = t % a.Hp; const int zl = t / a.Hp;
+            const int zi = z0 + zl - a.pz, yi = yl - a.py, xi = xl - a.px;
+            float e[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (zi >= 0 && zi < a.Din && yi >= 0 && yi < a.Hin && xi >= 0 && xi < a.Win) {
+                const int64_t base = fbase + ((int64_t)(zi * a.Hin + yi) * a.Win + xi) * a.Cin;
+                if (fast6) {
+                    const float2* p2 = reinterpret_cast<const float2*>((const float*)a.in + base);
+                    const float2 u0 = p2[0], u1 = p2[1], u2 = p2[2];
+                    e[0] = u0.x; e[1] = u0.y; e[2] = u1.x; e[3] = u1.y; e[4] = u2.x; e[5] = u2.y;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 2 * NST; ++c)
+                        if (c < a.Cin) e[c] = load_elem(a.in, a.dtype, base + c);
+                }
+            }
+            float* rec = A + (size_t)v * REC;
+            if (NST == 4) {
+                *reinterpret_cast<float4*>(rec) = make_float4(e[0], e[2], e[4], e[6]);
+                *reinterpret_cast<float4*>(rec + 4) = make_float4(e[1], e[3], e[5], e[7]);
+            } else if (NST == 3) {
+                *reinterpret_cast<float2*>(rec) = make_float2(e[0], e[2]);
+                *reinterpret_cast<float2*>(rec + 2) = make_float2(e[1], e[3]);
+                *reinterpret_cast<float2*>(rec + 4) = make_float2(e[4], e[5]);
+            } else if (NST == 2) {
+                *reinterpret_cast<float4*>(rec) = make_float4(e[0], e[2], e[1], e[3]);
+            } else {
+                *reinterpret_cast<float2*>(rec) = make_float2(e[0], e[1]);
+            }
+        }
+    }
+    __syncthreads();
+
+    const int rounds = (a.n_mtiles + WAVES - 1) / WAVES;
+    float* outb = a.out + f * a.out_fs + a.out_coff;
+    const int co = j;
+    const bool cok = co < a.Cout;
+    const int cc = cok ? co : 0;
+    const float bv = a.bias ? a.bias[cc] : 0.f;
+
+    for (int rd = 0; rd < rounds; ++rd) {
+        const int mt = rd * WAVES + wave;
+        if (mt >= a.n_mtiles) break;  // wave-uniform; no barriers below
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        const float* arow = A + (size_t)rowvox[mt * 32 + j] * REC;
+#pragma unroll
+        for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int t = (dz * 3 + dy) * 3 + dx;
+                    const float* rec = arow + ((dz * a.Hp + dy) * a.Wp + dx) * REC;
+                    float av[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (NST == 4) {
+                        const float4 q = *reinterpret_cast<const float4*>(rec + 4 * h);
+                        av[0] = q.x; av[1] = q.y; av[2] = q.z; av[3] = q.w;
+                    } else if (NST == 3) {
+                        const float2 q = *reinterpret_cast<const float2*>(rec + 2 * h);
+                        av[0] = q.x; av[1] = q.y; av[2] = rec[4 + h];
+                    } else if (NST == 2) {
+                        const float2 q = *reinterpret_cast<const float2*>(rec + 2 * h);
+                        av[0] = q.x; av[1] = q.y;
+                    } else {
+                        av[0] = rec[h];
+                    }
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], breg[t].x, acc, 0, 0, 0);
+                    if (NST > 1) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], breg[t].y, acc, 0, 0, 0);
+                    if (NST > 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], breg[t].z, acc, 0, 0, 0);
+                    if (NST > 3) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], breg[t].w, acc, 0, 0, 0);
+                }
+        // ---- epilogue in registers (see conv_mfma.hip for the row/lane layout) ----------------------
+        float x[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x[i] = th_post(acc[i] + bv, cc, a.post);
+        if (POOL == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int oo = cok ? rowout[mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h] : -1;
+                if (oo >= 0) outb[oo + co] = x[i];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float m;
+                if (POOL == 1) m = fmaxf(fmaxf(x[4 * q], x[4 * q + 1]), fmaxf(x[4 * q + 2], x[4 * q + 3]));
+                else m = (x[4 * q] + x[4 * q + 1]) + (x[4 * q + 2] + x[4 * q + 3]);
+                const float o2 = __shfl_xor(m, 32);
+                m = (POOL == 1) ? fmaxf(m, o2) : (m + o2) * 0.125f;
+                const int oo = cok ? rowout[mt * 4 + q] : -1;
+                if (oo >= 0 && (q >> 1) == h) outb[oo + co] = m;
+            }
+        }
+    }
+}
+
+typedef void (*FirstKernel)(const ConvFirstArgs);
+constexpr int kWaves = 4;
+#define ROW(NST) { k_conv_first<kWaves, NST, 0>, k_conv_first<kWaves, NST, 1>, k_conv_first<kWaves, NST, 2> }
+const FirstKernel kFirstKernels[4][3] = {ROW(1), ROW(2), ROW(3), ROW(4)};
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+}  // namespace
+
+bool conv_first_plan(int Din, int Hin, int Win, int Cin, const TView& oc, const ConvGeom& g, int Cout, int pool,
+                     ConvMfmaPlan* p) {
+    if (g.kd != 3 || g.kh != 3 || g.kw != 3) return false;
+    if (g.sd != 1 || g.sh != 1 || g.sw != 1 || g.dd != 1 || g.dh != 1 || g.dw != 1) return false;
+    if (Cin < 1 || Cin > 8 || Cout > 32) return false;
+    if (pool && (oc.D < 2 || oc.H < 2 || oc.W < 2)) return false;
+    p->cfg = 100;  // marks the first-layer kernel
+    p->CI = 8; p->CS = 8; p->BN = 32; p->nnb = 1; p->nchunks = 1; p->pool = pool; p->bres = 1; p->FB = 1;
+    p->Dc = pool ? (oc.D / 2) * 2 : oc.D;
+    p->Hc = pool ? (oc.H / 2) * 2 : oc.H;
+    p->Wc = pool ? (oc.W / 2) * 2 : oc.W;
+    p->Hp = p->Hc + 2;
+    p->Wp = p->Wc + 2;
+    auto rows_for = [&](int zb) {
+        return round_up(pool ? 8 * ((zb / 2) * (p->Hc / 2) * (p->Wc / 2)) : zb * p->Hc * p->Wc, 32);
+    };
+    const int nst = (Cin + 1) / 2;
+    const size_t rec_bytes = (size_t)8 * nst;
+    auto img_for = [&](int zb) { return ((size_t)(zb + 2) * p->Hp * p->Wp * rec_bytes + 15) / 16 * 16; };
+    auto lds_for = [&](int zb) {
+        const int rows = rows_for(zb);
+        return img_for(zb) + (size_t)rows * 4 + (size_t)(pool ? rows / 8 : rows) * 4;
+    };
+    const int step = pool ? 2 : 1;
+    // prefer bricks that leave room for two workgroups per CU (<= 80 KiB); fall back to one per CU
+    int ZB = 0;
+    for (size_t limit : {(size_t)160 * 1024 / 3, (size_t)80 * 1024, (size_t)160 * 1024}) {
+        for (int zb = p->Dc; zb >= step; zb -= step)
+            if (lds_for(zb) <= limit) { ZB = zb; break; }
+        if (ZB) break;
+    }
+    if (!ZB) return false;
+    for (int zb = ZB; zb >= step && zb * 10 >= ZB * 6; zb -= step)
+        if (p->Dc % zb == 0) { ZB = zb; break; }
+    p->ZB = ZB;
+    p->nzb = (p->Dc + ZB - 1) / ZB;
+    p->Zp = ZB + 2;
+    p->rows_pf = rows_for(ZB);
+    p->lds_bytes = lds_for(ZB);
+    p->tab_off = img_for(ZB);
+    p->wpk_floats = (size_t)kTaps * 2 * 32 * 4;
+    p->exec_flops = 2.0 * (double)p->nzb * p->rows_pf * 32.0 * (2.0 * nst) * kTaps;
+    if (oc.fs > 0x7fffffffLL) return false;
+    char buf[160];
+    snprintf(buf, sizeof buf, "conv_first<w%d,nst%d,pool%d> ZB%d/%d rows%d lds%zuK (weights in VGPRs, direct input)", kWaves,
+             nst, pool, ZB, p->Dc, p->rows_pf, p->lds_bytes / 1024);
+    p->label = buf;
+    return true;
+}
+
+// Keras [3,3,3,Cin,Cout] -> [tap][h][co(32)][t(4)] with channel c = 2t + h
+void conv_first_pack_weights(int Cin, int Cout, const float* w, float* dst) {
+    std::memset(dst, 0, (size_t)kTaps * 2 * 32 * 4 * sizeof(float));
+    for (int tap = 0; tap < kTaps; ++tap)
+        for (int c = 0; c < Cin; ++c)
+            for (int co = 0; co < Cout; ++co)
+                dst[(((size_t)tap * 2 + (c & 1)) * 32 + co) * 4 + (c >> 1)] = w[((size_t)tap * Cin + c) * Cout + co];
+}
+
+int launch_conv_first(hipStream_t s, int64_t n, const ConvMfmaPlan& p, const void* frames, int dtype, int Din, int Hin,
+                      int Win, int Cin, TView out, ConvGeom g, int Cout, const float* wpk, const float* bias, PostOps post) {
+    ConvFirstArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.in = frames; a.dtype = dtype; a.Din = Din; a.Hin = Hin; a.Win = Win; a.Cin = Cin;
+    a.pz = g.pz; a.py = g.py; a.px = g.px;
+    a.Dc = p.Dc; a.Hc = p.Hc; a.Wc = p.Wc;
+    a.ZB = p.ZB; a.nzb = p.nzb; a.Zp = p.Zp; a.Hp = p.Hp; a.Wp = p.Wp;
+    a.rows = p.rows_pf; a.n_mtiles = p.rows_pf / 32; a.tab_off = (int)p.tab_off;
+    a.wpk = wpk; a.Cout = Cout; a.bias = bias; a.post = post;
+    a.out = out.p; a.out_fs = out.fs; a.out_cs = out.cs; a.out_coff = out.coff; a.Ho = out.H; a.Wo = out.W;
+    a.nframes = n;
+    a.vec8 = (dtype == TH_F32 && Cin == 6 && ((uintptr_t)frames % 8) == 0) ? 1 : 0;
+    const int64_t grid = n * p.nzb;
+    if (grid > 0x7fffffffLL) TH_FAIL(TH_EINVAL, "conv_first: grid too large");
+    const int nst = (Cin + 1) / 2;
+    FirstKernel k = kFirstKernels[nst - 1][p.pool];
+    HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kWaves * 64), p.lds_bytes, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) TH_FAIL(TH_EHIP, "conv_first launch failed: %s (%s)", hipGetErrorString(e), p.label.c_str());
+    return TH_OK;
+}

@@ -6,7 +6,8 @@
 __device__ __forceinline__ float th_act(float x, int act, float alpha) {
     switch (act) {
         case ACT_RELU: return fmaxf(x, 0.f);
-        case ACT_ELU: return x > 0.f ? x : alpha * expm1f(x);
+        // exp via the hardware exp2 path (~2 ulp): |error| <= 1.2e-7 absolute on the negative branch
+        case ACT_ELU: return x > 0.f ? x : alpha * (__expf(x) - 1.f);
         case ACT_LEAKY: return x > 0.f ? x : alpha * x;
         case ACT_SIGMOID: return 1.f / (1.f + expf(-x));
         case ACT_TANH: return tanhf(x);

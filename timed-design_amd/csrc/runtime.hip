@@ -114,6 +114,9 @@ struct th_model {
     float* d_out_stage = nullptr;
     size_t out_stage_floats = 0;
     int64_t last_n = 0;
+    const void* cur_in = nullptr;  // caller's frames for the chunk in flight (first-layer kernel reads them directly)
+    int cur_dtype = TH_F32;
+    bool need_convert = true;      // some consumer of the input needs the fp32 arena copy
 
     TView view(int node) const {
         const Node& nd = nodes[node];
@@ -327,13 +330,17 @@ int plan(th_model* m) {
             TView ov; ov.D = n.D; ov.H = n.H; ov.W = n.W; ov.C = n.C; ov.fs = (int64_t)n.D * n.H * n.W * n.C;
             ConvMfmaPlan mp;
             bool ok = false;
-            if (use_mfma) {
+            if (use_mfma && fuse && f.src == m->input_node && f.pre.empty()) {
+                if (f.pool >= 0) ok = conv_first_plan(src.D, src.H, src.W, src.C, ov, g, n.C, N[f.pool].op == OP_MAXPOOL ? 1 : 2, &mp);
+                if (!ok && f.pool < 0) ok = conv_first_plan(src.D, src.H, src.W, src.C, ov, g, n.C, 0, &mp);
+            }
+            if (!ok && use_mfma) {
                 if (f.pool >= 0) {
                     ok = conv_mfma_plan(iv, ov, g, src.C, n.C, N[f.pool].op == OP_MAXPOOL ? 1 : 2, &mp);
                     if (!ok) f.pool = -1;
                 }
                 if (!ok) ok = conv_mfma_plan(iv, ov, g, src.C, n.C, 0, &mp);
-            } else {
+            } else if (!ok) {
                 f.pool = -1;
             }
             if (ok) mplans[i] = mp;
@@ -346,6 +353,14 @@ int plan(th_model* m) {
         if (f.last != i) n.absorbed_by = i;  // the conv's own raw output is never materialised
         fus[i] = f;
     }
+    // does anything still need the converted fp32 copy of the input?
+    m->need_convert = false;
+    for (int c : N[m->input_node].consumers) {
+        bool direct = false;
+        for (auto& kv : fus) if (kv.second.src == m->input_node && (kv.first == c) && mplans.count(kv.first) && mplans[kv.first].cfg == 100) direct = true;
+        if (!direct) m->need_convert = true;
+    }
+    if (m->output_node == m->input_node) m->need_convert = true;
     // which node outputs exist in memory
     for (int i = 0; i < nn; ++i) N[i].materialised = N[i].absorbed_by < 0;
     for (auto& kv : fus) N[kv.second.last].materialised = true;
@@ -446,7 +461,20 @@ int plan(th_model* m) {
                     if (M->blob_count[n.w[0]] != wcount) TH_FAIL(TH_EIO, "%s: kernel size mismatch", n.name.c_str());
                     st.flops = 2.0 * n.D * n.H * n.W * (double)g.kd * g.kh * g.kw * Cin * Cout;
                     st.bytes = 4.0 * ((double)sn.D * sn.H * sn.W * Cin + (double)N[dst].D * N[dst].H * N[dst].W * N[dst].C);
-                    if (mplans.count(i)) {
+                    if (mplans.count(i) && mplans[i].cfg == 100) {
+                        const ConvMfmaPlan mp = mplans[i];
+                        std::vector<float> packed(mp.wpk_floats);
+                        conv_first_pack_weights(Cin, Cout, hw, packed.data());
+                        float* dw;
+                        if ((rc = upload(M, packed.data(), packed.size(), &dw))) return rc;
+                        st.exec_flops = mp.exec_flops;
+                        st.label = n.name + ": " + mp.label;
+                        const int iD = sn.D, iH = sn.H, iW = sn.W;
+                        st.run = [=](hipStream_t s, int64_t cnt) {
+                            return launch_conv_first(s, cnt, mp, M->cur_in, M->cur_dtype, iD, iH, iW, Cin, M->view(dst), g, Cout,
+                                                     dw, dbias, po);
+                        };
+                    } else if (mplans.count(i)) {
                         const ConvMfmaPlan mp = mplans[i];
                         std::vector<float> packed(mp.wpk_floats);
                         conv_mfma_pack_weights(mp, g, Cin, Cout, hw, packed.data());
@@ -639,9 +667,12 @@ int run_device(th_model* m, const void* d_frames, int dtype, int64_t n, float* d
     std::vector<int> ev_step;
     for (int64_t off = 0; off < n; off += m->chunk) {
         const int64_t cnt = std::min<int64_t>(m->chunk, n - off);
-        rc = launch_convert_frames(m->stream, (const char*)d_frames + (size_t)off * frame_bytes, dtype, cnt, Vin, in.C,
-                                   m->view(m->input_node));
-        if (rc) return rc;
+        m->cur_in = (const char*)d_frames + (size_t)off * frame_bytes;
+        m->cur_dtype = dtype;
+        if (m->need_convert) {
+            rc = launch_convert_frames(m->stream, m->cur_in, dtype, cnt, Vin, in.C, m->view(m->input_node));
+            if (rc) return rc;
+        }
         for (size_t si = 0; si < m->steps.size(); ++si) {
             Step& st = m->steps[si];
             if (logits && st.is_final_softmax) continue;
