@@ -26,6 +26,7 @@
 #include "device_math.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -39,7 +40,7 @@ struct ConvMfmaArgs {
     int kd, kh, kw, pz, py, px, ntaps;
     int Dc, Hc, Wc;
     int FB, ZB, nzb, Zp, Hp, Wp, rows_pf, nrows, n_mtiles;
-    int CS, nchunks, nnb, tab_off;
+    int CS, nchunks, nnb, tab_off, dbg;  // dbg: timing experiments only (TH_CONV_DBG), results are wrong when set
     const float* wpk;
     int Cout;
     const float* bias;
@@ -50,7 +51,7 @@ struct ConvMfmaArgs {
 };
 
 template <int WAVES, int TM, int TN, int NT, int CI, int BRES, int POOL>
-__global__ void __launch_bounds__(WAVES * 64) k_conv_mfma(const ConvMfmaArgs a) {
+__global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(const ConvMfmaArgs a) {
     constexpr int NTHREADS = WAVES * 64;
     constexpr int BN = NT * 32;
     constexpr int CI4 = CI / 4;
@@ -79,6 +80,20 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_mfma(const ConvMfmaArgs a) 
     const int nbslabs = BRES ? a.ntaps : 2;
     int* rowvox = (int*)(reinterpret_cast<char*>(smem) + a.tab_off);
     int* rowout = rowvox + a.nrows;
+    int* tapoff = rowout + (POOL ? a.nrows / 8 : a.nrows);  // staged-voxel offset of every tap
+    for (int t = tid; t < a.ntaps; t += NTHREADS) {
+        const int dz = t / (a.kh * a.kw), r2 = t - dz * (a.kh * a.kw), dy = r2 / a.kw, dx = r2 - dy * a.kw;
+        tapoff[t] = (dz * a.Hp + dy) * a.Wp + dx;
+    }
+    int* voxsrc = tapoff + a.ntaps;  // staged voxel -> source offset (floats, relative to frame f0) or -1
+    for (int v = tid; v < nvox; v += NTHREADS) {
+        const int xl = v % a.Wp; int t = v / a.Wp;
+        const int yl = t % a.Hp; t /= a.Hp;
+        const int zl = t % a.Zp; const int f = t / a.Zp;
+        const int zi = z0 + zl - a.pz, yi = yl - a.py, xi = xl - a.px;
+        const bool ok = (f0 + f) < a.nframes && zi >= 0 && zi < a.Din && yi >= 0 && yi < a.Hin && xi >= 0 && xi < a.Win;
+        voxsrc[v] = ok ? f * (int)a.in_fs + ((zi * a.Hin + yi) * a.Win + xi) * a.in_cs : -1;
+    }
 
     // ---- row tables: GEMM row -> staged voxel index, and -> output offset -----------------------
     {
@@ -142,33 +157,52 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_mfma(const ConvMfmaArgs a) 
 
         for (int ch = 0; ch < a.nchunks; ++ch) {
             constexpr bool kLdsEpi = (TM * TN > 2);  // the LDS epilogue clobbers the staging area
-            const bool need_a = kLdsEpi || !(a.nchunks == 1 && rd > 0);
-            const bool need_b = BRES ? need_a : true;
+            const bool need_a = (kLdsEpi || !(a.nchunks == 1 && rd > 0)) && !((a.dbg & 1) && ch > 0);
+            const bool need_b = BRES == 2 ? false : (BRES ? need_a : true);
             __syncthreads();  // everyone is done reading the previous A image / B slabs
             if (need_a) {
                 // ---- stage the haloed input brick for channels [ch*CI, ch*CI+CI) ------------------
+                // voxsrc[v] (built once per workgroup) holds the source offset of staged voxel v or -1 for
+                // halo / out-of-range: no index arithmetic here, and loads go out 4 at a time so their L2
+                // latencies overlap instead of serialising.
+                constexpr int U = 4;
                 const int nvec = nvox * CI4;
-                for (int i = tid; i < nvec; i += NTHREADS) {
-                    const int v = i / CI4, g = i - v * CI4;
-                    const int xl = v % a.Wp; int t = v / a.Wp;
-                    const int yl = t % a.Hp; t /= a.Hp;
-                    const int zl = t % a.Zp; const int f = t / a.Zp;
-                    const int zi = z0 + zl - a.pz, yi = yl - a.py, xi = xl - a.px;
-                    const int c0 = ch * CI + g * 4;
-                    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if ((f0 + f) < a.nframes && zi >= 0 && zi < a.Din && yi >= 0 && yi < a.Hin && xi >= 0 && xi < a.Win &&
-                        c0 < a.Cin) {
-                        const float* src = a.in + (f0 + f) * a.in_fs + ((int64_t)(zi * a.Hin + yi) * a.Win + xi) * a.in_cs +
-                                           a.in_coff + c0;
-                        float e[4];
-                        if (a.vec_ok && c0 + 4 <= a.Cin) {
-                            const float4 q4 = *reinterpret_cast<const float4*>(src);
-                            e[0] = q4.x; e[1] = q4.y; e[2] = q4.z; e[3] = q4.w;
-                        } else {
+                const float* inb = a.in + f0 * a.in_fs + a.in_coff + ch * CI;
+                const bool has_pre = a.pre.scale || a.pre.act != ACT_LINEAR;
+                for (int base = tid; base < nvec; base += NTHREADS * U) {
+                    int off[U];
+                    float4 val[U];
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) e[k] = (c0 + k < a.Cin) ? src[k] : 0.f;
+                    for (int u = 0; u < U; ++u) {
+                        const int i = base + u * NTHREADS;
+                        off[u] = (i < nvec) ? voxsrc[i / CI4] : -1;
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int i = base + u * NTHREADS;
+                        const int g = i % CI4;
+                        const int c0 = ch * CI + g * 4;
+                        val[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (off[u] >= 0 && c0 < a.Cin) {
+                            const float* src = inb + off[u] + g * 4;
+                            if (a.vec_ok && c0 + 4 <= a.Cin) {
+                                val[u] = *reinterpret_cast<const float4*>(src);
+                            } else {
+                                val[u].x = src[0];
+                                if (c0 + 1 < a.Cin) val[u].y = src[1];
+                                if (c0 + 2 < a.Cin) val[u].z = src[2];
+                                if (c0 + 3 < a.Cin) val[u].w = src[3];
+                            }
                         }
-                        if (a.pre.scale || a.pre.act != ACT_LINEAR) {
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int i = base + u * NTHREADS;
+                        if (i >= nvec) continue;
+                        const int v = i / CI4, g = i % CI4;
+                        if (has_pre && off[u] >= 0) {
+                            const int c0 = ch * CI + g * 4;
+                            float e[4] = {val[u].x, val[u].y, val[u].z, val[u].w};
 #pragma unroll
                             for (int k = 0; k < 4; ++k) {
                                 if (c0 + k < a.Cin) {
@@ -177,10 +211,10 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_mfma(const ConvMfmaArgs a) 
                                     e[k] = th_act(x, a.pre.act, a.pre.alpha);
                                 }
                             }
+                            val[u] = make_float4(e[0], e[1], e[2], e[3]);
                         }
-                        val = make_float4(e[0], e[1], e[2], e[3]);
+                        A4[(size_t)v * CS4 + g] = val[u];
                     }
-                    A4[(size_t)v * CS4 + g] = val;
                 }
             }
             const float4* wch4 = wbase4 + (size_t)ch * a.ntaps * bslab4;
@@ -190,7 +224,118 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_mfma(const ConvMfmaArgs a) 
             }
             __syncthreads();
 
-            if (BRES) {
+            if (BRES == 2) {
+                // weights streamed L2 -> registers, one tap ahead: every lane fetches exactly its own MFMA
+                // B fragments (host layout [nb][chunk][tap][kk][ntile][lane] float4, 1 KiB per wave-load), so
+                // there is no weight slab in LDS and NO barrier inside a Cin-chunk — the 8 waves drift apart
+                // and cover each other's LDS latency.
+                if (active) {
+                    constexpr int TAPSTRIDE = KK * NT * 64;
+                    const float4* wf = reinterpret_cast<const float4*>(a.wpk) +
+                                       ((size_t)(nb * a.nchunks + ch) * a.ntaps) * TAPSTRIDE + (nbw * TN) * 64 + lane;
+                    // Software pipeline, pinned with sched_barrier so hipcc cannot sink the loads back next to
+                    // their uses.  Per stage (= 8 input channels of one tap): the NEXT stage's A fragments are
+                    // requested from LDS before this stage's TM*TN*4 MFMAs and consumed after them (ping-pong
+                    // register sets, no copies); a stage's B fragments are re-loaded for the next tap right
+                    // after their last use, so they have a whole stage (>= 2048 MFMA cycles) to arrive from L2.
+                    // Tap offsets come from scalar counters: no memory access, no wait, on the address path.
+                    int tz = 0, ty = 0, tx = 0;  // coordinates of the NEXT tap
+                    auto advance = [&]() {       // returns the staged-voxel offset of the next tap (clamped at the end)
+                        if (tx + 1 < a.kw) ++tx;
+                        else if (ty + 1 < a.kh) { tx = 0; ++ty; }
+                        else if (tz + 1 < a.kd) { tx = 0; ty = 0; ++tz; }
+                        return ((tz * a.Hp + ty) * a.Wp + tx) * CS4;
+                    };
+                    if (KK == 2) {
+                        float4 bc[2][TN], avA[TM], avB[TM];
+#pragma unroll
+                        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                            for (int tn = 0; tn < TN; ++tn) bc[kk][tn] = wf[(kk * NT + tn) * 64];
+#pragma unroll
+                        for (int tm = 0; tm < TM; ++tm) avA[tm] = A4[aidx[tm]];
+                        int toff_cur = 0;
+                        for (int tap = 0; tap < a.ntaps; ++tap) {
+                            const int toff_nxt = advance();
+                            const float4* wn = wf + (size_t)min(tap + 1, a.ntaps - 1) * TAPSTRIDE;
+                            // ---- stage 0 ----
+#pragma unroll
+                            for (int tm = 0; tm < TM; ++tm) avB[tm] = A4[aidx[tm] + toff_cur + 2];
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                                for (int tn = 0; tn < TN; ++tn) {
+                                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(avA[tm].x, bc[0][tn].x, acc[tm][tn], 0, 0, 0);
+                                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(avA[tm].y, bc[0][tn].y, acc[tm][tn], 0, 0, 0);
+                                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(avA[tm].z, bc[0][tn].z, acc[tm][tn], 0, 0, 0);
+                                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(avA[tm].w, bc[0][tn].w, acc[tm][tn], 0, 0, 0);
+                                }
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int tn = 0; tn < TN; ++tn) bc[0][tn] = wn[tn * 64];
+                            // ---- stage 1 ----
+#pragma unroll
+                            for (int tm = 0; tm < TM; ++tm) avA[tm] = A4[aidx[tm] + toff_nxt];
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                                for (int tn = 0; tn < TN; ++tn) {
+                                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(avB[tm].x, bc[1][tn].x, acc[tm][tn], 0, 0, 0);
+                                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(avB[tm].y, bc[1][tn].y, acc[tm][tn], 0, 0, 0);
+                                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(avB[tm].z, bc[1][tn].z, acc[tm][tn], 0, 0, 0);
+                                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(avB[tm].w, bc[1][tn].w, acc[tm][tn], 0, 0, 0);
+                                }
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int tn = 0; tn < TN; ++tn) bc[1][tn] = wn[(NT + tn) * 64];
+                            toff_cur = toff_nxt;
+                        }
+                    } else {
+                        float4 bcur[KK][TN], bnxt[KK][TN], av[TM], avn[TM];
+#pragma unroll
+                        for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+                            for (int tn = 0; tn < TN; ++tn) bcur[kk][tn] = wf[(kk * NT + tn) * 64];
+#pragma unroll
+                        for (int tm = 0; tm < TM; ++tm) av[tm] = A4[aidx[tm]];
+                        int toff_cur = 0;
+                        for (int tap = 0; tap < a.ntaps; ++tap) {
+                            const int toff_nxt = advance();
+                            const float4* wn = wf + (size_t)min(tap + 1, a.ntaps - 1) * TAPSTRIDE;
+#pragma unroll
+                            for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+                                for (int tn = 0; tn < TN; ++tn) bnxt[kk][tn] = wn[(kk * NT + tn) * 64];
+#pragma unroll
+                            for (int kk = 0; kk < KK; ++kk) {
+                                const int noff = (kk + 1 < KK) ? toff_cur + (kk + 1) * 2 : toff_nxt;
+#pragma unroll
+                                for (int tm = 0; tm < TM; ++tm) avn[tm] = A4[aidx[tm] + noff];
+                                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                                    for (int tn = 0; tn < TN; ++tn) {
+                                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm].x, bcur[kk][tn].x, acc[tm][tn], 0, 0, 0);
+                                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm].y, bcur[kk][tn].y, acc[tm][tn], 0, 0, 0);
+                                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm].z, bcur[kk][tn].z, acc[tm][tn], 0, 0, 0);
+                                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm].w, bcur[kk][tn].w, acc[tm][tn], 0, 0, 0);
+                                    }
+                                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                for (int tm = 0; tm < TM; ++tm) av[tm] = avn[tm];
+                            }
+#pragma unroll
+                            for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+                                for (int tn = 0; tn < TN; ++tn) bcur[kk][tn] = bnxt[kk][tn];
+                            toff_cur = toff_nxt;
+                        }
+                    }
+                }
+            } else if (BRES) {
                 if (active) {
                     int tap = 0;
                     for (int dz = 0; dz < a.kd; ++dz)
@@ -371,6 +516,12 @@ const CfgDesc kCfgs[] = {
     {8, 4, 2, 4, 16, 0},  // 2: BN=128
     {8, 2, 1, 1, 16, 0},  // 3: BN=32
     {8, 2, 2, 2, 8, 1},   // 4: Cin<=8, BN=64
+    {8, 4, 2, 2, 16, 2},  // 5: BN=64,  weights streamed L2 -> registers
+    {8, 4, 2, 4, 16, 2},  // 6: BN=128, streamed
+    {8, 2, 1, 1, 16, 2},  // 7: BN=32,  streamed
+    {4, 4, 2, 2, 16, 2},  // 8: 4-wave workgroups (two per CU: one's staging hides under the other's MFMAs)
+    {4, 4, 2, 4, 16, 2},  // 9
+    {4, 2, 1, 1, 16, 2},  // 10
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -380,18 +531,16 @@ typedef void (*ConvKernel)(const ConvMfmaArgs);
 const ConvKernel kKernels[kNumCfgs][3] = {
     CFG_ROW(8, 1, 1, 1, 8, 1), CFG_ROW(8, 4, 2, 2, 16, 0), CFG_ROW(8, 4, 2, 4, 16, 0),
     CFG_ROW(8, 2, 1, 1, 16, 0), CFG_ROW(8, 2, 2, 2, 8, 1),
+    CFG_ROW(8, 4, 2, 2, 16, 2), CFG_ROW(8, 4, 2, 4, 16, 2), CFG_ROW(8, 2, 1, 1, 16, 2),
+    CFG_ROW(4, 4, 2, 2, 16, 2), CFG_ROW(4, 4, 2, 4, 16, 2), CFG_ROW(4, 2, 1, 1, 16, 2),
 };
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 }  // namespace
 
-bool conv_mfma_plan(const TView& in, const TView& oc, const ConvGeom& g, int Cin, int Cout, int pool, ConvMfmaPlan* p) {
-    if (g.sd != 1 || g.sh != 1 || g.sw != 1 || g.dd != 1 || g.dh != 1 || g.dw != 1) return false;
-    if (pool && (oc.D < 2 || oc.H < 2 || oc.W < 2)) return false;
-    int cfg;
-    if (Cin <= 8) cfg = Cout <= 32 ? 0 : (Cout <= 64 ? 4 : 2);
-    else cfg = Cout <= 32 ? 3 : (Cout <= 64 ? 1 : 2);
+static bool plan_with_cfg(int cfg, size_t lds_limit, bool whole_frames_only, const TView& in, const TView& oc,
+                          const ConvGeom& g, int Cin, int Cout, int pool, ConvMfmaPlan* p) {
     const CfgDesc& c = kCfgs[cfg];
     p->cfg = cfg;
     p->CI = c.CI;
@@ -407,30 +556,34 @@ bool conv_mfma_plan(const TView& in, const TView& oc, const ConvGeom& g, int Cin
     p->Hp = p->Hc + g.kh - 1;
     p->Wp = p->Wc + g.kw - 1;
     const int ntaps = g.kd * g.kh * g.kw;
-    const size_t bbytes = (size_t)(c.BRES ? ntaps : 2) * p->BN * p->CS * 4;
+    const size_t bbytes = c.BRES == 2 ? 0 : (size_t)(c.BRES ? ntaps : 2) * p->BN * p->CS * 4;
     auto rows_for = [&](int zb) {
         const int r = pool ? 8 * ((zb / 2) * (p->Hc / 2) * (p->Wc / 2)) : zb * p->Hc * p->Wc;
         return round_up(r, 32);
     };
-    auto lds_for = [&](int fb, int zb) {
+    auto tab_bytes = [&](int fb, int zb) {
         const size_t nvox = (size_t)fb * (zb + g.kd - 1) * p->Hp * p->Wp;
         const int nrows = fb * rows_for(zb);
-        return std::max(nvox * p->CS * 4 + bbytes, (size_t)c.WAVES * 32 * 33 * 4) + (size_t)nrows * 4 +
-               (size_t)(pool ? nrows / 8 : nrows) * 4;
+        return (size_t)nrows * 4 + (size_t)(pool ? nrows / 8 : nrows) * 4 + (size_t)ntaps * 4 + nvox * 4;
+    };
+    auto lds_for = [&](int fb, int zb) {
+        const size_t nvox = (size_t)fb * (zb + g.kd - 1) * p->Hp * p->Wp;
+        return std::max(nvox * p->CS * 4 + bbytes, (size_t)c.WAVES * 32 * 33 * 4) + tab_bytes(fb, zb);
     };
     const int max_mt = c.WAVES * c.TM * c.TN / c.NT;  // m-tiles one round covers
     int FB = 0, ZB = 0;
-    if (lds_for(1, p->Dc) <= kLdsLimit) {
+    if (lds_for(1, p->Dc) <= lds_limit && (p->nchunks == 1 || rows_for(p->Dc) / 32 <= max_mt || !whole_frames_only)) {
         ZB = p->Dc;
         FB = 1;
-        while (FB < 16 && lds_for(FB + 1, ZB) <= kLdsLimit &&
+        while (FB < 16 && lds_for(FB + 1, ZB) <= lds_limit &&
                (p->nchunks == 1 || (FB + 1) * rows_for(ZB) / 32 <= max_mt))
             ++FB;
     } else {
+        if (whole_frames_only) return false;
         FB = 1;
         const int step = pool ? 2 : 1;
         for (int zb = p->Dc - step; zb >= step; zb -= step)
-            if (lds_for(1, zb) <= kLdsLimit) { ZB = zb; break; }
+            if (lds_for(1, zb) <= lds_limit) { ZB = zb; break; }
         if (ZB == 0) return false;
         // prefer a brick height that divides the extent evenly if one exists at >= 60% of the max
         for (int zb = ZB; zb >= step && zb * 10 >= ZB * 6; zb -= step)
@@ -442,21 +595,61 @@ bool conv_mfma_plan(const TView& in, const TView& oc, const ConvGeom& g, int Cin
     p->Zp = ZB + g.kd - 1;
     p->rows_pf = rows_for(ZB);
     p->lds_bytes = lds_for(FB, ZB);
-    p->tab_off = p->lds_bytes - ((size_t)FB * p->rows_pf * 4 + (size_t)(pool ? FB * p->rows_pf / 8 : FB * p->rows_pf) * 4);
-    p->wpk_floats = (size_t)p->nnb * p->nchunks * ntaps * p->BN * p->CS;
+    p->tab_off = p->lds_bytes - tab_bytes(FB, ZB);
+    p->wpk_floats = (size_t)p->nnb * p->nchunks * ntaps * p->BN * (c.BRES == 2 ? c.CI : p->CS);
     const double rows_exec = (double)p->nzb * p->rows_pf;  // per frame
     p->exec_flops = 2.0 * rows_exec * (double)(p->nnb * p->BN) * (double)(p->nchunks * c.CI) * ntaps;
-    if ((int64_t)FB * oc.fs > 0x7fffffffLL) return false;
+    if ((int64_t)FB * oc.fs > 0x7fffffffLL || (int64_t)FB * in.D * in.H * in.W * std::max(in.cs, in.C) > 0x7fffffffLL) return false;
     char buf[160];
     snprintf(buf, sizeof buf, "conv_mfma<w%d,%dx%d,nt%d,ci%d,%s,pool%d> FB%d ZB%d/%d rows%d lds%zuK", c.WAVES, c.TM,
-             c.TN, c.NT, c.CI, c.BRES ? "res" : "dbuf", pool, FB, ZB, p->Dc, p->rows_pf, p->lds_bytes / 1024);
+             c.TN, c.NT, c.CI, c.BRES == 2 ? "stream" : (c.BRES ? "res" : "dbuf"), pool, FB, ZB, p->Dc, p->rows_pf, p->lds_bytes / 1024);
     p->label = buf;
     return true;
+}
+
+bool conv_mfma_plan(const TView& in, const TView& oc, const ConvGeom& g, int Cin, int Cout, int pool, ConvMfmaPlan* p) {
+    if (g.sd != 1 || g.sh != 1 || g.sw != 1 || g.dd != 1 || g.dh != 1 || g.dw != 1) return false;
+    if (pool && (oc.D < 2 || oc.H < 2 || oc.W < 2)) return false;
+    int cfg;
+    if (Cin <= 8) cfg = Cout <= 32 ? 0 : (Cout <= 64 ? 4 : 2);
+    else cfg = Cout <= 32 ? 3 : (Cout <= 64 ? 1 : 2);
+    // TH_CONV_BMODE=dbuf keeps the LDS double-buffered weight slabs, =stream8 the 8-wave streamed kernels
+    // (A/B comparisons); default: weights streamed L2 -> registers, two 4-wave workgroups per CU when whole
+    // frames fit in half the LDS
+    const char* mode = getenv("TH_CONV_BMODE");
+    const bool dbuf = mode && std::strcmp(mode, "dbuf") == 0;
+    const bool stream8 = mode && std::strcmp(mode, "stream8") == 0;
+    if (!dbuf && cfg >= 1 && cfg <= 3) {
+        if (!stream8 && plan_with_cfg(cfg + 7, kLdsLimit / 2, true, in, oc, g, Cin, Cout, pool, p)) return true;
+        cfg += 4;
+    }
+    return plan_with_cfg(cfg, kLdsLimit, false, in, oc, g, Cin, Cout, pool, p);
 }
 
 void conv_mfma_pack_weights(const ConvMfmaPlan& p, const ConvGeom& g, int Cin, int Cout, const float* w, float* dst) {
     const int ntaps = g.kd * g.kh * g.kw;
     std::memset(dst, 0, p.wpk_floats * sizeof(float));
+    if (p.bres == 2) {
+        // fragment order: [nb][chunk][tap][kk][ntile][h][j][t]  with  ci = chunk*CI + kk*8 + 4h + t,  co = nb*BN + ntile*32 + j
+        const int KK = p.CI / 8, NT = p.BN / 32;
+        for (int nb = 0; nb < p.nnb; ++nb)
+            for (int ch = 0; ch < p.nchunks; ++ch)
+                for (int t = 0; t < ntaps; ++t)
+                    for (int kk = 0; kk < KK; ++kk)
+                        for (int nt = 0; nt < NT; ++nt) {
+                            float* frag = dst + ((((size_t)(nb * p.nchunks + ch) * ntaps + t) * KK + kk) * NT + nt) * 256;
+                            for (int h = 0; h < 2; ++h)
+                                for (int j = 0; j < 32; ++j) {
+                                    const int co = nb * p.BN + nt * 32 + j;
+                                    if (co >= Cout) continue;
+                                    for (int q = 0; q < 4; ++q) {
+                                        const int ci = ch * p.CI + kk * 8 + 4 * h + q;
+                                        if (ci < Cin) frag[(h * 32 + j) * 4 + q] = w[((size_t)t * Cin + ci) * Cout + co];
+                                    }
+                                }
+                        }
+        return;
+    }
     for (int nb = 0; nb < p.nnb; ++nb)
         for (int ch = 0; ch < p.nchunks; ++ch)
             for (int t = 0; t < ntaps; ++t) {
@@ -488,6 +681,7 @@ int launch_conv_mfma(hipStream_t s, int64_t n, const ConvMfmaPlan& p, TView in, 
     a.rows_pf = p.rows_pf; a.nrows = p.FB * p.rows_pf; a.n_mtiles = a.nrows / 32;
     a.CS = p.CS; a.nchunks = p.nchunks; a.nnb = p.nnb;
     a.tab_off = (int)p.tab_off;
+    { static const int dbg = getenv("TH_CONV_DBG") ? atoi(getenv("TH_CONV_DBG")) : 0; a.dbg = dbg; }
     a.wpk = wpk; a.Cout = Cout; a.bias = bias; a.pre = pre; a.post = post;
     a.out = out.p; a.out_fs = out.fs; a.out_cs = out.cs; a.out_coff = out.coff; a.Ho = out.H; a.Wo = out.W;
     a.nframes = n;
@@ -500,7 +694,8 @@ int launch_conv_mfma(hipStream_t s, int64_t n, const ConvMfmaPlan& p, TView in, 
         HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
         attr_set[p.cfg][p.pool] = true;
     }
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(c.WAVES * 64), p.lds_bytes, s, a);
+    static const size_t lds_pad = getenv("TH_CONV_LDSPAD") ? (size_t)atoi(getenv("TH_CONV_LDSPAD")) : 0;  // occupancy experiments
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(c.WAVES * 64), std::min(p.lds_bytes + lds_pad, kLdsLimit), s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) TH_FAIL(TH_EHIP, "conv_mfma launch failed: %s (%s)", hipGetErrorString(e), p.label.c_str());
     return TH_OK;
