@@ -115,35 +115,47 @@ __global__ void __launch_bounds__(WAVES * 64, 3) k_conv_first(const ConvFirstArg
     {
         const int64_t fbase = f * (int64_t)a.Din * a.Hin * a.Win * a.Cin;
         const bool fast6 = (a.vec8 && NST == 3);  // 24-byte voxels: three 8-byte loads
-        for (int v = tid; v < nvox; v += NTHREADS) {
-            const int xl = v % a.Wp; int t = v / a.Wp;
-            const int yl = t % a.Hp; const int zl = t / a.Hp;
-            const int zi = z0 + zl - a.pz, yi = yl - a.py, xi = xl - a.px;
-            float e[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (zi >= 0 && zi < a.Din && yi >= 0 && yi < a.Hin && xi >= 0 && xi < a.Win) {
-                const int64_t base = fbase + ((int64_t)(zi * a.Hin + yi) * a.Win + xi) * a.Cin;
-                if (fast6) {
-                    const float2* p2 = reinterpret_cast<const float2*>((const float*)a.in + base);
-                    const float2 u0 = p2[0], u1 = p2[1], u2 = p2[2];
-                    e[0] = u0.x; e[1] = u0.y; e[2] = u1.x; e[3] = u1.y; e[4] = u2.x; e[5] = u2.y;
-                } else {
+        constexpr int U = 4;  // voxels in flight per thread: their global loads overlap
+        for (int vb = tid; vb < nvox; vb += NTHREADS * U) {
+            float e[U][8];
 #pragma unroll
-                    for (int c = 0; c < 2 * NST; ++c)
-                        if (c < a.Cin) e[c] = load_elem(a.in, a.dtype, base + c);
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) e[u][c] = 0.f;
+                const int v = vb + u * NTHREADS;
+                const int xl = v % a.Wp; int t = v / a.Wp;
+                const int yl = t % a.Hp; const int zl = t / a.Hp;
+                const int zi = z0 + zl - a.pz, yi = yl - a.py, xi = xl - a.px;
+                if (v < nvox && zi >= 0 && zi < a.Din && yi >= 0 && yi < a.Hin && xi >= 0 && xi < a.Win) {
+                    const int64_t base = fbase + ((int64_t)(zi * a.Hin + yi) * a.Win + xi) * a.Cin;
+                    if (fast6) {
+                        const float2* p2 = reinterpret_cast<const float2*>((const float*)a.in + base);
+                        const float2 u0 = p2[0], u1 = p2[1], u2 = p2[2];
+                        e[u][0] = u0.x; e[u][1] = u0.y; e[u][2] = u1.x; e[u][3] = u1.y; e[u][4] = u2.x; e[u][5] = u2.y;
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 2 * NST; ++c)
+                            if (c < a.Cin) e[u][c] = load_elem(a.in, a.dtype, base + c);
+                    }
                 }
             }
-            float* rec = A + (size_t)v * REC;
-            if (NST == 4) {
-                *reinterpret_cast<float4*>(rec) = make_float4(e[0], e[2], e[4], e[6]);
-                *reinterpret_cast<float4*>(rec + 4) = make_float4(e[1], e[3], e[5], e[7]);
-            } else if (NST == 3) {
-                *reinterpret_cast<float2*>(rec) = make_float2(e[0], e[2]);
-                *reinterpret_cast<float2*>(rec + 2) = make_float2(e[1], e[3]);
-                *reinterpret_cast<float2*>(rec + 4) = make_float2(e[4], e[5]);
-            } else if (NST == 2) {
-                *reinterpret_cast<float4*>(rec) = make_float4(e[0], e[2], e[1], e[3]);
-            } else {
-                *reinterpret_cast<float2*>(rec) = make_float2(e[0], e[1]);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int v = vb + u * NTHREADS;
+                if (v >= nvox) continue;
+                float* rec = A + (size_t)v * REC;
+                if (NST == 4) {
+                    *reinterpret_cast<float4*>(rec) = make_float4(e[u][0], e[u][2], e[u][4], e[u][6]);
+                    *reinterpret_cast<float4*>(rec + 4) = make_float4(e[u][1], e[u][3], e[u][5], e[u][7]);
+                } else if (NST == 3) {
+                    *reinterpret_cast<float2*>(rec) = make_float2(e[u][0], e[u][2]);
+                    *reinterpret_cast<float2*>(rec + 2) = make_float2(e[u][1], e[u][3]);
+                    *reinterpret_cast<float2*>(rec + 4) = make_float2(e[u][4], e[u][5]);
+                } else if (NST == 2) {
+                    *reinterpret_cast<float4*>(rec) = make_float4(e[u][0], e[u][2], e[u][1], e[u][3]);
+                } else {
+                    *reinterpret_cast<float2*>(rec) = make_float2(e[u][0], e[u][1]);
+                }
             }
         }
     }
@@ -163,36 +175,40 @@ __global__ void __launch_bounds__(WAVES * 64, 3) k_conv_first(const ConvFirstArg
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
         const float* arow = A + (size_t)rowvox[mt * 32 + j] * REC;
+        // fully unrolled over the 27 taps; tap t+1's LDS reads are issued before tap t's MFMAs (ping-pong
+        // registers, pinned with sched_barrier) so the wave never sits on an LDS round trip
+        auto fetch = [&](int dz, int dy, int dx, float (&av)[4]) {
+            const float* rec = arow + ((dz * a.Hp + dy) * a.Wp + dx) * REC;
+            if (NST == 4) {
+                const float4 q = *reinterpret_cast<const float4*>(rec + 4 * h);
+                av[0] = q.x; av[1] = q.y; av[2] = q.z; av[3] = q.w;
+            } else if (NST == 3) {
+                const float2 q = *reinterpret_cast<const float2*>(rec + 2 * h);
+                av[0] = q.x; av[1] = q.y; av[2] = rec[4 + h];
+            } else if (NST == 2) {
+                const float2 q = *reinterpret_cast<const float2*>(rec + 2 * h);
+                av[0] = q.x; av[1] = q.y;
+            } else {
+                av[0] = rec[h];
+            }
+        };
+        float av[2][4];
+        fetch(0, 0, 0, av[0]);
 #pragma unroll
-        for (int dz = 0; dz < 3; ++dz)
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const int t = (dz * 3 + dy) * 3 + dx;
-                    const float* rec = arow + ((dz * a.Hp + dy) * a.Wp + dx) * REC;
-                    float av[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (NST == 4) {
-                        const float4 q = *reinterpret_cast<const float4*>(rec + 4 * h);
-                        av[0] = q.x; av[1] = q.y; av[2] = q.z; av[3] = q.w;
-                    } else if (NST == 3) {
-                        const float2 q = *reinterpret_cast<const float2*>(rec + 2 * h);
-                        av[0] = q.x; av[1] = q.y; av[2] = rec[4 + h];
-                    } else if (NST == 2) {
-                        const float2 q = *reinterpret_cast<const float2*>(rec + 2 * h);
-                        av[0] = q.x; av[1] = q.y;
-                    } else {
-                        av[0] = rec[h];
-                    }
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], breg[t].x, acc, 0, 0, 0);
-                    if (NST > 1) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], breg[t].y, acc, 0, 0, 0);
-                    if (NST > 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], breg[t].z, acc, 0, 0, 0);
-                    if (NST > 3) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], breg[t].w, acc, 0, 0, 0);
-                }
+        for (int t = 0; t < kTaps; ++t) {
+            if (t + 1 < kTaps) fetch((t + 1) / 9, ((t + 1) / 3) % 3, (t + 1) % 3, av[(t + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t & 1][0], breg[t].x, acc, 0, 0, 0);
+            if (NST > 1) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t & 1][1], breg[t].y, acc, 0, 0, 0);
+            if (NST > 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t & 1][2], breg[t].z, acc, 0, 0, 0);
+            if (NST > 3) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t & 1][3], breg[t].w, acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         // ---- epilogue in registers (see conv_mfma.hip for the row/lane layout) ----------------------
         float x[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) x[i] = th_post(acc[i] + bv, cc, a.post);
+        for (int i = 0; i < 16; ++i) x[i] = acc[i] + bv;
+        th_post16(x, cc, a.post);
         if (POOL == 0) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {

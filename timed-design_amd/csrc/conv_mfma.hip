@@ -431,7 +431,8 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
                         const float bv = a.bias ? a.bias[cc] : 0.f;
                         float x[16];
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) x[i] = th_post(acc[tm][tn][i] + bv, cc, a.post);
+                        for (int i = 0; i < 16; ++i) x[i] = acc[tm][tn][i] + bv;
+                        th_post16(x, cc, a.post);
                         if (POOL == 0) {
 #pragma unroll
                             for (int i = 0; i < 16; ++i) {
@@ -477,25 +478,31 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
                         const int cc = co < a.Cout ? co : 0;
                         const float bv = a.bias ? a.bias[cc] : 0.f;
                         if (POOL == 0) {
-#pragma unroll 1
+                            // lane (j, h) finishes rows h, h+2, ..., h+30 of column j
+                            float x[16];
+#pragma unroll
+                            for (int k = 0; k < 16; ++k) x[k] = T[(2 * k + h) * 33 + j] + bv;
+                            th_post16(x, cc, a.post);
+#pragma unroll
                             for (int k = 0; k < 16; ++k) {
-                                const int row = 2 * k + h;
-                                const int oo = cok ? rowout[mt * 32 + row] : -1;
-                                const float x = th_post(T[row * 33 + j] + bv, cc, a.post);
-                                if (oo >= 0) outb[oo + co] = x;
+                                const int oo = cok ? rowout[mt * 32 + 2 * k + h] : -1;
+                                if (oo >= 0) outb[oo + co] = x[k];
                             }
                         } else {
-#pragma unroll 1
+                            // lane (j, h) finishes pooled voxels q = h and h+2: their 8 mates each
+                            float x[16];
+#pragma unroll
+                            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) x[8 * k + e] = T[(8 * (2 * k + h) + e) * 33 + j] + bv;
+                            th_post16(x, cc, a.post);
+#pragma unroll
                             for (int k = 0; k < 2; ++k) {
-                                const int q = 2 * k + h;
-                                const int oo = cok ? rowout[mt * 4 + q] : -1;
-                                float m = (POOL == 1) ? -INFINITY : 0.f;
-#pragma unroll 1
-                                for (int e = 0; e < 8; ++e) {
-                                    const float x = th_post(T[(8 * q + e) * 33 + j] + bv, cc, a.post);
-                                    m = (POOL == 1) ? fmaxf(m, x) : m + x;
-                                }
+                                float m = x[8 * k];
+#pragma unroll
+                                for (int e = 1; e < 8; ++e) m = (POOL == 1) ? fmaxf(m, x[8 * k + e]) : m + x[8 * k + e];
                                 if (POOL == 2) m *= 0.125f;
+                                const int oo = cok ? rowout[mt * 4 + 2 * k + h] : -1;
                                 if (oo >= 0) outb[oo + co] = m;
                             }
                         }

@@ -27,3 +27,37 @@ __device__ __forceinline__ float th_post(float x, int c, const PostOps& ops) {
     }
     return x;
 }
+
+// Same epilogue for the 16 accumulator values a lane holds for ONE output channel c: the op list is
+// decoded once (op-outer, element-inner), so the per-element cost is the bare arithmetic
+// (ELU: exp2-path exp + select; affine: one fma) instead of a switch per element.
+__device__ __forceinline__ void th_post16(float (&x)[16], int c, const PostOps& ops) {
+    for (int i = 0; i < ops.n; ++i) {
+        if (ops.type[i] == POP_AFFINE) {
+            const float sc = ops.scale[i][c], sh = ops.shift[i][c];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) x[k] = fmaf(x[k], sc, sh);
+        } else {
+            const float alpha = ops.alpha[i];
+            switch (ops.act[i]) {
+                case ACT_RELU:
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) x[k] = fmaxf(x[k], 0.f);
+                    break;
+                case ACT_ELU:
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) x[k] = x[k] > 0.f ? x[k] : alpha * (__expf(x[k]) - 1.f);
+                    break;
+                case ACT_LEAKY:
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) x[k] = x[k] > 0.f ? x[k] : alpha * x[k];
+                    break;
+                case ACT_LINEAR:
+                    break;
+                default:
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) x[k] = th_act(x[k], ops.act[i], alpha);
+            }
+        }
+    }
+}
