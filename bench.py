@@ -49,7 +49,7 @@ def cpu_baseline(cfg, weights, topology: str, budget_s: float = 15.0):
     t0 = time.perf_counter()
     cnn_oracle.forward(cfg, weights, frames)
     rate = 4 / (time.perf_counter() - t0)
-    n = int(min(max(budget_s * rate, 8), 512))
+    n = int(min(max(budget_s * rate, 8), 4096))
     frames = synth.synthetic_frames(n, seed=1000)
     t0 = time.perf_counter()
     cnn_oracle.forward(cfg, weights, frames)
@@ -57,6 +57,25 @@ def cpu_baseline(cfg, weights, topology: str, budget_s: float = 15.0):
     return dict(value=n / dt, unit="frames/s", cores=os.cpu_count(), kind="port",
                 sample=f"{n} synthetic frames of {topology} through oracle/cnn_oracle.py (NumPy im2col + BLAS sgemm, "
                        f"fp32), {dt:.1f} s wall")
+
+
+def pmc_traffic(label: str, avg_ms: float):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/pmc_latest.json, written by tools/rocpd_summary.py --json from separate --pmc FETCH_SIZE /
+    --pmc WRITE_SIZE runs of this same command; FETCH x2 per the gfx950 correction).  Matched on the
+    kernel instantiation and launch duration (same chunk size); None when nothing matches."""
+    import re
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    m = re.search(r"\[(k_conv_[a-z]+<[^>]*>)\]", label)
+    if not m or not os.path.exists(path):
+        return None
+    best = None
+    for k in json.load(open(path))["kernels"]:
+        if k["kernel"] == m.group(1) and "FETCH_SIZE_bytes" in k and "WRITE_SIZE_bytes" in k and "avg_us" in k:
+            err = abs(k["avg_us"] / 1e3 - avg_ms) / avg_ms
+            if err < 0.15 and (best is None or err < best[0]):
+                best = (err, k["FETCH_SIZE_bytes"] + k["WRITE_SIZE_bytes"])
+    return best[1] if best else None
 
 
 def main():
@@ -184,7 +203,7 @@ def main():
             frames_per_launch = n * args.steps / dom["launches"]
             achieved = dom["flops"] * frames_per_launch / (avg_ms * 1e-3) / 1e12
             line["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                                "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(dom["label"], avg_ms),
                                 "kernel": dom["label"], "avg_launch_ms": avg_ms, "launches": dom["launches"],
                                 "share_of_device_time": dom["ms"] / tot_ms,
                                 "exec_tflops": dom["exec_flops"] * frames_per_launch / (avg_ms * 1e-3) / 1e12}

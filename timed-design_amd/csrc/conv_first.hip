@@ -282,9 +282,9 @@ bool conv_first_plan(int Din, int Hin, int Win, int Cin, const TView& oc, const 
     p->wpk_floats = (size_t)kTaps * 2 * 32 * 4;
     p->exec_flops = 2.0 * (double)p->nzb * p->rows_pf * 32.0 * (2.0 * nst) * kTaps;
     if (oc.fs > 0x7fffffffLL) return false;
-    char buf[160];
-    snprintf(buf, sizeof buf, "conv_first<w%d,nst%d,pool%d> ZB%d/%d rows%d lds%zuK (weights in VGPRs, direct input)", kWaves,
-             nst, pool, ZB, p->Dc, p->rows_pf, p->lds_bytes / 1024);
+    char buf[224];
+    snprintf(buf, sizeof buf, "conv_first<w%d,nst%d,pool%d> ZB%d/%d rows%d lds%zuK (weights in VGPRs, direct input) [k_conv_first<%d,%d,%d>]",
+             kWaves, nst, pool, ZB, p->Dc, p->rows_pf, p->lds_bytes / 1024, kWaves, nst, pool);
     p->label = buf;
     return true;
 }

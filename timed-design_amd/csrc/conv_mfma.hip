@@ -607,9 +607,10 @@ static bool plan_with_cfg(int cfg, size_t lds_limit, bool whole_frames_only, con
     const double rows_exec = (double)p->nzb * p->rows_pf;  // per frame
     p->exec_flops = 2.0 * rows_exec * (double)(p->nnb * p->BN) * (double)(p->nchunks * c.CI) * ntaps;
     if ((int64_t)FB * oc.fs > 0x7fffffffLL || (int64_t)FB * in.D * in.H * in.W * std::max(in.cs, in.C) > 0x7fffffffLL) return false;
-    char buf[160];
-    snprintf(buf, sizeof buf, "conv_mfma<w%d,%dx%d,nt%d,ci%d,%s,pool%d> FB%d ZB%d/%d rows%d lds%zuK", c.WAVES, c.TM,
-             c.TN, c.NT, c.CI, c.BRES == 2 ? "stream" : (c.BRES ? "res" : "dbuf"), pool, FB, ZB, p->Dc, p->rows_pf, p->lds_bytes / 1024);
+    char buf[224];
+    snprintf(buf, sizeof buf, "conv_mfma<w%d,%dx%d,nt%d,ci%d,%s,pool%d> FB%d ZB%d/%d rows%d lds%zuK [k_conv_mfma<%d,%d,%d,%d,%d,%d,%d>]",
+             c.WAVES, c.TM, c.TN, c.NT, c.CI, c.BRES == 2 ? "stream" : (c.BRES ? "res" : "dbuf"), pool, FB, ZB, p->Dc, p->rows_pf,
+             p->lds_bytes / 1024, c.WAVES, c.TM, c.TN, c.NT, c.CI, c.BRES, pool);
     p->label = buf;
     return true;
 }

@@ -1,0 +1,129 @@
+"""Multi-GPU prediction: contiguous frame shards, one gather.
+
+The reference is single-process (its only parallelism is a multiprocessing.Pool in the sampler),
+so nothing here replaces reference code; it is what lets rank 0 write the per-chain ``.csv`` /
+``.fasta`` exactly as reference predict.py:161-185 does when the frames of one dataset were
+predicted on several GPUs.
+
+Frames are independent at inference (BatchNorm uses moving statistics, no cross-frame op), so the
+flat dataset map — whose order is fixed by create_flat_dataset_map (reference utils.py:362-393) — is
+cut into ``world`` contiguous ranges ``[floor(i*N/W), floor((i+1)*N/W))``; every rank holds the full
+(small) weights, predicts its range, and the ``[n_i, n_classes]`` fp32 blocks are gathered to rank 0
+in rank order, which IS map order.  One process per GPU (``torch.distributed.run`` sets
+RANK/LOCAL_RANK/WORLD_SIZE).
+
+Two transports for the single exchange step:
+  * ``RcclGather``  device buffers, RCCL grouped send/recv over xGMI through the C ABI
+                    (th_comm_gather_rows) — the production path on a GPU node;
+  * ``GlooGather``  host arrays through torch.distributed's gloo backend — used by the CPU tests
+                    (world_size 2) and usable when the probabilities are wanted on the host anyway.
+Both present ``gather_rows(local, counts, root) -> ndarray | None``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+
+
+def shard_bounds(n: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous ranges [floor(i*n/world), floor((i+1)*n/world)); sizes differ by at most one."""
+    if world < 1 or n < 0:
+        raise ValueError("need world >= 1 and n >= 0")
+    return [((i * n) // world, ((i + 1) * n) // world) for i in range(world)]
+
+
+def shard_counts(n: int, world: int) -> List[int]:
+    return [hi - lo for lo, hi in shard_bounds(n, world)]
+
+
+def env_rank_world() -> Tuple[int, int, int]:
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+class GlooGather:
+    """Row gather of host arrays over an initialised torch.distributed (gloo) group."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised (init_process_group(backend='gloo'))")
+        self.dist, self.group = dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+
+    def gather_rows(self, local: np.ndarray, counts: Sequence[int], root: int = 0) -> Optional[np.ndarray]:
+        import torch
+        local = np.ascontiguousarray(local, dtype=np.float32)
+        if local.shape[0] != counts[self.rank]:
+            raise ValueError(f"rank {self.rank}: local block has {local.shape[0]} rows, expected {counts[self.rank]}")
+        width = local.shape[1]
+        # gloo's gather wants equal sizes: pad every block to the largest shard, trim at the root
+        mx = max(counts) if counts else 0
+        buf = torch.zeros((mx, width), dtype=torch.float32)
+        buf[: local.shape[0]] = torch.from_numpy(local)
+        if self.rank == root:
+            parts = [torch.empty((mx, width), dtype=torch.float32) for _ in range(self.world)]
+            self.dist.gather(buf, parts, dst=root, group=self.group)
+            return np.concatenate([p[:c].numpy() for p, c in zip(parts, counts)], axis=0)
+        self.dist.gather(buf, None, dst=root, group=self.group)
+        return None
+
+    def barrier(self):
+        self.dist.barrier(group=self.group)
+
+
+class RcclGather:
+    """Row gather of DEVICE buffers through th_comm_* (RCCL over xGMI).  ``unique_id`` is created on
+    rank 0 with ``RcclGather.new_unique_id()`` and shipped to the other ranks out of band (e.g. a gloo
+    broadcast, see bench.py)."""
+
+    def __init__(self, unique_id: bytes, world: int, rank: int, device: int):
+        self._lib = _lib.load()
+        self.rank, self.world, self.device = rank, world, device
+        self._h = C.c_void_p()
+        _lib.check(self._lib.th_comm_init(unique_id, world, rank, device, C.byref(self._h)))
+
+    @staticmethod
+    def new_unique_id() -> bytes:
+        buf = C.create_string_buffer(_lib.TH_COMM_ID_BYTES)
+        _lib.check(_lib.load().th_comm_unique_id(buf))
+        return buf.raw
+
+    def gather_rows_device(self, d_local: int, counts: Sequence[int], width: int, root: int, d_out: int = 0):
+        arr = (C.c_int64 * self.world)(*[int(c) for c in counts])
+        _lib.check(self._lib.th_comm_gather_rows(self._h, C.c_void_p(d_local), arr, int(width), int(root),
+                                                 C.c_void_p(d_out)))
+
+    def barrier(self):
+        _lib.check(self._lib.th_comm_barrier(self._h))
+
+    def close(self):
+        if self._h:
+            self._lib.th_comm_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def predict_sharded(model, frames_for_range, n_total: int, gather, root: int = 0) -> Optional[np.ndarray]:
+    """Predict this rank's contiguous shard and gather the probability rows to ``root``.
+
+    ``frames_for_range(lo, hi) -> ndarray[hi-lo, D,H,W,C]`` loads the frames of map rows [lo, hi)
+    (e.g. ``lambda lo, hi: load_batch(path, flat_map[lo:hi])[0]``); ``gather`` is a GlooGather (host)
+    transport.  Returns the full [n_total, n_classes] matrix in map order on ``root``, None elsewhere.
+    """
+    counts = shard_counts(n_total, gather.world)
+    lo, hi = shard_bounds(n_total, gather.world)[gather.rank]
+    if hi > lo:
+        local = model.predict(frames_for_range(lo, hi))
+    else:
+        local = np.empty((0, model.n_classes), dtype=np.float32)
+    return gather.gather_rows(local, counts, root)

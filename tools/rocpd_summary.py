@@ -36,7 +36,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--kernel-trace")
     ap.add_argument("--pmc", action="append", default=[], help="NAME=path.db")
+    ap.add_argument("--json", help="write per-kernel {avg_us, FETCH/WRITE bytes per launch} for bench.py's roofline.traffic")
     args = ap.parse_args()
+    js = {}
     if args.kernel_trace:
         _, rows = dispatches(args.kernel_trace)
         agg = defaultdict(list)
@@ -53,6 +55,7 @@ def main():
             wg, vg, ag, sg = meta[key]
             print(f"{key[0]:58s} {key[1]:7d} {key[2]:7d} {wg:4d} {vg + ag:5d} {len(v):6d} {sum(v)/1e3:10.3f} {sum(v)/len(v):10.1f} "
                   f"{min(v):10.1f} {max(v):10.1f} {100*sum(v)/total:6.2f}")
+            js.setdefault("|".join(map(str, key)), {})["avg_us"] = sum(v) / len(v)
     for spec in args.pmc:
         cname, path = spec.split("=", 1)
         c, rows = dispatches(path)
@@ -70,6 +73,13 @@ def main():
         for key, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
             avg = sum(v) / len(v)
             print(f"{key[0]:58s} {key[1]:7d} {key[2]:7d} {len(v):6d} {avg:14.1f} {avg*1024/1e6:10.3f} {corr*avg*1024/1e6:20.3f}")
+            js.setdefault("|".join(map(str, key)), {})[cname + "_bytes"] = corr * avg * 1024
+    if args.json:
+        import json
+        out = [dict(kernel=k.split("|")[0].replace(" ", ""), wgs=int(k.split("|")[1]), lds=int(k.split("|")[2]), **v) for k, v in js.items()
+               if k.startswith("k_conv")]
+        json.dump(dict(note="per-launch averages; FETCH_SIZE x2 (gfx950 correction), WRITE_SIZE x1; separate --pmc passes", kernels=out),
+                  open(args.json, "w"), indent=1)
 
 
 if __name__ == "__main__":
