@@ -131,26 +131,44 @@ def main():
     # multi-GPU exchange: RCCL gather of the probability shards to rank 0
     comm = None
     d_gather = None
+    host_gather = None
+    exchange = "rccl gather to rank 0 (grouped send/recv over xGMI)" if world > 1 else "none"
     counts = (C.c_int64 * world)(*([n] * world))
     if world > 1:
         import torch
         idbuf = C.create_string_buffer(_lib.TH_COMM_ID_BYTES)
-        if rank == 0:
-            _lib.check(lib.th_comm_unique_id(idbuf))
+        if rank == 0 and lib.th_comm_unique_id(idbuf) != 0:
+            idbuf = C.create_string_buffer(_lib.TH_COMM_ID_BYTES)  # all zeros = "no id": every rank falls back together
         t = torch.frombuffer(bytearray(idbuf.raw), dtype=torch.uint8).clone()
         dist.broadcast(t, src=0)
         idbytes = bytes(t.numpy().tobytes())
         h = C.c_void_p()
-        _lib.check(lib.th_comm_init(idbytes, world, rank, device, C.byref(h)))
-        comm = h
-        if rank == 0:
-            d_gather = engine.DeviceBuffer(world * n * model.n_classes * 4, device)
+        rc = lib.th_comm_init(idbytes, world, rank, device, C.byref(h)) if any(idbytes) else -6
+        ok = torch.tensor([1 if rc == 0 else 0])
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            comm = h
+            if rank == 0:
+                d_gather = engine.DeviceBuffer(world * n * model.n_classes * 4, device)
+        else:
+            # RCCL could not be brought up on some rank: keep measuring, with the exchange done on the host
+            # (device->host copy + gloo gather), and say so in the JSON line
+            if rc == 0:
+                lib.th_comm_free(h)
+            exchange = "HOST FALLBACK (gloo gather of downloaded rows): RCCL init failed: " + \
+                lib.th_last_error().decode(errors="replace")
+            if rank == 0:
+                print("[bench] " + exchange, file=sys.stderr)
+            from timed_hip import distributed as td
+            host_gather = td.GlooGather()
 
     def step():
         model.predict_device(d_frames.ptr, n, d_probs.ptr)
         if comm is not None:
             _lib.check(lib.th_comm_gather_rows(comm, C.c_void_p(d_probs.ptr), counts, model.n_classes, 0,
                                                C.c_void_p(d_gather.ptr if d_gather else 0)))
+        elif host_gather is not None:
+            host_gather.gather_rows(d_probs.download((n, model.n_classes), np.float32), [n] * world, 0)
 
     for _ in range(args.warmup):
         step()
@@ -187,7 +205,7 @@ def main():
             "config": {"workload": f"{model.name}-synth forward, {D}x{H}x{W}x{Cc} fp32 frames resident in HBM, "
                                    f"{n} frames per GPU per step, {model.n_classes} classes, random-init weights",
                        "frames_per_gpu": n, "chunk": args.chunk, "parallelism": f"frame-shard x{world}",
-                       "exchange": "rccl gather to rank 0" if world > 1 else "none",
+                       "exchange": exchange,
                        "algo_mflop_per_frame": cost["algo_flops"] / 1e6, "exec_mflop_per_frame": cost["exec_flops"] / 1e6,
                        "device": f"{model.device_arch} {model.device_cus} CUs"},
             "model_tflops": fps / world * cost["algo_flops"] / 1e12,

@@ -515,6 +515,235 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
     }  // rounds
 }
 
+// =====================================================================================================
+// Narrow-output variant: Cout <= 16 (DenseNet/DenseCPD growth convolutions), 3x3x3, stride 1.
+// A 32-wide MFMA tile would spend half its columns on zero padding, so this kernel uses
+// v_mfma_f32_16x16x4_f32 (same 64 FLOP/clk/SIMD rate): lane (i = l&15, q = l>>4) supplies
+// A[i][k=q] / B[k=q][i]; with one ds_read_b128 it holds channels 4q..4q+3 of its voxel, i.e. the
+// operands of 4 consecutive MFMAs (K order permuted identically in the packed weights).
+// All 27 taps' weight fragments of the current 16-channel chunk live in registers (108 VGPRs) and
+// each is re-loaded for the NEXT chunk right after its last use, so weight latency is a whole chunk
+// away.  The tap loop is fully unrolled with ping-pong A registers pinned by sched_barrier.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int WAVES, int TM, int POOL>
+__global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(const ConvMfmaArgs a) {
+    constexpr int NTHREADS = WAVES * 64;
+    constexpr int CI = 16, CI4 = 4, NTAPS = 27;
+    extern __shared__ __attribute__((aligned(16))) float4 smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, q = lane >> 4;
+    const int CS4 = a.CS >> 2;
+
+    int bid = blockIdx.x;
+    const int zb = bid % a.nzb; bid /= a.nzb;
+    const int64_t f0 = (int64_t)bid * a.FB;
+    const int z0 = zb * a.ZB;
+    const int nvox = a.FB * a.Zp * a.Hp * a.Wp;
+    float4* A4 = smem;
+    int* rowvox = (int*)(reinterpret_cast<char*>(smem) + a.tab_off);
+    int* rowout = rowvox + a.nrows;
+    int* voxsrc = rowout + (POOL ? a.nrows / 8 : a.nrows);
+    for (int v = tid; v < nvox; v += NTHREADS) {
+        const int xl = v % a.Wp; int t = v / a.Wp;
+        const int yl = t % a.Hp; t /= a.Hp;
+        const int zl = t % a.Zp; const int f = t / a.Zp;
+        const int zi = z0 + zl - a.pz, yi = yl - a.py, xi = xl - a.px;
+        const bool ok = (f0 + f) < a.nframes && zi >= 0 && zi < a.Din && yi >= 0 && yi < a.Hin && xi >= 0 && xi < a.Win;
+        voxsrc[v] = ok ? f * (int)a.in_fs + ((zi * a.Hin + yi) * a.Win + xi) * a.in_cs : -1;
+    }
+    {
+        const int ZBv = min(a.ZB, a.Dc - z0);
+        for (int r = tid; r < a.nrows; r += NTHREADS) {
+            const int f = r / a.rows_pf, qq = r - f * a.rows_pf;
+            const bool fok = (f0 + f) < a.nframes;
+            int vox = 0, oo = -1;
+            if (POOL == 0) {
+                const int hw = a.Hc * a.Wc;
+                if (fok && qq < ZBv * hw) {
+                    const int zl = qq / hw, rem = qq - zl * hw, y = rem / a.Wc, x = rem - y * a.Wc;
+                    vox = ((f * a.Zp + zl) * a.Hp + y) * a.Wp + x;
+                    oo = f * (int)a.out_fs + (((z0 + zl) * a.Ho + y) * a.Wo + x) * a.out_cs;
+                }
+                rowout[r] = oo;
+            } else {
+                const int pq = qq >> 3, mate = qq & 7;
+                const int PH = a.Hc >> 1, PW = a.Wc >> 1;
+                if (fok && pq < (ZBv >> 1) * PH * PW) {
+                    const int pzz = pq / (PH * PW), rem = pq - pzz * (PH * PW), pyy = rem / PW, pxx = rem - pyy * PW;
+                    const int zl = 2 * pzz + (mate >> 2), y = 2 * pyy + ((mate >> 1) & 1), x = 2 * pxx + (mate & 1);
+                    vox = ((f * a.Zp + zl) * a.Hp + y) * a.Wp + x;
+                    oo = f * (int)a.out_fs + ((((z0 >> 1) + pzz) * a.Ho + pyy) * a.Wo + pxx) * a.out_cs;
+                }
+                if (mate == 0) rowout[r >> 3] = oo;
+            }
+            rowvox[r] = vox;
+        }
+    }
+
+    const int n_mt = a.nrows / 16;
+    const int total_blocks = (n_mt + TM - 1) / TM;
+    const int rounds = (total_blocks + WAVES - 1) / WAVES;
+    const float4* wpk4 = reinterpret_cast<const float4*>(a.wpk) + lane;  // [chunk][tap][lane]
+    const int co = i16;
+    const bool cvalid = co < a.Cout;
+    const int cc = cvalid ? co : 0;
+    const float bv = a.bias ? a.bias[cc] : 0.f;
+    float* outb = a.out + f0 * a.out_fs + a.out_coff;
+
+    for (int rd = 0; rd < rounds; ++rd) {
+        const int blk = rd * WAVES + wave;
+        const bool active = blk < total_blocks;
+        f32x4 acc[TM];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) acc[tm] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (rd == 0) __syncthreads();
+        int aidx[TM];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const int mt = blk * TM + tm;
+            aidx[tm] = ((active && mt < n_mt) ? rowvox[mt * 16 + i16] : 0) * CS4 + q;
+        }
+        float4 breg[NTAPS];
+        if (active) {
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t) breg[t] = wpk4[(size_t)t * 64];
+        }
+        for (int ch = 0; ch < a.nchunks; ++ch) {
+            const bool need_a = !(a.nchunks == 1 && rd > 0);
+            __syncthreads();
+            if (need_a) {
+                constexpr int U = 4;
+                const int nvec = nvox * CI4;
+                const float* inb = a.in + f0 * a.in_fs + a.in_coff + ch * CI;
+                const bool has_pre = a.pre.scale || a.pre.act != ACT_LINEAR;
+                for (int base = tid; base < nvec; base += NTHREADS * U) {
+                    int off[U];
+                    float4 val[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int i = base + u * NTHREADS;
+                        off[u] = (i < nvec) ? voxsrc[i / CI4] : -1;
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int i = base + u * NTHREADS;
+                        const int g = i % CI4;
+                        const int c0 = ch * CI + g * 4;
+                        val[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (off[u] >= 0 && c0 < a.Cin) {
+                            const float* src = inb + off[u] + g * 4;
+                            if (a.vec_ok && c0 + 4 <= a.Cin) {
+                                val[u] = *reinterpret_cast<const float4*>(src);
+                            } else {
+                                val[u].x = src[0];
+                                if (c0 + 1 < a.Cin) val[u].y = src[1];
+                                if (c0 + 2 < a.Cin) val[u].z = src[2];
+                                if (c0 + 3 < a.Cin) val[u].w = src[3];
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int i = base + u * NTHREADS;
+                        if (i >= nvec) continue;
+                        const int v = i / CI4, g = i % CI4;
+                        if (has_pre && off[u] >= 0) {
+                            const int c0 = ch * CI + g * 4;
+                            float e[4] = {val[u].x, val[u].y, val[u].z, val[u].w};
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                if (c0 + k < a.Cin) {
+                                    float x = e[k];
+                                    if (a.pre.scale) x = fmaf(x, a.pre.scale[c0 + k], a.pre.shift[c0 + k]);
+                                    e[k] = th_act(x, a.pre.act, a.pre.alpha);
+                                }
+                            }
+                            val[u] = make_float4(e[0], e[1], e[2], e[3]);
+                        }
+                        A4[(size_t)v * CS4 + g] = val[u];
+                    }
+                }
+            }
+            __syncthreads();
+            if (active) {
+                const float4* wnext = wpk4 + (size_t)min(ch + 1, a.nchunks - 1) * NTAPS * 64;
+                constexpr bool PING = (TM <= 4);  // TM = 8 has no registers left for a second A set: rely on 2 waves/SIMD
+                float4 av[PING ? 2 : 1][TM];
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) av[0][tm] = A4[aidx[tm]];
+#pragma unroll
+                for (int t = 0; t < NTAPS; ++t) {
+                    if (PING && t + 1 < NTAPS) {
+                        const int nt = t + 1;
+                        int noff = (((nt / 9) * a.Hp + (nt / 3) % 3) * a.Wp + nt % 3) * CS4;
+                        // opaque to LICM: otherwise hipcc hoists all 27*TM read addresses out of the chunk loop
+                        // and spills them to scratch
+                        asm volatile("" : "+s"(noff));
+#pragma unroll
+                        for (int tm = 0; tm < TM; ++tm) av[nt & 1][tm] = A4[aidx[tm] + noff];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    constexpr int dummy = 0; (void)dummy;
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) {
+                        const float4 aq = av[PING ? (t & 1) : 0][tm];
+                        acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.x, breg[t].x, acc[tm], 0, 0, 0);
+                        acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.y, breg[t].y, acc[tm], 0, 0, 0);
+                        acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.z, breg[t].z, acc[tm], 0, 0, 0);
+                        acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.w, breg[t].w, acc[tm], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    breg[t] = wnext[(size_t)t * 64];  // this tap's weights for the next chunk: a whole chunk to arrive
+                    if (!PING && t + 1 < NTAPS) {
+                        const int nt = t + 1;
+                        int noff = (((nt / 9) * a.Hp + (nt / 3) % 3) * a.Wp + nt % 3) * CS4;
+                        asm volatile("" : "+s"(noff));
+#pragma unroll
+                        for (int tm = 0; tm < TM; ++tm) av[0][tm] = A4[aidx[tm] + noff];
+                    }
+                }
+            }
+        }
+        // ---- epilogue in registers: C layout col = lane&15, row = 4*(lane>>4) + reg --------------------
+        if (active) {
+#pragma unroll
+            for (int g0 = 0; g0 < TM; g0 += 4) {
+                float x[16];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[4 * g + r] = (g0 + g < TM) ? acc[(g0 + g < TM) ? g0 + g : 0][r] + bv : 0.f;
+                th_post16(x, cc, a.post);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (g0 + g >= TM) continue;
+                    const int mt = blk * TM + g0 + g;
+                    const bool ok = cvalid && mt < n_mt;
+                    if (POOL == 0) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int oo = ok ? rowout[mt * 16 + 4 * q + r] : -1;
+                            if (oo >= 0) outb[oo + co] = x[4 * g + r];
+                        }
+                    } else {
+                        // rows 4q..4q+3 of the tile = mates (4q)&7.. of pooled voxel q>>1: combine with lane q^1
+                        float m;
+                        if (POOL == 1) m = fmaxf(fmaxf(x[4 * g], x[4 * g + 1]), fmaxf(x[4 * g + 2], x[4 * g + 3]));
+                        else m = (x[4 * g] + x[4 * g + 1]) + (x[4 * g + 2] + x[4 * g + 3]);
+                        const float o2 = __shfl_xor(m, 16);
+                        m = (POOL == 1) ? fmaxf(m, o2) : (m + o2) * 0.125f;
+                        const int oo = ok ? rowout[mt * 2 + (q >> 1)] : -1;
+                        if (oo >= 0 && (q & 1) == 0) outb[oo + co] = m;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ---- tile configurations ------------------------------------------------------------------------
 struct CfgDesc { int WAVES, TM, TN, NT, CI, BRES; };
 const CfgDesc kCfgs[] = {
@@ -615,6 +844,52 @@ static bool plan_with_cfg(int cfg, size_t lds_limit, bool whole_frames_only, con
     return true;
 }
 
+
+// ---- narrow-output (Cout <= 16) kernel: planning, packing, launch ------------------------------------------
+namespace {
+struct N16Cfg { int WAVES, TM; };
+const N16Cfg kN16[] = {{8, 8}, {4, 4}};
+typedef void (*ConvKernelN16)(const ConvMfmaArgs);
+const ConvKernelN16 kN16Kernels[2][3] = {
+    {k_conv_n16<8, 8, 0>, k_conv_n16<8, 8, 1>, k_conv_n16<8, 8, 2>},
+    {k_conv_n16<4, 4, 0>, k_conv_n16<4, 4, 1>, k_conv_n16<4, 4, 2>},
+};
+bool plan_n16(int variant, size_t lds_limit, const TView& in, const TView& oc, const ConvGeom& g, int Cin, int Cout, int pool,
+              ConvMfmaPlan* p) {
+    const N16Cfg& c = kN16[variant];
+    p->cfg = 200 + variant;
+    p->CI = 16; p->CS = 20; p->BN = 16; p->nnb = 1; p->nchunks = (Cin + 15) / 16; p->pool = pool; p->bres = 3;
+    p->Dc = pool ? (oc.D / 2) * 2 : oc.D;
+    p->Hc = pool ? (oc.H / 2) * 2 : oc.H;
+    p->Wc = pool ? (oc.W / 2) * 2 : oc.W;
+    p->Hp = p->Hc + 2; p->Wp = p->Wc + 2;
+    auto rows_for = [&](int zb) { return round_up(pool ? 8 * ((zb / 2) * (p->Hc / 2) * (p->Wc / 2)) : zb * p->Hc * p->Wc, 16); };
+    auto tab_bytes = [&](int fb, int zb) {
+        const size_t nvox = (size_t)fb * (zb + 2) * p->Hp * p->Wp;
+        const int nrows = fb * rows_for(zb);
+        return (size_t)nrows * 4 + (size_t)(pool ? nrows / 8 : nrows) * 4 + nvox * 4;
+    };
+    auto lds_for = [&](int fb, int zb) { return (size_t)fb * (zb + 2) * p->Hp * p->Wp * p->CS * 4 + tab_bytes(fb, zb); };
+    const int max_mt = c.WAVES * c.TM;
+    if (lds_for(1, p->Dc) > lds_limit) return false;              // whole frames only
+    if (p->nchunks > 1 && rows_for(p->Dc) / 16 > max_mt) return false;
+    int FB = 1;
+    while (FB < 32 && lds_for(FB + 1, p->Dc) <= lds_limit && (FB + 1) * rows_for(p->Dc) / 16 <= max_mt) ++FB;
+    p->FB = FB; p->ZB = p->Dc; p->nzb = 1; p->Zp = p->Dc + 2;
+    p->rows_pf = rows_for(p->Dc);
+    p->lds_bytes = lds_for(FB, p->Dc);
+    p->tab_off = p->lds_bytes - tab_bytes(FB, p->Dc);
+    p->wpk_floats = (size_t)p->nchunks * 27 * 64 * 4;
+    p->exec_flops = 2.0 * (double)p->rows_pf * 16.0 * (double)(p->nchunks * 16) * 27;
+    if ((int64_t)FB * oc.fs > 0x7fffffffLL || (int64_t)FB * in.D * in.H * in.W * std::max(in.cs, in.C) > 0x7fffffffLL) return false;
+    char buf[224];
+    snprintf(buf, sizeof buf, "conv_n16<w%d,tm%d,pool%d> FB%d rows%d lds%zuK (16x16x4 MFMA, weights in VGPRs) [k_conv_n16<%d,%d,%d>]",
+             c.WAVES, c.TM, pool, FB, p->rows_pf, p->lds_bytes / 1024, c.WAVES, c.TM, pool);
+    p->label = buf;
+    return true;
+}
+}  // namespace
+
 bool conv_mfma_plan(const TView& in, const TView& oc, const ConvGeom& g, int Cin, int Cout, int pool, ConvMfmaPlan* p) {
     if (g.sd != 1 || g.sh != 1 || g.sw != 1 || g.dd != 1 || g.dh != 1 || g.dw != 1) return false;
     if (pool && (oc.D < 2 || oc.H < 2 || oc.W < 2)) return false;
@@ -627,6 +902,10 @@ bool conv_mfma_plan(const TView& in, const TView& oc, const ConvGeom& g, int Cin
     const char* mode = getenv("TH_CONV_BMODE");
     const bool dbuf = mode && std::strcmp(mode, "dbuf") == 0;
     const bool stream8 = mode && std::strcmp(mode, "stream8") == 0;
+    if (!dbuf && !stream8 && Cout <= 16 && Cin > 8 && g.kd == 3 && g.kh == 3 && g.kw == 3 && !(mode && std::strcmp(mode, "no16") == 0)) {
+        if (plan_n16(1, kLdsLimit / 2, in, oc, g, Cin, Cout, pool, p)) return true;   // two 4-wave workgroups per CU
+        if (plan_n16(0, kLdsLimit, in, oc, g, Cin, Cout, pool, p)) return true;       // one 8-wave workgroup
+    }
     if (!dbuf && cfg >= 1 && cfg <= 3) {
         if (!stream8 && plan_with_cfg(cfg + 7, kLdsLimit / 2, true, in, oc, g, Cin, Cout, pool, p)) return true;
         cfg += 4;
@@ -637,6 +916,17 @@ bool conv_mfma_plan(const TView& in, const TView& oc, const ConvGeom& g, int Cin
 void conv_mfma_pack_weights(const ConvMfmaPlan& p, const ConvGeom& g, int Cin, int Cout, const float* w, float* dst) {
     const int ntaps = g.kd * g.kh * g.kw;
     std::memset(dst, 0, p.wpk_floats * sizeof(float));
+    if (p.bres == 3) {  // k_conv_n16: [chunk][tap][q][j][t] with ci = chunk*16 + 4q + t, co = j
+        for (int ch = 0; ch < p.nchunks; ++ch)
+            for (int t = 0; t < ntaps; ++t)
+                for (int q = 0; q < 4; ++q)
+                    for (int j = 0; j < 16 && j < Cout; ++j)
+                        for (int e = 0; e < 4; ++e) {
+                            const int ci = ch * 16 + 4 * q + e;
+                            if (ci < Cin) dst[((((size_t)ch * ntaps + t) * 4 + q) * 16 + j) * 4 + e] = w[((size_t)t * Cin + ci) * Cout + j];
+                        }
+        return;
+    }
     if (p.bres == 2) {
         // fragment order: [nb][chunk][tap][kk][ntile][h][j][t]  with  ci = chunk*CI + kk*8 + 4h + t,  co = nb*BN + ntile*32 + j
         const int KK = p.CI / 8, NT = p.BN / 32;
@@ -676,8 +966,10 @@ void conv_mfma_pack_weights(const ConvMfmaPlan& p, const ConvGeom& g, int Cin, i
 
 int launch_conv_mfma(hipStream_t s, int64_t n, const ConvMfmaPlan& p, TView in, TView out, ConvGeom g, int Cin, int Cout,
                      const float* wpk, const float* bias, PreOp pre, PostOps post) {
-    if (p.cfg < 0 || p.cfg >= kNumCfgs) TH_FAIL(TH_EINVAL, "conv_mfma: bad plan");
-    const CfgDesc& c = kCfgs[p.cfg];
+    const bool n16 = p.cfg >= 200 && p.cfg < 202;
+    if (!n16 && (p.cfg < 0 || p.cfg >= kNumCfgs)) TH_FAIL(TH_EINVAL, "conv_mfma: bad plan");
+    const CfgDesc c16 = {n16 ? kN16[p.cfg - 200].WAVES : 0, 0, 0, 0, 16, 3};
+    const CfgDesc& c = n16 ? c16 : kCfgs[p.cfg];
     ConvMfmaArgs a;
     std::memset(&a, 0, sizeof a);
     a.in = in.p; a.in_fs = in.fs; a.in_cs = in.cs; a.in_coff = in.coff;
@@ -696,12 +988,8 @@ int launch_conv_mfma(hipStream_t s, int64_t n, const ConvMfmaPlan& p, TView in, 
     const int64_t groups = (n + p.FB - 1) / p.FB;
     const int64_t grid = groups * p.nzb * p.nnb;
     if (grid > 0x7fffffffLL) TH_FAIL(TH_EINVAL, "conv_mfma: grid too large");
-    ConvKernel k = kKernels[p.cfg][p.pool];
-    static bool attr_set[kNumCfgs][3] = {};
-    if (!attr_set[p.cfg][p.pool]) {
-        HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
-        attr_set[p.cfg][p.pool] = true;
-    }
+    ConvKernel k = n16 ? kN16Kernels[p.cfg - 200][p.pool] : kKernels[p.cfg][p.pool];
+    HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     static const size_t lds_pad = getenv("TH_CONV_LDSPAD") ? (size_t)atoi(getenv("TH_CONV_LDSPAD")) : 0;  // occupancy experiments
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(c.WAVES * 64), std::min(p.lds_bytes + lds_pad, kLdsLimit), s, a);
     hipError_t e = hipGetLastError();
