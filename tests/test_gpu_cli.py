@@ -148,3 +148,23 @@ def test_sample_cli_end_to_end(gpu, tmp_path, monkeypatch, temperature):
     assert again == got
     args.seed = 7
     assert json.load(open(sample.main_sample(args)[0])) != got
+
+
+def test_predict_from_frame_pack_equals_hdf5(gpu, tmp_path):
+    """§8 f-1: the HDF5-free packed dataset gives byte-identical prediction files."""
+    import warnings
+    from pathlib import Path
+    import predict
+    from timed_hip import framepack
+    model_path = Path(os.path.join(G, "keras_tiny.h5"))
+    src = os.path.join(G, "frames_tiny.hdf5")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        framepack.pack_dataset(src, tmp_path / "tiny")
+        a, b = tmp_path / "a", tmp_path / "b"
+        a.mkdir(); b.mkdir()
+        predict.load_dataset_and_predict([model_path], src, batch_size=9, dataset_map_path=a / "datasetmap.txt", path_to_output=a)
+        predict.load_dataset_and_predict([model_path], str(tmp_path / "tiny.framepack"), batch_size=9,
+                                         dataset_map_path=b / "datasetmap.txt", path_to_output=b)
+    for fn in ("keras_tiny.csv", "keras_tiny.fasta", "keras_tiny.txt", "dataset.fasta", "datasetmap.txt", "encoded_labels.csv"):
+        assert (a / fn).read_bytes() == (b / fn).read_bytes(), fn

@@ -189,3 +189,30 @@ def test_seq_metrics_shapes():
     assert m[1, 0] > 3 and m[2, 0] < -3 and m[1, 1] > m[2, 1]          # lysines positive / high pI
     assert abs(m[0, 2] - 2395.7) < 2.0 and m[0, 3] == 5690 + 1280 + 120  # 20-mer mass, W+Y+C extinction
     assert calculate_seq_metrics("KKKK") == tuple(float(x) for x in m[1])
+
+
+def test_frame_pack_matches_hdf5(tmp_path):
+    """§8 f-1: the packed (HDF5-free) dataset returns the same frames, labels and map as the HDF5 path."""
+    import warnings
+    from timed_hip import framepack
+    for name in ("frames_tiny.hdf5", "frames_tiny_bool.hdf5"):
+        src = os.path.join(G, name)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            fp = framepack.pack_dataset(src, tmp_path / name)
+            flat, pdbs = utils.create_flat_dataset_map(src)
+        stem = str(tmp_path / name)
+        assert framepack.is_pack(stem) and framepack.is_pack(stem + ".framepack") and framepack.is_pack(stem + ".frames.npy")
+        flat2, pdbs2 = utils.create_flat_dataset_map(stem)
+        assert [tuple(map(str, r)) for r in flat] == [tuple(r) for r in flat2] and pdbs == pdbs2
+        X, y = utils.load_batch(src, flat)
+        X2, y2 = utils.load_batch(stem, flat2)
+        assert X2.dtype == (np.float32 if "bool" not in name else np.uint8)
+        assert np.array_equal(X.astype(np.float32), np.asarray(X2, dtype=np.float32)) and np.array_equal(y, y2)
+        # arbitrary (non-contiguous, reordered) rows
+        pick = [flat2[i] for i in (7, 3, 20, 4)]
+        Xa, ya = utils.load_batch(stem, pick)
+        Xb, yb = utils.load_batch(src, pick)
+        assert np.array_equal(np.asarray(Xa, dtype=np.float32), Xb.astype(np.float32)) and np.array_equal(ya, yb)
+        assert len(fp) == 26 and fp.frame_dims == (7, 7, 7, 5)
+    assert not framepack.is_pack(os.path.join(G, "frames_tiny.hdf5"))

@@ -80,6 +80,10 @@ def create_flat_dataset_map(
     whole pipeline relies on: pdb groups in HDF5 name order, chains in name order, residues sorted
     NUMERICALLY (the reference's ``np.int`` at :368 only runs on NumPy < 1.24; plain ``int`` here).
     Uncommon residue labels are mapped through aposteriori's table (:381-385)."""
+    from timed_hip import framepack
+    if framepack.is_pack(frame_dataset):  # packed dataset: the map was fixed when the pack was written
+        fmap = [tuple(r) for r in framepack.FramePack(frame_dataset).flat_map]
+        return fmap, {r[0] for r in fmap}
     standard_residues = list(standard_amino_acids.values())
     uncommon = UNCOMMON_RESIDUE_DICT if uncommon_residue_dict is None else uncommon_residue_dict
     training_set_pdbs = set()
@@ -115,6 +119,9 @@ def create_flat_dataset_map(
 def load_batch(dataset_path: Path, data_point_batch: t.List[t.Tuple]) -> (np.ndarray, np.ndarray):
     """reference utils.py:487-530: X[batch, *frame_dims] (float64 when voxels_as_gaussian, else bool —
     :518-521) and y[batch, 20] one-hot labels from the ``encoded_residue`` attribute."""
+    from timed_hip import framepack
+    if framepack.is_pack(dataset_path):  # HDF5-free fast path (SURVEY f-1): memory-mapped rows, no per-residue reads
+        return _frame_pack(dataset_path).load_batch(data_point_batch)
     batch_size = len(data_point_batch)
     with open_frame_dataset(dataset_path) as dataset:
         dims = tuple(int(d) for d in np.asarray(dataset.attrs["frame_dims"]).ravel())
@@ -126,6 +133,17 @@ def load_batch(dataset_path: Path, data_point_batch: t.List[t.Tuple]) -> (np.nda
             X[i] = np.asarray(ds[()])
             y[i] = np.asarray(ds.attrs["encoded_residue"])
     return X, y
+
+
+_PACKS: dict = {}
+
+
+def _frame_pack(path):
+    from timed_hip import framepack
+    key = framepack.pack_stem(path)
+    if key not in _PACKS:
+        _PACKS[key] = framepack.FramePack(path)
+    return _PACKS[key]
 
 
 # ---- rotamer codec ------------------------------------------------------------------------------------

@@ -1,0 +1,116 @@
+"""Packed frame datasets — the HDF5-free ingest path.
+
+The reference reads one small HDF5 dataset per residue, re-opening the file for every batch
+(reference design_utils/utils.py:514-529): a few hundred frames/s, three orders of magnitude below
+what the GPU consumes.  A *frame pack* is the same information laid out for streaming:
+
+    <stem>.frames.npy   [N, D, H, W, C]  uint8 (boolean datasets) or float32 (Gaussian datasets),
+                        rows in flat-dataset-map order (create_flat_dataset_map, reference utils.py:362-393)
+    <stem>.labels.npy   [N, 20] uint8 one-hot ``encoded_residue`` rows
+    <stem>.map.txt      the flat dataset map as the reference writes it (csv: pdb,chain,residue,label)
+    <stem>.meta.json    frame_dims, voxels_as_gaussian, source file, aposteriori version string
+
+``pack_dataset`` converts an aposteriori HDF5 file once (host side, any HDF5 reader); afterwards
+``FramePack.batch(lo, hi)`` is a zero-copy memory-mapped slice that goes straight to ``th_predict``.
+``design_utils.utils.load_batch`` / ``predict.load_dataset_and_predict`` accept a pack wherever they
+accept a ``.hdf5`` path.  Values are bit-identical to what ``load_batch`` would return (uint8 0/1 vs
+bool, float32 vs the float64 up-cast of float32 data — Keras casts to float32 either way).
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+SUFFIXES = (".frames.npy", ".labels.npy", ".map.txt", ".meta.json")
+
+
+def is_pack(path) -> bool:
+    p = os.fspath(path)
+    stem = pack_stem(p)
+    return stem is not None and all(os.path.exists(stem + s) for s in SUFFIXES)
+
+
+def pack_stem(path) -> Optional[str]:
+    p = os.fspath(path)
+    for s in SUFFIXES:
+        if p.endswith(s):
+            return p[: -len(s)]
+    if p.endswith(".framepack"):
+        return p[: -len(".framepack")]
+    if all(os.path.exists(p + s) for s in SUFFIXES):
+        return p
+    return None
+
+
+def pack_dataset(hdf5_path, out_stem, filter_list: Sequence[str] = (), remove_blacklist_silently: bool = False,
+                 progress_every: int = 0) -> "FramePack":
+    """Convert an aposteriori frame dataset (HDF5) into a frame pack.  One sequential pass."""
+    from design_utils import utils  # local import: design_utils imports timed_hip lazily too
+    out_stem = os.fspath(out_stem)
+    flat_map, _ = utils.create_flat_dataset_map(hdf5_path, list(filter_list), remove_blacklist_silently)
+    n = len(flat_map)
+    with utils.open_frame_dataset(hdf5_path) as ds:
+        dims = tuple(int(d) for d in np.asarray(ds.attrs["frame_dims"]).ravel())
+        gaussian = bool(ds.attrs["voxels_as_gaussian"])
+        ver = str(ds.attrs["make_frame_dataset_ver"]) if "make_frame_dataset_ver" in ds.attrs else ""
+        dtype = np.float32 if gaussian else np.uint8
+        frames = np.lib.format.open_memmap(out_stem + ".frames.npy", mode="w+", dtype=dtype, shape=(n, *dims))
+        labels = np.zeros((n, 20), dtype=np.uint8)
+        for i, (pdb, chain, res, _label) in enumerate(flat_map):
+            d = ds[pdb][chain][res]
+            fr = np.asarray(d[()])
+            if gaussian and fr.dtype != np.float32 and not np.array_equal(fr.astype(np.float32).astype(fr.dtype), fr):
+                raise ValueError(f"{pdb}/{chain}/{res}: frame values are not exactly representable in float32")
+            frames[i] = fr
+            labels[i] = np.asarray(d.attrs["encoded_residue"]).astype(np.uint8)
+            if progress_every and (i + 1) % progress_every == 0:
+                print(f"packed {i + 1}/{n} frames")
+        frames.flush()
+        del frames
+    np.save(out_stem + ".labels.npy", labels)
+    np.savetxt(out_stem + ".map.txt", np.asarray(flat_map), delimiter=",", fmt="%s")
+    with open(out_stem + ".meta.json", "w") as f:
+        json.dump(dict(frame_dims=list(dims), voxels_as_gaussian=gaussian, n_frames=n, source=os.path.basename(os.fspath(hdf5_path)),
+                       make_frame_dataset_ver=ver), f)
+    return FramePack(out_stem)
+
+
+class FramePack:
+    def __init__(self, path):
+        stem = pack_stem(path)
+        if stem is None or not all(os.path.exists(stem + s) for s in SUFFIXES):
+            raise FileNotFoundError(f"{path}: not a frame pack (need {', '.join(SUFFIXES)})")
+        self.stem = stem
+        self.meta = json.load(open(stem + ".meta.json"))
+        self.frames = np.load(stem + ".frames.npy", mmap_mode="r")
+        self.labels = np.load(stem + ".labels.npy")
+        self.flat_map = np.atleast_2d(np.genfromtxt(stem + ".map.txt", delimiter=",", dtype=str))
+        if len(self.flat_map) != self.frames.shape[0] or self.labels.shape[0] != self.frames.shape[0]:
+            raise ValueError(f"{stem}: inconsistent pack (map {len(self.flat_map)}, frames {self.frames.shape[0]})")
+        self._index: Optional[Dict[Tuple[str, str, str], int]] = None
+
+    def __len__(self):
+        return self.frames.shape[0]
+
+    @property
+    def frame_dims(self):
+        return tuple(self.meta["frame_dims"])
+
+    def batch(self, lo: int, hi: int) -> Tuple[np.ndarray, np.ndarray]:
+        """Rows [lo, hi) of the flat map: (frames view, labels as float like load_batch's y)."""
+        return self.frames[lo:hi], self.labels[lo:hi].astype(float)
+
+    def rows_of(self, data_point_batch) -> np.ndarray:
+        if self._index is None:
+            self._index = {(str(p), str(c), str(r)): i for i, (p, c, r, _l) in enumerate(self.flat_map)}
+        return np.array([self._index[(str(p), str(c), str(r))] for p, c, r, *_ in data_point_batch], dtype=np.int64)
+
+    def load_batch(self, data_point_batch) -> Tuple[np.ndarray, np.ndarray]:
+        """Same contract as design_utils.utils.load_batch for an arbitrary list of map rows."""
+        rows = self.rows_of(data_point_batch)
+        if len(rows) and np.array_equal(rows, np.arange(rows[0], rows[0] + len(rows))):
+            return self.batch(int(rows[0]), int(rows[0]) + len(rows))
+        return np.asarray(self.frames[rows]), self.labels[rows].astype(float)
