@@ -54,9 +54,16 @@ def cpu_baseline(cfg, weights, topology: str, budget_s: float = 15.0):
     t0 = time.perf_counter()
     cnn_oracle.forward(cfg, weights, frames)
     dt = time.perf_counter() - t0
-    return dict(value=n / dt, unit="frames/s", cores=os.cpu_count(), kind="port",
-                sample=f"{n} synthetic frames of {topology} through oracle/cnn_oracle.py (NumPy im2col + BLAS sgemm, "
-                       f"fp32), {dt:.1f} s wall")
+    # threads actually used: the BLAS pool NumPy's matmul runs on (im2col gather and elementwise ops are 1 thread)
+    threads = 1
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] or [1])
+    except Exception:
+        pass
+    return dict(value=n / dt, unit="frames/s", cores=threads, kind="port",
+                sample=f"{n} synthetic frames of {topology} through oracle/cnn_oracle.py (NumPy im2col + BLAS sgemm on "
+                       f"{threads} threads of {os.cpu_count()} host cores, fp32), {dt:.1f} s wall")
 
 
 def pmc_traffic(label: str, avg_ms: float):

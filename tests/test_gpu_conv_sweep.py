@@ -1,0 +1,130 @@
+"""Per-element parity of the fused convolution kernels over a sweep of shapes: non-cubic volumes,
+odd channel counts, anisotropic / 1x1x1 / 5x5x5 kernels, 'same' vs 'valid', pooling on odd extents,
+pre-activation (BN -> ReLU -> Conv) and post-activation chains, channel-offset writes into concat
+buffers, batch sizes that do not divide the frames-per-workgroup.  The block output is Flatten-ed so
+every voxel/channel is compared against the CPU oracle (tolerance 2e-5 relative to the tensor's scale;
+fp32 MFMA vs BLAS differ only in accumulation order)."""
+import numpy as np
+import pytest
+
+from oracle import cnn_oracle
+from timed_hip import _lib, engine, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _net(shape, cin, build, seed=0, bias_std=0.3):
+    b = synth.KerasGraphBuilder((*shape, cin), seed=seed, bias_std=bias_std)
+    x = build(b, b.input_name)
+    x = b.flatten(x)
+    return b.finish(x)
+
+
+def _frames(n, shape, cin, seed):
+    rng = np.random.default_rng(seed)
+    return (rng.standard_normal((n, *shape, cin)) * (rng.random((n, *shape, cin)) < 0.5)).astype(np.float32)
+
+
+def _check(cfg, weights, frames, flags=0, chunk=None):
+    want = cnn_oracle.forward(cfg, weights, frames, np.float32)
+    m = engine.HipFrameModel.from_keras(cfg, weights, flags=flags)
+    if chunk:
+        m.set_chunk(chunk)
+    got = m.predict(frames)
+    labels = [s["label"] for s in m.steps()]
+    m.close()
+    scale = max(1.0, float(np.abs(want).max()))
+    err = float(np.abs(got - want).max())
+    assert got.shape == want.shape and err <= 2e-5 * scale, (err, scale, labels)
+    return labels
+
+
+# (shape, cin, cout, kernel, padding, pool, post, n_frames)
+SWEEP = [
+    ((21, 21, 21), 6, 32, 3, "same", "max", "elu_bn", 3),      # TIMED block 1 -> conv_first
+    ((21, 21, 21), 5, 24, 3, "same", "max", "elu_bn", 2),      # 5-channel codec (CNOCBCA), Cout not a multiple of 32
+    ((9, 7, 5), 3, 7, 3, "same", None, "relu", 5),              # non-cubic, tiny channel counts
+    ((9, 7, 5), 8, 32, 3, "valid", "avg", "bn_relu", 5),        # valid padding + average pool on odd extents
+    ((10, 10, 10), 32, 64, 3, "same", "max", "elu_bn", 3),      # TIMED block 2 shape
+    ((5, 5, 5), 64, 128, 3, "same", None, "elu_bn", 7),         # TIMED block 3, n not a multiple of frames/workgroup
+    ((5, 5, 5), 40, 130, 3, "same", None, "leaky", 3),          # Cin not a multiple of 16, Cout spans two N blocks
+    ((5, 5, 5), 128, 20, 3, "same", None, "elu_bn", 5),         # last TIMED conv (Cout 20 -> padded tile)
+    ((6, 6, 6), 48, 16, 3, "same", None, "none", 5),            # narrow output -> conv_n16
+    ((10, 10, 10), 64, 16, 3, "same", None, "bn_relu", 2),      # DenseCPD growth conv shape
+    ((4, 4, 4), 24, 12, 3, "same", "max", "relu", 9),           # conv_n16 + pool, Cout < 16
+    ((8, 8, 8), 20, 64, 1, "same", None, "bn_relu", 3),         # 1x1x1 bottleneck
+    ((7, 7, 7), 6, 16, 5, "same", None, "relu", 2),             # 5x5x5 kernel (125 taps)
+    ((8, 6, 7), 12, 40, (3, 1, 3), "same", None, "elu", 3),     # anisotropic kernel
+    ((2, 2, 2), 96, 16, 3, "same", None, "none", 17),           # tiny volume (DenseCPD block 3)
+]
+
+
+@pytest.mark.parametrize("shape,cin,cout,k,padding,pool,post,n", SWEEP)
+def test_fused_conv_block_per_element(gpu, shape, cin, cout, k, padding, pool, post, n):
+    def build(b, x):
+        x = b.conv3d(x, cout, k, padding=padding)
+        if post == "elu_bn":
+            x = b.batchnorm(b.elu(x))
+        elif post == "bn_relu":
+            x = b.relu(b.batchnorm(x))
+        elif post == "relu":
+            x = b.relu(x)
+        elif post == "elu":
+            x = b.elu(x, 0.7)
+        elif post == "leaky":
+            x = b.leaky_relu(x, 0.2)
+        if pool == "max":
+            x = b.maxpool(x, 2)
+        elif pool == "avg":
+            x = b.avgpool(x, 2)
+        return x
+
+    cfg, weights = _net(shape, cin, build, seed=hash((shape, cin, cout)) % 1000)
+    frames = _frames(n, shape, cin, seed=n)
+    labels = _check(cfg, weights, frames)
+    assert any("conv_" in l for l in labels), labels               # an MFMA kernel ran, not the direct fallback
+    _check(cfg, weights, frames, flags=_lib.TH_LOAD_NO_MFMA)        # and the generic path agrees too
+    _check(cfg, weights, frames, chunk=2)                           # ragged chunks
+
+
+def test_preactivation_dense_layer_with_concat(gpu):
+    """BN -> ReLU -> Conv1x1 -> BN -> ReLU -> Conv3x3x3 -> Concat, twice, written at channel offsets."""
+    def build(b, x):
+        x = b.conv3d(x, 24, 3, padding="same")
+        for _ in range(2):
+            y = b.relu(b.batchnorm(x))
+            y = b.conv3d(y, 32, 1, padding="same", use_bias=False)
+            y = b.relu(b.batchnorm(y))
+            y = b.conv3d(y, 16, 3, padding="same", use_bias=False)
+            x = b.concat([x, y])
+        return b.relu(b.batchnorm(x))
+
+    cfg, weights = _net((6, 6, 6), 6, build, seed=3)
+    labels = _check(cfg, weights, _frames(5, (6, 6, 6), 6, 1))
+    assert sum("concat(copy" in l for l in labels) == 0, labels      # zero-copy concat
+    assert any("conv_n16" in l for l in labels), labels
+
+
+def test_branches_add_and_strided_fallback(gpu):
+    def build(b, x):
+        a = b.conv3d(x, 16, 3, padding="same", activation="relu")
+        c = b.conv3d(x, 16, (1, 3, 3), padding="same", activation="elu")
+        s = b.add([a, c])
+        t = b.conv3d(s, 20, 3, strides=2, padding="same")            # stride 2 -> direct kernel
+        return b.batchnorm(t)
+
+    cfg, weights = _net((9, 9, 9), 4, build, seed=5)
+    _check(cfg, weights, _frames(4, (9, 9, 9), 4, 2))
+
+
+def test_nan_and_extreme_inputs_propagate_like_numpy(gpu):
+    cfg, weights = _net((5, 5, 5), 6, lambda b, x: b.elu(b.conv3d(x, 8, 3, padding="same")), seed=9)
+    fr = _frames(3, (5, 5, 5), 6, 4)
+    fr[1, 2, 2, 2, 3] = np.nan
+    fr[2, 0, 0, 0, 0] = 1e30
+    want = cnn_oracle.forward(cfg, weights, fr, np.float32)
+    got = engine.HipFrameModel.from_keras(cfg, weights).predict(fr)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    ok = np.isfinite(want)
+    np.testing.assert_allclose(got[ok], want[ok], rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(want[ok]).max())))
+    assert np.array_equal(got[0], engine.HipFrameModel.from_keras(cfg, weights).predict(fr[:1])[0])  # frame independence

@@ -53,14 +53,16 @@ class KerasGraphBuilder:
     def conv3d(self, x, filters, k=3, strides=1, padding="same", activation="linear", use_bias=True):
         d, h, w, cin = self.shapes[x]
         same = padding == "same"
-        fan_in = k * k * k * cin
-        kern = (self.rng.standard_normal((k, k, k, cin, filters)) * np.sqrt(2.0 / fan_in)).astype(np.float32)
+        ks = (k, k, k) if isinstance(k, int) else tuple(k)   # anisotropic kernels allowed: k=(3, 1, 3)
+        fan_in = ks[0] * ks[1] * ks[2] * cin
+        kern = (self.rng.standard_normal((*ks, cin, filters)) * np.sqrt(2.0 / fan_in)).astype(np.float32)
         ws = [kern]
         if use_bias:
             ws.append((self.rng.standard_normal(filters) * self.bias_std).astype(np.float32))
-        shape = (self._out(d, k, strides, same), self._out(h, k, strides, same), self._out(w, k, strides, same), filters)
+        shape = (self._out(d, ks[0], strides, same), self._out(h, ks[1], strides, same), self._out(w, ks[2], strides, same),
+                 filters)
         name = self._emit("Conv3D", "conv3d",
-                          dict(filters=filters, kernel_size=[k] * 3, strides=[strides] * 3, padding=padding,
+                          dict(filters=filters, kernel_size=list(ks), strides=[strides] * 3, padding=padding,
                                data_format="channels_last", dilation_rate=[1, 1, 1], groups=1,
                                activation=activation, use_bias=use_bias, trainable=True, dtype="float32"),
                           [x], shape)
