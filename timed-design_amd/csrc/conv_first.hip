@@ -21,6 +21,7 @@
 #include <hip/hip_fp16.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -273,6 +274,10 @@ bool conv_first_plan(int Din, int Hin, int Win, int Cin, const TView& oc, const 
     if (!ZB) return false;
     for (int zb = ZB; zb >= step && zb * 10 >= ZB * 6; zb -= step)
         if (p->Dc % zb == 0) { ZB = zb; break; }
+    if (const char* e = getenv("TH_FIRST_ZB")) {  // tuning experiments
+        const int zb = atoi(e);
+        if (zb >= step && zb % step == 0 && zb <= p->Dc && lds_for(zb) <= (size_t)160 * 1024) ZB = zb;
+    }
     p->ZB = ZB;
     p->nzb = (p->Dc + ZB - 1) / ZB;
     p->Zp = ZB + 2;

@@ -805,11 +805,13 @@ int th_model_set_chunk(th_model* m, int frames_per_chunk) {
 }
 
 int th_predict_device(th_model* m, const void* d_frames, int dtype, int64_t n, float* d_probs, unsigned flags) {
+    if (n < 0) TH_FAIL(TH_EINVAL, "negative frame count");
     if (!m || (n > 0 && (!d_frames || !d_probs))) TH_FAIL(TH_EINVAL, "null argument");
     return run_device(m, d_frames, dtype, n, d_probs, flags);
 }
 
 int th_predict(th_model* m, const void* frames, int dtype, int64_t n, float* probs_out, unsigned flags) {
+    if (n < 0) TH_FAIL(TH_EINVAL, "negative frame count");
     if (!m || (n > 0 && (!frames || !probs_out))) TH_FAIL(TH_EINVAL, "null argument");
     const size_t esz = dtype_size(dtype);
     if (!esz) TH_FAIL(TH_EINVAL, "unknown frame dtype %d", dtype);
