@@ -40,7 +40,7 @@ struct ConvMfmaArgs {
     int kd, kh, kw, pz, py, px, ntaps;
     int Dc, Hc, Wc;
     int FB, ZB, nzb, Zp, Hp, Wp, rows_pf, nrows, n_mtiles;
-    int CS, nchunks, nnb, tab_off, dbg;  // dbg: timing experiments only (TH_CONV_DBG), results are wrong when set
+    int CS, nchunks, nnb, tab_off, zmajor, dbg;  // dbg: timing experiments only (TH_CONV_DBG), results are wrong when set
     const float* wpk;
     int Cout;
     const float* bias;
@@ -95,16 +95,44 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
         voxsrc[v] = ok ? f * (int)a.in_fs + ((zi * a.Hin + yi) * a.Win + xi) * a.in_cs : -1;
     }
 
+    // per m-tile bitmask over dz: set when EVERY row of the tile reads the zero halo for that dz
+    int* tskip = voxsrc + nvox;
+    for (int mt = tid; mt < a.n_mtiles; mt += NTHREADS) {
+        int mask = 0;
+        if (POOL == 0 && a.zmajor) {
+            const int ZBv = min(a.ZB, a.Dc - z0);
+            const int fhw = a.FB * a.Hc * a.Wc, total = ZBv * fhw;
+            if (mt * 32 >= total) mask = 0xff;
+            else {
+                const int zlo = z0 + (mt * 32) / fhw, zhi = z0 + min(mt * 32 + 31, total - 1) / fhw;
+                for (int dz = 0; dz < a.kd && dz < 8; ++dz)
+                    if (zhi + dz - a.pz < 0 || zlo + dz - a.pz >= a.Din) mask |= 1 << dz;
+            }
+        }
+        tskip[mt] = mask;
+    }
+
     // ---- row tables: GEMM row -> staged voxel index, and -> output offset -----------------------
     {
         const int ZBv = min(a.ZB, a.Dc - z0);
         for (int r = tid; r < a.nrows; r += NTHREADS) {
-            const int f = r / a.rows_pf, q = r - f * a.rows_pf;
-            const bool fok = (f0 + f) < a.nframes;
+            int f = r / a.rows_pf, q = r - f * a.rows_pf;
+            bool fok = (f0 + f) < a.nframes;
             int vox = 0, oo = -1;
             if (POOL == 0) {
                 const int hw = a.Hc * a.Wc;
-                if (fok && q < ZBv * hw) {
+                bool rok = q < ZBv * hw;
+                if (a.zmajor) {
+                    // rows ordered (z, frame, y, x): a 32-row tile then usually lies inside ONE z-plane, and
+                    // tiles of the first/last plane can skip the taps that only ever see the zero halo
+                    const int fhw = a.FB * hw;
+                    rok = r < ZBv * fhw;
+                    const int zl0 = r / fhw, rem0 = r - zl0 * fhw;
+                    f = rem0 / hw;
+                    q = zl0 * hw + (rem0 - f * hw);
+                    fok = (f0 + f) < a.nframes;
+                }
+                if (fok && rok) {
                     const int zl = q / hw, rem = q - zl * hw, y = rem / a.Wc, x = rem - y * a.Wc;
                     vox = ((f * a.Zp + zl) * a.Hp + y) * a.Wp + x;
                     oo = f * (int)a.out_fs + (((z0 + zl) * a.Ho + y) * a.Wo + x) * a.out_cs;
@@ -146,11 +174,15 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
                 for (int i = 0; i < 16; ++i) acc[tm][tn][i] = 0.f;
 
         if (rd == 0) __syncthreads();  // row tables visible
-        int aidx[TM], bidx[TN];
+        // a wave's TM m-tiles are interleaved (mb, mb + nmb, ...) so that every wave gets its share of the
+        // boundary-plane tiles that skip taps
+        const int nmb = (a.n_mtiles + TM - 1) / TM;
+        int aidx[TM], bidx[TN], skp[TM];
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
-            const int mt = mb * TM + tm;
+            const int mt = mb + tm * nmb;
             aidx[tm] = (mt < a.n_mtiles ? rowvox[mt * 32 + j] : 0) * CS4 + h;
+            skp[tm] = __builtin_amdgcn_readfirstlane((active && mt < a.n_mtiles) ? tskip[mt] : 0xff);
         }
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) bidx[tn] = ((nbw * TN + tn) * 32 + j) * CS4 + h;
@@ -256,6 +288,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
                         for (int tm = 0; tm < TM; ++tm) avA[tm] = A4[aidx[tm]];
                         int toff_cur = 0;
                         for (int tap = 0; tap < a.ntaps; ++tap) {
+                            const int cz = tz;  // dz of the current tap
                             const int toff_nxt = advance();
                             const float4* wn = wf + (size_t)min(tap + 1, a.ntaps - 1) * TAPSTRIDE;
                             // ---- stage 0 ----
@@ -263,7 +296,8 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
                             for (int tm = 0; tm < TM; ++tm) avB[tm] = A4[aidx[tm] + toff_cur + 2];
                             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                            for (int tm = 0; tm < TM; ++tm)
+                            for (int tm = 0; tm < TM; ++tm) {
+                                if ((skp[tm] >> cz) & 1) continue;  // whole tile sees only the zero halo for this dz
 #pragma unroll
                                 for (int tn = 0; tn < TN; ++tn) {
                                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(avA[tm].x, bc[0][tn].x, acc[tm][tn], 0, 0, 0);
@@ -271,6 +305,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
                                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(avA[tm].z, bc[0][tn].z, acc[tm][tn], 0, 0, 0);
                                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(avA[tm].w, bc[0][tn].w, acc[tm][tn], 0, 0, 0);
                                 }
+                            }
                             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                             for (int tn = 0; tn < TN; ++tn) bc[0][tn] = wn[tn * 64];
@@ -279,7 +314,8 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
                             for (int tm = 0; tm < TM; ++tm) avA[tm] = A4[aidx[tm] + toff_nxt];
                             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                            for (int tm = 0; tm < TM; ++tm)
+                            for (int tm = 0; tm < TM; ++tm) {
+                                if ((skp[tm] >> cz) & 1) continue;  // whole tile sees only the zero halo for this dz
 #pragma unroll
                                 for (int tn = 0; tn < TN; ++tn) {
                                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(avB[tm].x, bc[1][tn].x, acc[tm][tn], 0, 0, 0);
@@ -287,6 +323,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
                                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(avB[tm].z, bc[1][tn].z, acc[tm][tn], 0, 0, 0);
                                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(avB[tm].w, bc[1][tn].w, acc[tm][tn], 0, 0, 0);
                                 }
+                            }
                             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                             for (int tn = 0; tn < TN; ++tn) bc[1][tn] = wn[(NT + tn) * 64];
@@ -421,7 +458,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
                 float* outb = a.out + f0 * a.out_fs + a.out_coff;
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm) {
-                    const int mt = mb * TM + tm;
+                    const int mt = mb + tm * nmb;
                     const bool mt_ok = mt < a.n_mtiles;
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn) {
@@ -467,7 +504,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
                 for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn) {
-                        const int mt = mb * TM + tm;
+                        const int mt = mb + tm * nmb;
 #pragma unroll
                         for (int i = 0; i < 16; ++i) T[((i & 3) + 8 * (i >> 2) + 4 * h) * 33 + j] = acc[tm][tn][i];
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -800,7 +837,7 @@ static bool plan_with_cfg(int cfg, size_t lds_limit, bool whole_frames_only, con
     auto tab_bytes = [&](int fb, int zb) {
         const size_t nvox = (size_t)fb * (zb + g.kd - 1) * p->Hp * p->Wp;
         const int nrows = fb * rows_for(zb);
-        return (size_t)nrows * 4 + (size_t)(pool ? nrows / 8 : nrows) * 4 + (size_t)ntaps * 4 + nvox * 4;
+        return (size_t)nrows * 4 + (size_t)(pool ? nrows / 8 : nrows) * 4 + (size_t)ntaps * 4 + nvox * 4 + (size_t)(nrows / 32) * 4;
     };
     auto lds_for = [&](int fb, int zb) {
         const size_t nvox = (size_t)fb * (zb + g.kd - 1) * p->Hp * p->Wp;
@@ -981,6 +1018,7 @@ int launch_conv_mfma(hipStream_t s, int64_t n, const ConvMfmaPlan& p, TView in, 
     a.rows_pf = p.rows_pf; a.nrows = p.FB * p.rows_pf; a.n_mtiles = a.nrows / 32;
     a.CS = p.CS; a.nchunks = p.nchunks; a.nnb = p.nnb;
     a.tab_off = (int)p.tab_off;
+    { static const bool nozm = getenv("TH_CONV_NOZMAJOR") != nullptr; a.zmajor = (!nozm && !n16 && p.pool == 0 && p.bres == 2 && c.CI == 16) ? 1 : 0; }
     { static const int dbg = getenv("TH_CONV_DBG") ? atoi(getenv("TH_CONV_DBG")) : 0; a.dbg = dbg; }
     a.wpk = wpk; a.Cout = Cout; a.bias = bias; a.pre = pre; a.post = post;
     a.out = out.p; a.out_fs = out.fs; a.out_cs = out.cs; a.out_coff = out.coff; a.Ho = out.H; a.Wo = out.W;
