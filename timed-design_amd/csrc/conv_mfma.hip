@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
         int aidx[TM], bidx[TN], skp[TM];
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
-            const int mt = mb + tm * nmb;
+            const int mt = a.zmajor ? mb + tm * nmb : mb * TM + tm;
             aidx[tm] = (mt < a.n_mtiles ? rowvox[mt * 32 + j] : 0) * CS4 + h;
             skp[tm] = __builtin_amdgcn_readfirstlane((active && mt < a.n_mtiles) ? tskip[mt] : 0xff);
         }
@@ -458,7 +458,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
                 float* outb = a.out + f0 * a.out_fs + a.out_coff;
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm) {
-                    const int mt = mb + tm * nmb;
+                    const int mt = a.zmajor ? mb + tm * nmb : mb * TM + tm;
                     const bool mt_ok = mt < a.n_mtiles;
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn) {
@@ -504,7 +504,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
                 for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn) {
-                        const int mt = mb + tm * nmb;
+                        const int mt = a.zmajor ? mb + tm * nmb : mb * TM + tm;
 #pragma unroll
                         for (int i = 0; i < 16; ++i) T[((i & 3) + 8 * (i >> 2) + 4 * h) * 33 + j] = acc[tm][tn][i];
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
