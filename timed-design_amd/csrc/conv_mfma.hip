@@ -34,6 +34,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 namespace {
 
 constexpr size_t kLdsLimit = 160 * 1024;
+#ifndef STAGE_U
+#define STAGE_U 8  // staging loads in flight per thread
+#endif
 
 struct ConvMfmaArgs {
     const float* in; int64_t in_fs; int in_cs, in_coff, Din, Hin, Win, Cin, vec_ok;
@@ -197,7 +200,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
                 // voxsrc[v] (built once per workgroup) holds the source offset of staged voxel v or -1 for
                 // halo / out-of-range: no index arithmetic here, and loads go out 4 at a time so their L2
                 // latencies overlap instead of serialising.
-                constexpr int U = 4;
+                constexpr int U = STAGE_U;
                 const int nvec = nvox * CI4;
                 const float* inb = a.in + f0 * a.in_fs + a.in_coff + ch * CI;
                 const bool has_pre = a.pre.scale || a.pre.act != ACT_LINEAR;
@@ -652,7 +655,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
             const bool need_a = !(a.nchunks == 1 && rd > 0);
             __syncthreads();
             if (need_a) {
-                constexpr int U = 4;
+                constexpr int U = 4;  // breg[27] is live here: keep the staging footprint small
                 const int nvec = nvox * CI4;
                 const float* inb = a.in + f0 * a.in_fs + a.in_coff + ch * CI;
                 const bool has_pre = a.pre.scale || a.pre.act != ACT_LINEAR;
