@@ -53,6 +53,9 @@ SWEEP = [
     ((10, 10, 10), 64, 16, 3, "same", None, "bn_relu", 2),      # DenseCPD growth conv shape
     ((4, 4, 4), 24, 12, 3, "same", "max", "relu", 9),           # conv_n16 + pool, Cout < 16
     ((8, 8, 8), 20, 64, 1, "same", None, "bn_relu", 3),         # 1x1x1 bottleneck
+    ((7, 5, 9), 18, 100, 1, "same", "max", "elu_bn", 3),        # 1x1x1: Cin % 4 != 0, 4 output tiles, max pool on odd extents
+    ((5, 5, 5), 136, 48, 1, "valid", "avg", "none", 5),         # 1x1x1: K > 128 (two K passes) + avg pool (transition layer)
+    ((3, 3, 3), 12, 130, 1, "same", None, "relu", 4),           # 1x1x1 with Cout > 128 -> generic MFMA kernel
     ((7, 7, 7), 6, 16, 5, "same", None, "relu", 2),             # 5x5x5 kernel (125 taps)
     ((8, 6, 7), 12, 40, (3, 1, 3), "same", None, "elu", 3),     # anisotropic kernel
     ((2, 2, 2), 96, 16, 3, "same", None, "none", 17),           # tiny volume (DenseCPD block 3)
@@ -103,6 +106,29 @@ def test_preactivation_dense_layer_with_concat(gpu):
     labels = _check(cfg, weights, _frames(5, (6, 6, 6), 6, 1))
     assert sum("concat(copy" in l for l in labels) == 0, labels      # zero-copy concat
     assert any("conv_n16" in l for l in labels), labels
+
+
+def test_dense_block_transition_pointwise_kernel(gpu):
+    """DenseCPD transition: concat buffer -> BN -> ReLU -> Conv1x1x1 (no bias) -> AvgPool(2), plus a
+    bottleneck that reads a channel slice at a non-16-byte-aligned offset (scalar load path)."""
+    def build(b, x):
+        x = b.conv3d(x, 18, 3, padding="same")                       # 18 channels: the next concat slice starts at offset 18
+        y = b.relu(b.batchnorm(x))
+        y = b.conv3d(y, 32, 1, padding="same", use_bias=False)
+        y = b.relu(b.batchnorm(y))
+        y = b.conv3d(y, 14, 3, padding="same", use_bias=False)
+        x = b.concat([x, y])                                         # 32 channels
+        z = b.relu(b.batchnorm(y))                                   # reads the slice at channel offset 18
+        z = b.conv3d(z, 40, 1, padding="same")
+        t = b.relu(b.batchnorm(x))
+        t = b.avgpool(b.conv3d(t, 16, 1, padding="same", use_bias=False), 2)
+        return b.concat([b.avgpool(z, 2), t])
+
+    cfg, weights = _net((7, 6, 6), 5, build, seed=11)
+    labels = _check(cfg, weights, _frames(5, (7, 6, 6), 5, 6))
+    assert sum("conv_pw" in l for l in labels) == 3, labels
+    assert any("conv_pw" in l and "pool2" in l for l in labels), labels
+    _check(cfg, weights, _frames(3, (7, 6, 6), 5, 7), flags=_lib.TH_LOAD_NO_MFMA)
 
 
 def test_branches_add_and_strided_fallback(gpu):

@@ -116,6 +116,12 @@ void conv_first_pack_weights(int Cin, int Cout, const float* w_keras, float* dst
 int launch_conv_first(hipStream_t s, int64_t n, const ConvMfmaPlan& p, const void* frames, int dtype, int Din, int Hin,
                       int Win, int Cin, TView out, ConvGeom g, int Cout, const float* wpk, const float* bias, PostOps post);
 
+// ---- pointwise (1x1x1) streaming convolution (conv_pointwise.hip); plan.cfg in [300, 309) ----
+bool conv_pw_plan(const TView& in, const TView& out_conv, const ConvGeom& g, int Cin, int Cout, int pool, ConvMfmaPlan* plan);
+void conv_pw_pack_weights(const ConvMfmaPlan& p, int Cin, int Cout, const float* w_keras, float* dst);
+int launch_conv_pw(hipStream_t s, int64_t n, const ConvMfmaPlan& p, TView in, TView out, int Cin, int Cout, const float* wpk,
+                   const float* bias, PreOp pre, PostOps post);
+
 // ---- sampler (sampler.hip) -----------------------------------------------------------------
 int sampler_run(int device, const double* h_probs, int64_t n_res, int n_cls, int64_t n_samples, double temperature,
                 int rng_mode, uint64_t seed, uint64_t rng_offset, const double* h_uniforms, int32_t* h_idx, double* h_r_out,

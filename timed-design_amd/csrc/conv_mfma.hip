@@ -875,6 +875,23 @@ static bool plan_with_cfg(int cfg, size_t lds_limit, bool whole_frames_only, con
     p->wpk_floats = (size_t)p->nnb * p->nchunks * ntaps * p->BN * (c.BRES == 2 ? c.CI : p->CS);
     const double rows_exec = (double)p->nzb * p->rows_pf;  // per frame
     p->exec_flops = 2.0 * rows_exec * (double)(p->nnb * p->BN) * (double)(p->nchunks * c.CI) * ntaps;
+    if (p->pool == 0 && c.BRES == 2 && c.CI == 16 && g.kd <= 8) {
+        // z-major rows: m-tiles whose rows all read the zero halo for a dz skip that dz's taps
+        // (same rule as the kernel's tskip table); exec_flops counts what is actually issued
+        const int n_mtiles = FB * p->rows_pf / 32, fhw = FB * p->Hc * p->Wc;
+        double issued = 0, full = 0;
+        for (int zbk = 0; zbk < p->nzb; ++zbk) {
+            const int z0 = zbk * ZB, ZBv = std::min(ZB, p->Dc - z0), total = ZBv * fhw;
+            for (int mt = 0; mt < n_mtiles; ++mt) {
+                full += g.kd;
+                if (mt * 32 >= total) continue;   // whole tile is padding: never issued
+                const int zlo = z0 + (mt * 32) / fhw, zhi = z0 + std::min(mt * 32 + 31, total - 1) / fhw;
+                for (int dz = 0; dz < g.kd; ++dz)
+                    if (!(zhi + dz - g.pz < 0 || zlo + dz - g.pz >= in.D)) issued += 1;
+            }
+        }
+        if (full > 0) p->exec_flops *= issued / full;
+    }
     if ((int64_t)FB * oc.fs > 0x7fffffffLL || (int64_t)FB * in.D * in.H * in.W * std::max(in.cs, in.C) > 0x7fffffffLL) return false;
     char buf[224];
     snprintf(buf, sizeof buf, "conv_mfma<w%d,%dx%d,nt%d,ci%d,%s,pool%d> FB%d ZB%d/%d rows%d lds%zuK [k_conv_mfma<%d,%d,%d,%d,%d,%d,%d>]",

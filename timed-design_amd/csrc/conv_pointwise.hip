@@ -1,0 +1,283 @@
+// Pointwise (1x1x1, stride 1) fused Conv3D for gfx950 — the DenseCPD/DenseNet bottleneck and
+// transition convolutions (BN -> ReLU -> Conv1^3 [-> AvgPool 2]; SURVEY.md §8(d) DenseCPD-synth,
+// reference README.md:242-258 for the model family, predict.py:142 for the call that runs it).
+//
+// A 1x1x1 convolution is a plain GEMM  Y[M, Cout] = post(pre(X[M, Cin]) . W + b)  over M = frames x
+// voxels rows with arithmetic intensity ~ Cin*Cout/(2(Cin+Cout)) FLOP/B ~ 18 for 80 -> 64: it sits at
+// the ridge of the fp32-MFMA / HBM roofline, so it is built as a STREAMING kernel, not as the
+// haloed-brick implicit GEMM of conv_mfma.hip:
+//   * no LDS staging of activations and no barrier in the loop: lane (j = l&31, h = l>>5) reads the
+//     4 channels its MFMA k-slot contracts straight from global memory (16 B per lane, all Cin/8
+//     loads of a 32-row tile issued back to back so every 128 B line is fetched once);
+//   * the whole weight matrix sits in LDS in MFMA fragment order (one conflict-free ds_read_b128 per
+//     4 MFMAs), loaded once per workgroup; workgroups are persistent and stride over the row tiles;
+//   * the BN->ReLU prologue is applied to the loaded registers, bias + {act | BN-affine}* to the
+//     accumulators, and a 2x2x2 max/avg pool is reduced in registers: GEMM rows are grouped 8
+//     pool-mates per output voxel, which the 32x32 accumulator layout puts in 4 registers of lane l
+//     and 4 of lane l^32 -> one cross-half exchange;
+//   * stores are 128 B per (row, 32-channel tile): lanes 0..31 hold consecutive channels of one row.
+// v_mfma_f32_32x32x2_f32, exact fp32.  Four 4-wave workgroups per CU hide the load latency.
+#include "common.h"
+#include "device_math.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+struct ConvPwArgs {
+    const float* in; int64_t in_fs; int in_cs, in_coff, Cin, K8, vec_ok, in_dense;
+    int V, H, W;        // conv extent per frame (input voxels), V = D*H*W
+    int Vo, Ho, Wo;     // pooled extent (POOL != 0)
+    const float* wpk;
+    int Cout;
+    const float* bias;
+    PreOp pre;
+    PostOps post;
+    float* out; int64_t out_fs; int out_cs, out_coff, out_dense;
+    unsigned nrows;     // GEMM rows: frames*V, or frames*Vo*8 when pooled
+    unsigned ntiles;
+};
+
+// KMAX: float4 A-slots a lane keeps per K pass (8 channels each); NT: 32-wide output tiles; POOL 0/1 max/2 avg
+template <int KMAX, int NT, int POOL>
+__global__ void __launch_bounds__(256, NT == 4 ? 2 : (KMAX == 16 && NT == 2 ? 3 : 4)) k_conv_pw(const ConvPwArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float4 smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int K8 = a.K8;
+
+    // ---- weights (fragment order [kk][nt][lane] float4) and prologue constants -> LDS ---------------
+    float4* Bs = smem;
+    float* psc = reinterpret_cast<float*>(smem + (size_t)K8 * NT * 64);
+    float* psh = psc + K8 * 8;
+    {
+        const float4* src = reinterpret_cast<const float4*>(a.wpk);
+        for (int i = tid; i < K8 * NT * 64; i += 256) Bs[i] = src[i];
+        for (int i = tid; i < K8 * 8; i += 256) {
+            psc[i] = (a.pre.scale && i < a.Cin) ? a.pre.scale[i] : 1.f;
+            psh[i] = (a.pre.shift && i < a.Cin) ? a.pre.shift[i] : 0.f;
+        }
+    }
+    __syncthreads();
+    const bool has_pre = a.pre.scale != nullptr || a.pre.act != ACT_LINEAR;
+
+    const unsigned wstride = gridDim.x * 4;
+    for (unsigned tile = blockIdx.x * 4 + wave; tile < a.ntiles; tile += wstride) {
+        // ---- this lane's input row ---------------------------------------------------------------------
+        const float* src;
+        bool rok;
+        if (POOL == 0) {
+            const unsigned r = tile * 32 + j;
+            rok = r < a.nrows;
+            const unsigned rc = rok ? r : a.nrows - 1;
+            if (a.in_dense) src = a.in + (int64_t)rc * a.in_cs;
+            else { const unsigned f = rc / (unsigned)a.V; src = a.in + (int64_t)f * a.in_fs + (int64_t)(rc - f * a.V) * a.in_cs; }
+        } else {
+            const unsigned p = tile * 4 + (j >> 3), m = j & 7;
+            rok = p * 8 < a.nrows;
+            const unsigned pc = rok ? p : a.nrows / 8 - 1;
+            const unsigned f = pc / (unsigned)a.Vo, vo = pc - f * a.Vo;
+            const unsigned zo = vo / (unsigned)(a.Ho * a.Wo), rem = vo - zo * (a.Ho * a.Wo);
+            const unsigned yo = rem / (unsigned)a.Wo, xo = rem - yo * a.Wo;
+            const unsigned v = ((2 * zo + (m >> 2)) * a.H + 2 * yo + ((m >> 1) & 1)) * a.W + 2 * xo + (m & 1);
+            src = a.in + (int64_t)f * a.in_fs + (int64_t)v * a.in_cs;
+        }
+        src += a.in_coff + 4 * h;
+
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+
+        for (int k0 = 0; k0 < K8; k0 += KMAX) {
+            float4 av[KMAX];
+#pragma unroll
+            for (int u = 0; u < KMAX; ++u) {
+                const int c = (k0 + u) * 8 + 4 * h;   // first of this lane's 4 channels
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k0 + u < K8) {
+                    if (a.vec_ok && c + 3 < a.Cin) v = *reinterpret_cast<const float4*>(src + (k0 + u) * 8);
+                    else {
+                        const float* s = src + (k0 + u) * 8;
+                        if (c + 0 < a.Cin) v.x = s[0];
+                        if (c + 1 < a.Cin) v.y = s[1];
+                        if (c + 2 < a.Cin) v.z = s[2];
+                        if (c + 3 < a.Cin) v.w = s[3];
+                    }
+                }
+                av[u] = v;
+            }
+#pragma unroll
+            for (int u = 0; u < KMAX; ++u) {
+                if (k0 + u < K8) {
+                    float4 v = av[u];
+                    if (has_pre) {
+                        const float4 sc = *reinterpret_cast<const float4*>(psc + (k0 + u) * 8 + 4 * h);
+                        const float4 sh = *reinterpret_cast<const float4*>(psh + (k0 + u) * 8 + 4 * h);
+                        v.x = th_act(fmaf(v.x, sc.x, sh.x), a.pre.act, a.pre.alpha);
+                        v.y = th_act(fmaf(v.y, sc.y, sh.y), a.pre.act, a.pre.alpha);
+                        v.z = th_act(fmaf(v.z, sc.z, sh.z), a.pre.act, a.pre.alpha);
+                        v.w = th_act(fmaf(v.w, sc.w, sh.w), a.pre.act, a.pre.alpha);
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const float4 b = Bs[((k0 + u) * NT + nt) * 64 + lane];
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, b.x, acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, b.y, acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.z, b.z, acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.w, b.w, acc[nt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+
+        // ---- epilogue: lane holds output channel (nt*32 + j) of rows (r&3) + 8*(r>>2) + 4h ------------
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int co = nt * 32 + j;
+            const bool cok = co < a.Cout;
+            const int cc = cok ? co : 0;
+            float x[16];
+            const float bv = a.bias ? a.bias[cc] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[r] = acc[nt][r] + bv;
+            th_post16(x, cc, a.post);
+            if (POOL == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned row = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (cok && row < a.nrows) {
+                        int64_t off;
+                        if (a.out_dense) off = (int64_t)row * a.out_cs;
+                        else { const unsigned f = row / (unsigned)a.V; off = (int64_t)f * a.out_fs + (int64_t)(row - f * a.V) * a.out_cs; }
+                        a.out[off + a.out_coff + co] = x[r];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    float s;
+                    if (POOL == 1) s = fmaxf(fmaxf(x[4 * o], x[4 * o + 1]), fmaxf(x[4 * o + 2], x[4 * o + 3]));
+                    else s = (x[4 * o] + x[4 * o + 1]) + (x[4 * o + 2] + x[4 * o + 3]);
+                    const float t = __shfl_xor(s, 32, 64);
+                    s = POOL == 1 ? fmaxf(s, t) : (s + t) * 0.125f;
+                    const unsigned p = tile * 4 + o;
+                    if (h == 0 && cok && p * 8 < a.nrows) {
+                        int64_t off;
+                        if (a.out_dense) off = (int64_t)p * a.out_cs;
+                        else { const unsigned f = p / (unsigned)a.Vo; off = (int64_t)f * a.out_fs + (int64_t)(p - f * a.Vo) * a.out_cs; }
+                        a.out[off + a.out_coff + co] = s;
+                    }
+                }
+            }
+        }
+    }
+}
+
+typedef void (*PwKernel)(const ConvPwArgs);
+// [kmax index: 4, 8, 16][nt index: 1, 2, 4][pool]
+const PwKernel kPw[3][3][3] = {
+    {{k_conv_pw<4, 1, 0>, k_conv_pw<4, 1, 1>, k_conv_pw<4, 1, 2>},
+     {k_conv_pw<4, 2, 0>, k_conv_pw<4, 2, 1>, k_conv_pw<4, 2, 2>},
+     {k_conv_pw<4, 4, 0>, k_conv_pw<4, 4, 1>, k_conv_pw<4, 4, 2>}},
+    {{k_conv_pw<8, 1, 0>, k_conv_pw<8, 1, 1>, k_conv_pw<8, 1, 2>},
+     {k_conv_pw<8, 2, 0>, k_conv_pw<8, 2, 1>, k_conv_pw<8, 2, 2>},
+     {k_conv_pw<8, 4, 0>, k_conv_pw<8, 4, 1>, k_conv_pw<8, 4, 2>}},
+    {{k_conv_pw<16, 1, 0>, k_conv_pw<16, 1, 1>, k_conv_pw<16, 1, 2>},
+     {k_conv_pw<16, 2, 0>, k_conv_pw<16, 2, 1>, k_conv_pw<16, 2, 2>},
+     {k_conv_pw<16, 4, 0>, k_conv_pw<16, 4, 1>, k_conv_pw<16, 4, 2>}},
+};
+const int kPwKmax[3] = {4, 8, 16};
+const int kPwNt[3] = {1, 2, 4};
+constexpr size_t kPwLdsLimit = 64 * 1024;
+
+}  // namespace
+
+// plan encoding (ConvMfmaPlan): cfg = 300 + 3*kmax_index + nt_index, CI = 8*K8 (padded Cin), BN = 32*NT, bres = 4
+bool conv_pw_plan(const TView& in, const TView& oc, const ConvGeom& g, int Cin, int Cout, int pool, ConvMfmaPlan* p) {
+    static const bool off = getenv("TH_CONV_NOPW") != nullptr;   // A/B comparisons against conv_mfma
+    if (off) return false;
+    if (g.kd != 1 || g.kh != 1 || g.kw != 1) return false;
+    if (g.sd != 1 || g.sh != 1 || g.sw != 1 || g.dd != 1 || g.dh != 1 || g.dw != 1) return false;
+    if (pool && (oc.D < 2 || oc.H < 2 || oc.W < 2)) return false;
+    if (Cout > 128 || Cin < 1) return false;
+    const int nti = Cout <= 32 ? 0 : (Cout <= 64 ? 1 : 2);
+    const int NT = kPwNt[nti];
+    const int K8 = (Cin + 7) / 8;
+    const int kmi = K8 <= 4 ? 0 : (K8 <= 8 ? 1 : 2);
+    const size_t lds = (size_t)K8 * NT * 64 * 16 + (size_t)K8 * 8 * 2 * 4;
+    if (lds > kPwLdsLimit) return false;
+    p->cfg = 300 + 3 * kmi + nti;
+    p->CI = K8 * 8; p->CS = 0; p->BN = 32 * NT; p->nnb = 1; p->nchunks = 1; p->pool = pool; p->bres = 4;
+    p->Dc = pool ? (oc.D / 2) * 2 : oc.D;
+    p->Hc = pool ? (oc.H / 2) * 2 : oc.H;
+    p->Wc = pool ? (oc.W / 2) * 2 : oc.W;
+    p->FB = 1; p->ZB = p->Dc; p->nzb = 1; p->Zp = p->Dc; p->Hp = p->Hc; p->Wp = p->Wc;
+    p->rows_pf = p->Dc * p->Hc * p->Wc;
+    p->lds_bytes = lds;
+    p->tab_off = 0;
+    p->wpk_floats = (size_t)K8 * NT * 256;
+    p->exec_flops = 2.0 * (double)p->rows_pf * (double)(32 * NT) * (double)(K8 * 8);
+    char buf[224];
+    snprintf(buf, sizeof buf, "conv_pw<k%d,nt%d,pool%d> K8=%d lds%zuK (streaming 1x1x1, weights in LDS) [k_conv_pw<%d,%d,%d>]",
+             kPwKmax[kmi], NT, pool, K8, lds / 1024, kPwKmax[kmi], NT, pool);
+    p->label = buf;
+    (void)in;
+    return true;
+}
+
+// Keras [1,1,1,Cin,Cout] -> fragment order [kk][ntile][h][j][q] with ci = kk*8 + 4h + q, co = ntile*32 + j
+void conv_pw_pack_weights(const ConvMfmaPlan& p, int Cin, int Cout, const float* w, float* dst) {
+    std::memset(dst, 0, p.wpk_floats * sizeof(float));
+    const int K8 = p.CI / 8, NT = p.BN / 32;
+    for (int kk = 0; kk < K8; ++kk)
+        for (int nt = 0; nt < NT; ++nt) {
+            float* frag = dst + ((size_t)kk * NT + nt) * 256;
+            for (int h = 0; h < 2; ++h)
+                for (int j = 0; j < 32; ++j) {
+                    const int co = nt * 32 + j;
+                    if (co >= Cout) continue;
+                    for (int q = 0; q < 4; ++q) {
+                        const int ci = kk * 8 + 4 * h + q;
+                        if (ci < Cin) frag[(h * 32 + j) * 4 + q] = w[(size_t)ci * Cout + co];
+                    }
+                }
+        }
+}
+
+int launch_conv_pw(hipStream_t s, int64_t n, const ConvMfmaPlan& p, TView in, TView out, int Cin, int Cout, const float* wpk,
+                   const float* bias, PreOp pre, PostOps post) {
+    const int idx = p.cfg - 300;
+    if (idx < 0 || idx >= 9 || p.bres != 4) TH_FAIL(TH_EINVAL, "conv_pw: bad plan");
+    const int kmi = idx / 3, nti = idx % 3;
+    if (n <= 0) return TH_OK;
+    ConvPwArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.in = in.p; a.in_fs = in.fs; a.in_cs = in.cs; a.in_coff = in.coff; a.Cin = Cin; a.K8 = p.CI / 8;
+    a.vec_ok = (in.cs % 4 == 0 && in.coff % 4 == 0 && in.fs % 4 == 0 && ((uintptr_t)in.p % 16) == 0) ? 1 : 0;
+    a.V = in.D * in.H * in.W; a.H = in.H; a.W = in.W;
+    a.in_dense = (in.fs == (int64_t)a.V * in.cs) ? 1 : 0;
+    a.Vo = out.D * out.H * out.W; a.Ho = out.H; a.Wo = out.W;
+    a.wpk = wpk; a.Cout = Cout; a.bias = bias; a.pre = pre; a.post = post;
+    a.out = out.p; a.out_fs = out.fs; a.out_cs = out.cs; a.out_coff = out.coff;
+    const int64_t out_v = p.pool ? a.Vo : a.V;
+    a.out_dense = (out.fs == out_v * out.cs) ? 1 : 0;
+    const int64_t nrows = p.pool ? n * a.Vo * 8 : n * a.V;
+    if (nrows >= 0x7fffffffLL) TH_FAIL(TH_EINVAL, "conv_pw: %lld rows per launch exceed the 32-bit row index; lower the chunk size", (long long)nrows);
+    a.nrows = (unsigned)nrows;
+    a.ntiles = (unsigned)((nrows + 31) / 32);
+    const unsigned want = (a.ntiles + 3) / 4;
+    const unsigned grid = std::min(want, 256u * 8u);   // persistent: up to 8 workgroups per CU queued, waves stride over tiles
+    PwKernel k = kPw[kmi][nti][p.pool];
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), p.lds_bytes, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) TH_FAIL(TH_EHIP, "conv_pw launch failed: %s (%s)", hipGetErrorString(e), p.label.c_str());
+    return TH_OK;
+}

@@ -334,6 +334,10 @@ int plan(th_model* m) {
                 if (f.pool >= 0) ok = conv_first_plan(src.D, src.H, src.W, src.C, ov, g, n.C, N[f.pool].op == OP_MAXPOOL ? 1 : 2, &mp);
                 if (!ok && f.pool < 0) ok = conv_first_plan(src.D, src.H, src.W, src.C, ov, g, n.C, 0, &mp);
             }
+            if (!ok && use_mfma && g.kd * g.kh * g.kw == 1) {
+                if (f.pool >= 0) ok = conv_pw_plan(iv, ov, g, src.C, n.C, N[f.pool].op == OP_MAXPOOL ? 1 : 2, &mp);
+                if (!ok && f.pool < 0) ok = conv_pw_plan(iv, ov, g, src.C, n.C, 0, &mp);
+            }
             if (!ok && use_mfma) {
                 if (f.pool >= 0) {
                     ok = conv_mfma_plan(iv, ov, g, src.C, n.C, N[f.pool].op == OP_MAXPOOL ? 1 : 2, &mp);
@@ -473,6 +477,17 @@ int plan(th_model* m) {
                         st.run = [=](hipStream_t s, int64_t cnt) {
                             return launch_conv_first(s, cnt, mp, M->cur_in, M->cur_dtype, iD, iH, iW, Cin, M->view(dst), g, Cout,
                                                      dw, dbias, po);
+                        };
+                    } else if (mplans.count(i) && mplans[i].cfg >= 300) {
+                        const ConvMfmaPlan mp = mplans[i];
+                        std::vector<float> packed(mp.wpk_floats);
+                        conv_pw_pack_weights(mp, Cin, Cout, hw, packed.data());
+                        float* dw;
+                        if ((rc = upload(M, packed.data(), packed.size(), &dw))) return rc;
+                        st.exec_flops = mp.exec_flops;
+                        st.label = n.name + ": " + mp.label;
+                        st.run = [=](hipStream_t s, int64_t cnt) {
+                            return launch_conv_pw(s, cnt, mp, M->view(src), M->view(dst), Cin, Cout, dw, dbias, pre, po);
                         };
                     } else if (mplans.count(i)) {
                         const ConvMfmaPlan mp = mplans[i];
