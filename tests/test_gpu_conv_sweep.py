@@ -131,6 +131,24 @@ def test_dense_block_transition_pointwise_kernel(gpu):
     _check(cfg, weights, _frames(3, (7, 6, 6), 5, 7), flags=_lib.TH_LOAD_NO_MFMA)
 
 
+@pytest.mark.parametrize("shape,cin,cout,pool,n", [((6, 6, 6), 48, 16, None, 11), ((4, 4, 4), 40, 12, "max", 23),
+                                                    ((5, 5, 5), 16, 16, None, 9)])
+def test_narrow_conv_persistent_workgroups_walk_several_groups(gpu, monkeypatch, shape, cin, cout, pool, n):
+    """k_conv_n16 workgroups are persistent and prefetch the next frame group's first chunk: force 3
+    resident workgroups so each walks several (incl. a ragged last) groups."""
+    monkeypatch.setenv("TH_N16_RESIDENT", "3")
+
+    def build(b, x):
+        x = b.relu(b.batchnorm(x))
+        x = b.conv3d(x, cout, 3, padding="same", use_bias=False)
+        x = b.elu(x)
+        return b.maxpool(x, 2) if pool else x
+
+    cfg, weights = _net(shape, cin, build, seed=21)
+    labels = _check(cfg, weights, _frames(n, shape, cin, 13))
+    assert any("conv_n16" in l for l in labels), labels
+
+
 def test_branches_add_and_strided_fallback(gpu):
     def build(b, x):
         a = b.conv3d(x, 16, 3, padding="same", activation="relu")

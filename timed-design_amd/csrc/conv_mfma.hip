@@ -561,15 +561,21 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
 // v_mfma_f32_16x16x4_f32 (same 64 FLOP/clk/SIMD rate): lane (i = l&15, q = l>>4) supplies
 // A[i][k=q] / B[k=q][i]; with one ds_read_b128 it holds channels 4q..4q+3 of its voxel, i.e. the
 // operands of 4 consecutive MFMAs (K order permuted identically in the packed weights).
-// All 27 taps' weight fragments of the current 16-channel chunk live in registers (108 VGPRs) and
-// each is re-loaded for the NEXT chunk right after its last use, so weight latency is a whole chunk
-// away.  The tap loop is fully unrolled with ping-pong A registers pinned by sched_barrier.
+// Weight fragments stream L2 -> registers through a 9-tap ring (slot refilled right after its last
+// use, 9 taps = several microseconds ahead).  Workgroups are PERSISTENT: the row/voxel tables are
+// built once, then the workgroup walks its frame groups; while the MFMAs of one 16-channel chunk run,
+// the global loads of the next chunk (or of chunk 0 of the next frame group) are already in flight
+// into registers and are written to LDS between two barriers, so staging latency never sits on the
+// MFMA pipe even with a single workgroup per CU.  The tap loop is fully unrolled with A registers
+// pinned by sched_barrier.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int WAVES, int TM, int POOL>
 __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(const ConvMfmaArgs a) {
     constexpr int NTHREADS = WAVES * 64;
     constexpr int CI = 16, CI4 = 4, NTAPS = 27;
+    constexpr int BR = 9;                       // weight-ring depth (taps in flight)
+    constexpr int PF = (TM <= 4) ? 11 : 14;     // float4 per thread of next-chunk prefetch
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -577,210 +583,263 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
     const int i16 = lane & 15, q = lane >> 4;
     const int CS4 = a.CS >> 2;
 
-    int bid = blockIdx.x;
-    const int zb = bid % a.nzb; bid /= a.nzb;
-    const int64_t f0 = (int64_t)bid * a.FB;
-    const int z0 = zb * a.ZB;
-    const int nvox = a.FB * a.Zp * a.Hp * a.Wp;
+    const int vox_pf = a.Zp * a.Hp * a.Wp;   // staged (haloed) voxels per frame; whole frames only (nzb == 1)
+    const int nvox = a.FB * vox_pf;
     float4* A4 = smem;
     int* rowvox = (int*)(reinterpret_cast<char*>(smem) + a.tab_off);
     int* rowout = rowvox + a.nrows;
     int* voxsrc = rowout + (POOL ? a.nrows / 8 : a.nrows);
+
+    // ---- tables, relative to the first frame of a group: built ONCE per (persistent) workgroup -------
     for (int v = tid; v < nvox; v += NTHREADS) {
         const int xl = v % a.Wp; int t = v / a.Wp;
         const int yl = t % a.Hp; t /= a.Hp;
         const int zl = t % a.Zp; const int f = t / a.Zp;
-        const int zi = z0 + zl - a.pz, yi = yl - a.py, xi = xl - a.px;
-        const bool ok = (f0 + f) < a.nframes && zi >= 0 && zi < a.Din && yi >= 0 && yi < a.Hin && xi >= 0 && xi < a.Win;
+        const int zi = zl - a.pz, yi = yl - a.py, xi = xl - a.px;
+        const bool ok = zi >= 0 && zi < a.Din && yi >= 0 && yi < a.Hin && xi >= 0 && xi < a.Win;
         voxsrc[v] = ok ? f * (int)a.in_fs + ((zi * a.Hin + yi) * a.Win + xi) * a.in_cs : -1;
     }
-    {
-        const int ZBv = min(a.ZB, a.Dc - z0);
-        for (int r = tid; r < a.nrows; r += NTHREADS) {
-            const int f = r / a.rows_pf, qq = r - f * a.rows_pf;
-            const bool fok = (f0 + f) < a.nframes;
-            int vox = 0, oo = -1;
-            if (POOL == 0) {
-                const int hw = a.Hc * a.Wc;
-                if (fok && qq < ZBv * hw) {
-                    const int zl = qq / hw, rem = qq - zl * hw, y = rem / a.Wc, x = rem - y * a.Wc;
-                    vox = ((f * a.Zp + zl) * a.Hp + y) * a.Wp + x;
-                    oo = f * (int)a.out_fs + (((z0 + zl) * a.Ho + y) * a.Wo + x) * a.out_cs;
-                }
-                rowout[r] = oo;
-            } else {
-                const int pq = qq >> 3, mate = qq & 7;
-                const int PH = a.Hc >> 1, PW = a.Wc >> 1;
-                if (fok && pq < (ZBv >> 1) * PH * PW) {
-                    const int pzz = pq / (PH * PW), rem = pq - pzz * (PH * PW), pyy = rem / PW, pxx = rem - pyy * PW;
-                    const int zl = 2 * pzz + (mate >> 2), y = 2 * pyy + ((mate >> 1) & 1), x = 2 * pxx + (mate & 1);
-                    vox = ((f * a.Zp + zl) * a.Hp + y) * a.Wp + x;
-                    oo = f * (int)a.out_fs + ((((z0 >> 1) + pzz) * a.Ho + pyy) * a.Wo + pxx) * a.out_cs;
-                }
-                if (mate == 0) rowout[r >> 3] = oo;
+    for (int r = tid; r < a.nrows; r += NTHREADS) {
+        const int f = r / a.rows_pf, qq = r - f * a.rows_pf;
+        int vox = 0, oo = -1;
+        if (POOL == 0) {
+            const int hw = a.Hc * a.Wc;
+            if (qq < a.Dc * hw) {
+                const int zl = qq / hw, rem = qq - zl * hw, y = rem / a.Wc, x = rem - y * a.Wc;
+                vox = ((f * a.Zp + zl) * a.Hp + y) * a.Wp + x;
+                oo = f * (int)a.out_fs + ((zl * a.Ho + y) * a.Wo + x) * a.out_cs;
             }
-            rowvox[r] = vox;
+            rowout[r] = oo;
+        } else {
+            const int pq = qq >> 3, mate = qq & 7;
+            const int PH = a.Hc >> 1, PW = a.Wc >> 1;
+            if (pq < (a.Dc >> 1) * PH * PW) {
+                const int pzz = pq / (PH * PW), rem = pq - pzz * (PH * PW), pyy = rem / PW, pxx = rem - pyy * PW;
+                const int zl = 2 * pzz + (mate >> 2), y = 2 * pyy + ((mate >> 1) & 1), x = 2 * pxx + (mate & 1);
+                vox = ((f * a.Zp + zl) * a.Hp + y) * a.Wp + x;
+                oo = f * (int)a.out_fs + ((pzz * a.Ho + pyy) * a.Wo + pxx) * a.out_cs;
+            }
+            if (mate == 0) rowout[r >> 3] = oo;
         }
+        rowvox[r] = vox;
     }
+    __syncthreads();
 
     const int n_mt = a.nrows / 16;
     const int total_blocks = (n_mt + TM - 1) / TM;
     const int rounds = (total_blocks + WAVES - 1) / WAVES;
     const float4* wpk4 = reinterpret_cast<const float4*>(a.wpk) + lane;  // [chunk][tap][lane]
+    const int wcount = a.nchunks * NTAPS;
     const int co = i16;
     const bool cvalid = co < a.Cout;
     const int cc = cvalid ? co : 0;
     const float bv = a.bias ? a.bias[cc] : 0.f;
-    float* outb = a.out + f0 * a.out_fs + a.out_coff;
+    const int nvec = nvox * CI4;
+    const bool has_pre = a.pre.scale || a.pre.act != ACT_LINEAR;
+    const int64_t ngroups = (a.nframes + a.FB - 1) / a.FB;
+    // next-chunk prefetch: when the whole staged image is <= PF float4 per thread, the global loads of the
+    // NEXT chunk (or of chunk 0 of this workgroup's next frame group) are issued before the MFMA phase of the
+    // current chunk and land in registers underneath it
+    const bool can_pf = rounds == 1 && nvec <= PF * NTHREADS && a.vec_ok && (a.Cin & 3) == 0 && !(a.dbg & 64);
 
-    for (int rd = 0; rd < rounds; ++rd) {
-        const int blk = rd * WAVES + wave;
-        const bool active = blk < total_blocks;
-        f32x4 acc[TM];
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) acc[tm] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (rd == 0) __syncthreads();
-        int aidx[TM];
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            const int mt = blk * TM + tm;
-            aidx[tm] = ((active && mt < n_mt) ? rowvox[mt * 16 + i16] : 0) * CS4 + q;
+    // nvalid: frames of the group that exist (the last group of a batch may be ragged)
+    auto load_vec = [&](const float* inb, int nvalid, int ch, int i, bool* okp) -> float4 {
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        int off = (i < nvec) ? voxsrc[i / CI4] : -1;
+        if (nvalid < a.FB && off >= 0 && (i / CI4) / vox_pf >= nvalid) off = -1;
+        const int g = i % CI4;
+        const int c0 = ch * CI + g * 4;
+        *okp = off >= 0;
+        if (off >= 0 && c0 < a.Cin) {
+            const float* src = inb + ch * CI + off + g * 4;
+            if (a.vec_ok && c0 + 4 <= a.Cin) {
+                val = *reinterpret_cast<const float4*>(src);
+            } else {
+                val.x = src[0];
+                if (c0 + 1 < a.Cin) val.y = src[1];
+                if (c0 + 2 < a.Cin) val.z = src[2];
+                if (c0 + 3 < a.Cin) val.w = src[3];
+            }
         }
-        float4 breg[NTAPS];
-        if (active) {
+        return val;
+    };
+    auto store_vec = [&](int ch, int i, float4 val, bool ok) {
+        if (i >= nvec) return;
+        const int v = i / CI4, g = i % CI4;
+        if (has_pre && ok) {
+            const int c0 = ch * CI + g * 4;
+            float e[4] = {val.x, val.y, val.z, val.w};
 #pragma unroll
-            for (int t = 0; t < NTAPS; ++t) breg[t] = wpk4[(size_t)t * 64];
+            for (int k = 0; k < 4; ++k) {
+                if (c0 + k < a.Cin) {
+                    float x = e[k];
+                    if (a.pre.scale) x = fmaf(x, a.pre.scale[c0 + k], a.pre.shift[c0 + k]);
+                    e[k] = th_act(x, a.pre.act, a.pre.alpha);
+                }
+            }
+            val = make_float4(e[0], e[1], e[2], e[3]);
         }
-        for (int ch = 0; ch < a.nchunks; ++ch) {
-            const bool need_a = !(a.nchunks == 1 && rd > 0);
-            __syncthreads();
-            if (need_a) {
-                constexpr int U = 4;  // breg[27] is live here: keep the staging footprint small
-                const int nvec = nvox * CI4;
-                const float* inb = a.in + f0 * a.in_fs + a.in_coff + ch * CI;
-                const bool has_pre = a.pre.scale || a.pre.act != ACT_LINEAR;
-                for (int base = tid; base < nvec; base += NTHREADS * U) {
-                    int off[U];
-                    float4 val[U];
+        A4[(size_t)v * CS4 + g] = val;
+    };
+
+    // weight ring: slot t % BR holds tap t's fragment and is refilled with tap t + BR right after its last
+    // use; the packed image is [chunk][tap][lane], the index runs on into the next chunk and wraps to chunk 0
+    // for the next frame group
+    float4 breg[BR];
+    if (wave < total_blocks) {
 #pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const int i = base + u * NTHREADS;
-                        off[u] = (i < nvec) ? voxsrc[i / CI4] : -1;
+        for (int t = 0; t < BR; ++t) breg[t] = wpk4[(size_t)(t % wcount) * 64];
+    }
+
+    bool staged = false;   // chunk 0 of the current group was already written to LDS from the prefetch registers
+    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int64_t f0 = grp * a.FB;
+        const int nvalid = (int)min((int64_t)a.FB, a.nframes - f0);
+        const float* inb0 = a.in + f0 * a.in_fs + a.in_coff;
+        float* outb = a.out + f0 * a.out_fs + a.out_coff;
+        const int64_t gnext = grp + gridDim.x;
+        const bool has_next = gnext < ngroups;
+        const float* inb_next = a.in + (has_next ? gnext : grp) * a.FB * a.in_fs + a.in_coff;
+        const int nvalid_next = has_next ? (int)min((int64_t)a.FB, a.nframes - gnext * a.FB) : nvalid;
+
+        for (int rd = 0; rd < rounds; ++rd) {
+            const int blk = rd * WAVES + wave;
+            const bool active = blk < total_blocks;
+            f32x4 acc[TM];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) acc[tm] = f32x4{0.f, 0.f, 0.f, 0.f};
+            int aidx[TM];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const int mt = blk * TM + tm;
+                aidx[tm] = ((active && mt < n_mt) ? rowvox[mt * 16 + i16] : 0) * CS4 + q;
+            }
+            for (int ch = 0; ch < a.nchunks; ++ch) {
+                const bool need_a = !(a.nchunks == 1 && rd > 0) && !((a.dbg & 1) && (ch > 0 || grp != blockIdx.x));
+                if (!(can_pf && (ch > 0 || staged))) {   // otherwise this chunk was written from registers already
+                    __syncthreads();
+                    if (need_a) {
+                        constexpr int U = 4;
+                        for (int base = tid; base < nvec; base += NTHREADS * U) {
+                            float4 val[U];
+                            bool ok[U];
+#pragma unroll
+                            for (int u = 0; u < U; ++u) val[u] = load_vec(inb0, nvalid, ch, base + u * NTHREADS, &ok[u]);
+#pragma unroll
+                            for (int u = 0; u < U; ++u) store_vec(ch, base + u * NTHREADS, val[u], ok[u]);
+                        }
                     }
+                }
+                __syncthreads();
+                const bool last_ch = ch + 1 == a.nchunks;
+                const bool do_pf = can_pf && (!last_ch || has_next) && !(a.dbg & 1);
+                const int pch = last_ch ? 0 : ch + 1;
+                // The PF loads are issued UNCONDITIONALLY (a dummy aligned address when there is nothing to fetch):
+                // hipcc can then count them and waits for the weight ring with vmcnt(N) instead of vmcnt(0),
+                // which would drain the prefetch in front of the first MFMA.
+                float4 pfv[PF];
+                unsigned pfok = 0, pfld = 0;
+                {
+                    const float* pin = (last_ch ? inb_next : inb0) + pch * CI;
+                    const int pnv = last_ch ? nvalid_next : nvalid;
 #pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const int i = base + u * NTHREADS;
+                    for (int u = 0; u < PF; ++u) {
+                        const int i = tid + u * NTHREADS;
+                        int off = (do_pf && i < nvec) ? voxsrc[i / CI4] : -1;
+                        if (pnv < a.FB && off >= 0 && (i / CI4) / vox_pf >= pnv) off = -1;
                         const int g = i % CI4;
-                        const int c0 = ch * CI + g * 4;
-                        val[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (off[u] >= 0 && c0 < a.Cin) {
-                            const float* src = inb + off[u] + g * 4;
-                            if (a.vec_ok && c0 + 4 <= a.Cin) {
-                                val[u] = *reinterpret_cast<const float4*>(src);
-                            } else {
-                                val[u].x = src[0];
-                                if (c0 + 1 < a.Cin) val[u].y = src[1];
-                                if (c0 + 2 < a.Cin) val[u].z = src[2];
-                                if (c0 + 3 < a.Cin) val[u].w = src[3];
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const int i = base + u * NTHREADS;
-                        if (i >= nvec) continue;
-                        const int v = i / CI4, g = i % CI4;
-                        if (has_pre && off[u] >= 0) {
-                            const int c0 = ch * CI + g * 4;
-                            float e[4] = {val[u].x, val[u].y, val[u].z, val[u].w};
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                if (c0 + k < a.Cin) {
-                                    float x = e[k];
-                                    if (a.pre.scale) x = fmaf(x, a.pre.scale[c0 + k], a.pre.shift[c0 + k]);
-                                    e[k] = th_act(x, a.pre.act, a.pre.alpha);
-                                }
-                            }
-                            val[u] = make_float4(e[0], e[1], e[2], e[3]);
-                        }
-                        A4[(size_t)v * CS4 + g] = val[u];
+                        const bool ld = off >= 0 && pch * CI + g * 4 + 4 <= a.Cin;
+                        const float4* src = ld ? reinterpret_cast<const float4*>(pin + off + g * 4)
+                                               : reinterpret_cast<const float4*>(a.wpk);
+                        pfv[u] = *src;
+                        pfok |= off >= 0 ? (1u << u) : 0u;
+                        pfld |= ld ? (1u << u) : 0u;
                     }
                 }
+                if (active) {
+                    constexpr bool PING = (TM <= 4);  // TM = 8: a single A set, the second wave on the SIMD covers the LDS latency
+                    float4 av[PING ? 2 : 1][TM];
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) av[0][tm] = A4[aidx[tm]];
+#pragma unroll
+                    for (int t = 0; t < NTAPS; ++t) {
+                        if (PING && t + 1 < NTAPS) {
+                            const int nt = t + 1;
+                            int noff = (((nt / 9) * a.Hp + (nt / 3) % 3) * a.Wp + nt % 3) * CS4;
+                            // opaque to LICM: otherwise hipcc hoists all 27*TM read addresses out of the chunk loop
+                            // and spills them to scratch
+                            asm volatile("" : "+s"(noff));
+#pragma unroll
+                            for (int tm = 0; tm < TM; ++tm) av[nt & 1][tm] = A4[aidx[tm] + noff];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int tm = 0; tm < TM; ++tm) {
+                            const float4 aq = av[PING ? (t & 1) : 0][tm];
+                            acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.x, breg[t % BR].x, acc[tm], 0, 0, 0);
+                            acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.y, breg[t % BR].y, acc[tm], 0, 0, 0);
+                            acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.z, breg[t % BR].z, acc[tm], 0, 0, 0);
+                            acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.w, breg[t % BR].w, acc[tm], 0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        {
+                            int widx = ch * NTAPS + t + BR;
+                            widx = widx >= wcount ? widx - wcount : widx;
+                            breg[t % BR] = wpk4[(size_t)min(widx, wcount - 1) * 64];
+                        }
+                        if (!PING && t + 1 < NTAPS) {
+                            const int nt = t + 1;
+                            int noff = (((nt / 9) * a.Hp + (nt / 3) % 3) * a.Wp + nt % 3) * CS4;
+                            asm volatile("" : "+s"(noff));
+#pragma unroll
+                            for (int tm = 0; tm < TM; ++tm) av[0][tm] = A4[aidx[tm] + noff];
+                        }
+                    }
+                }
+                if (do_pf) {
+                    __syncthreads();   // every wave is done reading chunk ch
+#pragma unroll
+                    for (int u = 0; u < PF; ++u)
+                        store_vec(pch, tid + u * NTHREADS, ((pfld >> u) & 1u) ? pfv[u] : make_float4(0.f, 0.f, 0.f, 0.f), (pfok >> u) & 1u);
+                }
             }
-            __syncthreads();
+            // ---- epilogue in registers: C layout col = lane&15, row = 4*(lane>>4) + reg --------------------
             if (active) {
-                const float4* wnext = wpk4 + (size_t)min(ch + 1, a.nchunks - 1) * NTAPS * 64;
-                constexpr bool PING = (TM <= 4);  // TM = 8 has no registers left for a second A set: rely on 2 waves/SIMD
-                float4 av[PING ? 2 : 1][TM];
 #pragma unroll
-                for (int tm = 0; tm < TM; ++tm) av[0][tm] = A4[aidx[tm]];
+                for (int g0 = 0; g0 < TM; g0 += 4) {
+                    float x[16];
 #pragma unroll
-                for (int t = 0; t < NTAPS; ++t) {
-                    if (PING && t + 1 < NTAPS) {
-                        const int nt = t + 1;
-                        int noff = (((nt / 9) * a.Hp + (nt / 3) % 3) * a.Wp + nt % 3) * CS4;
-                        // opaque to LICM: otherwise hipcc hoists all 27*TM read addresses out of the chunk loop
-                        // and spills them to scratch
-                        asm volatile("" : "+s"(noff));
+                    for (int g = 0; g < 4; ++g)
 #pragma unroll
-                        for (int tm = 0; tm < TM; ++tm) av[nt & 1][tm] = A4[aidx[tm] + noff];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    constexpr int dummy = 0; (void)dummy;
+                        for (int r = 0; r < 4; ++r) x[4 * g + r] = (g0 + g < TM) ? acc[(g0 + g < TM) ? g0 + g : 0][r] + bv : 0.f;
+                    th_post16(x, cc, a.post);
 #pragma unroll
-                    for (int tm = 0; tm < TM; ++tm) {
-                        const float4 aq = av[PING ? (t & 1) : 0][tm];
-                        acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.x, breg[t].x, acc[tm], 0, 0, 0);
-                        acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.y, breg[t].y, acc[tm], 0, 0, 0);
-                        acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.z, breg[t].z, acc[tm], 0, 0, 0);
-                        acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.w, breg[t].w, acc[tm], 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    breg[t] = wnext[(size_t)t * 64];  // this tap's weights for the next chunk: a whole chunk to arrive
-                    if (!PING && t + 1 < NTAPS) {
-                        const int nt = t + 1;
-                        int noff = (((nt / 9) * a.Hp + (nt / 3) % 3) * a.Wp + nt % 3) * CS4;
-                        asm volatile("" : "+s"(noff));
+                    for (int g = 0; g < 4; ++g) {
+                        if (g0 + g >= TM) continue;
+                        const int mt = blk * TM + g0 + g;
+                        // rows of frames past the end of a ragged last group are dropped
+                        const bool ok = cvalid && mt < n_mt && (nvalid == a.FB || (mt * 16 + 4 * q) / a.rows_pf < nvalid);
+                        if (POOL == 0) {
 #pragma unroll
-                        for (int tm = 0; tm < TM; ++tm) av[0][tm] = A4[aidx[tm] + noff];
-                    }
-                }
-            }
-        }
-        // ---- epilogue in registers: C layout col = lane&15, row = 4*(lane>>4) + reg --------------------
-        if (active) {
-#pragma unroll
-            for (int g0 = 0; g0 < TM; g0 += 4) {
-                float x[16];
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) x[4 * g + r] = (g0 + g < TM) ? acc[(g0 + g < TM) ? g0 + g : 0][r] + bv : 0.f;
-                th_post16(x, cc, a.post);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    if (g0 + g >= TM) continue;
-                    const int mt = blk * TM + g0 + g;
-                    const bool ok = cvalid && mt < n_mt;
-                    if (POOL == 0) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int oo = ok ? rowout[mt * 16 + 4 * q + r] : -1;
-                            if (oo >= 0) outb[oo + co] = x[4 * g + r];
+                            for (int r = 0; r < 4; ++r) {
+                                const int oo = ok ? rowout[mt * 16 + 4 * q + r] : -1;
+                                if (oo >= 0) outb[oo + co] = x[4 * g + r];
+                            }
+                        } else {
+                            // rows 4q..4q+3 of the tile = mates (4q)&7.. of pooled voxel q>>1: combine with lane q^1
+                            float m;
+                            if (POOL == 1) m = fmaxf(fmaxf(x[4 * g], x[4 * g + 1]), fmaxf(x[4 * g + 2], x[4 * g + 3]));
+                            else m = (x[4 * g] + x[4 * g + 1]) + (x[4 * g + 2] + x[4 * g + 3]);
+                            const float o2 = __shfl_xor(m, 16);
+                            m = (POOL == 1) ? fmaxf(m, o2) : (m + o2) * 0.125f;
+                            const int oo = ok ? rowout[mt * 2 + (q >> 1)] : -1;
+                            if (oo >= 0 && (q & 1) == 0) outb[oo + co] = m;
                         }
-                    } else {
-                        // rows 4q..4q+3 of the tile = mates (4q)&7.. of pooled voxel q>>1: combine with lane q^1
-                        float m;
-                        if (POOL == 1) m = fmaxf(fmaxf(x[4 * g], x[4 * g + 1]), fmaxf(x[4 * g + 2], x[4 * g + 3]));
-                        else m = (x[4 * g] + x[4 * g + 1]) + (x[4 * g + 2] + x[4 * g + 3]);
-                        const float o2 = __shfl_xor(m, 16);
-                        m = (POOL == 1) ? fmaxf(m, o2) : (m + o2) * 0.125f;
-                        const int oo = ok ? rowout[mt * 2 + (q >> 1)] : -1;
-                        if (oo >= 0 && (q & 1) == 0) outb[oo + co] = m;
                     }
                 }
             }
         }
+        staged = can_pf && has_next && !(a.dbg & 1);
     }
 }
 
@@ -1044,7 +1103,20 @@ int launch_conv_mfma(hipStream_t s, int64_t n, const ConvMfmaPlan& p, TView in, 
     a.out = out.p; a.out_fs = out.fs; a.out_cs = out.cs; a.out_coff = out.coff; a.Ho = out.H; a.Wo = out.W;
     a.nframes = n;
     const int64_t groups = (n + p.FB - 1) / p.FB;
-    const int64_t grid = groups * p.nzb * p.nnb;
+    int64_t grid = groups * p.nzb * p.nnb;
+    if (n16) {  // persistent workgroups: one resident set, each walks groups blockIdx.x, +gridDim.x, ...
+        static int ncu = 0;
+        if (!ncu) {
+            int dev = 0;
+            HIP_TRY(hipGetDevice(&dev));
+            HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+        }
+        int64_t resident = (int64_t)ncu * (c.WAVES == 4 ? 2 : 1);
+        if (const char* e = getenv("TH_N16_RESIDENT")) resident = std::max(1, atoi(e));   // tests: force multi-trip workgroups
+        // equal trip counts: ceil(groups / ceil(groups / resident)) workgroups
+        const int64_t trips = (groups + resident - 1) / resident;
+        grid = std::max<int64_t>(1, (groups + trips - 1) / std::max<int64_t>(trips, 1));
+    }
     if (grid > 0x7fffffffLL) TH_FAIL(TH_EINVAL, "conv_mfma: grid too large");
     ConvKernel k = n16 ? kN16Kernels[p.cfg - 200][p.pool] : kKernels[p.cfg][p.pool];
     HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
