@@ -757,24 +757,29 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
                     }
                 }
                 if (active) {
-                    constexpr bool PING = (TM <= 4);  // TM = 8: a single A set, the second wave on the SIMD covers the LDS latency
+                    // A fragments: TM <= 4 keeps two register sets (ping-pong by tap).  TM = 8 has ONE set and pipelines at
+                    // half-tap granularity instead: as soon as the MFMAs of tiles 0..3 of tap t have issued, their
+                    // registers are re-loaded with tap t+1 while the MFMAs of tiles 4..7 run (and vice versa), so every
+                    // ds_read has 16 MFMAs (512 cycles) of cover without a second register set.
+                    constexpr bool PING = (TM <= 4);
+                    constexpr int HT = PING ? TM : TM / 2;
                     float4 av[PING ? 2 : 1][TM];
 #pragma unroll
                     for (int tm = 0; tm < TM; ++tm) av[0][tm] = A4[aidx[tm]];
 #pragma unroll
                     for (int t = 0; t < NTAPS; ++t) {
-                        if (PING && t + 1 < NTAPS) {
-                            const int nt = t + 1;
-                            int noff = (((nt / 9) * a.Hp + (nt / 3) % 3) * a.Wp + nt % 3) * CS4;
-                            // opaque to LICM: otherwise hipcc hoists all 27*TM read addresses out of the chunk loop
-                            // and spills them to scratch
-                            asm volatile("" : "+s"(noff));
+                        const int nt = t + 1;
+                        int noff = (((nt / 9) * a.Hp + (nt / 3) % 3) * a.Wp + nt % 3) * CS4;
+                        // opaque to LICM: otherwise hipcc hoists all 27*TM read addresses out of the chunk loop
+                        // and spills them to scratch
+                        asm volatile("" : "+s"(noff));
+                        if (PING && nt < NTAPS) {
 #pragma unroll
                             for (int tm = 0; tm < TM; ++tm) av[nt & 1][tm] = A4[aidx[tm] + noff];
                         }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int tm = 0; tm < TM; ++tm) {
+                        for (int tm = 0; tm < HT; ++tm) {
                             const float4 aq = av[PING ? (t & 1) : 0][tm];
                             acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.x, breg[t % BR].x, acc[tm], 0, 0, 0);
                             acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.y, breg[t % BR].y, acc[tm], 0, 0, 0);
@@ -782,17 +787,30 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
                             acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.w, breg[t % BR].w, acc[tm], 0, 0, 0);
                         }
                         __builtin_amdgcn_sched_barrier(0);
+                        if (!PING) {
+                            if (nt < NTAPS) {
+#pragma unroll
+                                for (int tm = 0; tm < HT; ++tm) av[0][tm] = A4[aidx[tm] + noff];
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int tm = HT; tm < TM; ++tm) {
+                                const float4 aq = av[0][tm];
+                                acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.x, breg[t % BR].x, acc[tm], 0, 0, 0);
+                                acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.y, breg[t % BR].y, acc[tm], 0, 0, 0);
+                                acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.z, breg[t % BR].z, acc[tm], 0, 0, 0);
+                                acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.w, breg[t % BR].w, acc[tm], 0, 0, 0);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                         {
                             int widx = ch * NTAPS + t + BR;
                             widx = widx >= wcount ? widx - wcount : widx;
                             breg[t % BR] = wpk4[(size_t)min(widx, wcount - 1) * 64];
                         }
-                        if (!PING && t + 1 < NTAPS) {
-                            const int nt = t + 1;
-                            int noff = (((nt / 9) * a.Hp + (nt / 3) % 3) * a.Wp + nt % 3) * CS4;
-                            asm volatile("" : "+s"(noff));
+                        if (!PING && nt < NTAPS) {
 #pragma unroll
-                            for (int tm = 0; tm < TM; ++tm) av[0][tm] = A4[aidx[tm] + noff];
+                            for (int tm = HT; tm < TM; ++tm) av[0][tm] = A4[aidx[tm] + noff];
                         }
                     }
                 }
