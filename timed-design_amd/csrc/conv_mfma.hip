@@ -756,6 +756,12 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
                         pfld |= ld ? (1u << u) : 0u;
                     }
                 }
+                // a thread's prefetched vectors all cover the same 4 channels (NTHREADS % 4 == 0): their BN constants
+                // are fetched once, also unconditionally
+                const int pc0 = min(pch * CI + (tid % CI4) * 4, a.Cin - 4);
+                const bool pbn = a.pre.scale && can_pf;   // can_pf: Cin % 4 == 0, so pc0 is aligned and in bounds
+                const float4 psc = *reinterpret_cast<const float4*>(pbn ? a.pre.scale + pc0 : a.wpk);
+                const float4 psh = *reinterpret_cast<const float4*>(pbn ? a.pre.shift + pc0 : a.wpk);
                 if (active) {
                     // A fragments: TM <= 4 keeps two register sets (ping-pong by tap).  TM = 8 has ONE set and pipelines at
                     // half-tap granularity instead: as soon as the MFMAs of tiles 0..3 of tap t have issued, their
@@ -815,10 +821,26 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
                     }
                 }
                 if (do_pf) {
+                    // BN -> activation prologue in registers BEFORE the barrier (overlaps the other waves' last MFMAs)
+#pragma unroll
+                    for (int u = 0; u < PF; ++u) {
+                        float4 v = ((pfld >> u) & 1u) ? pfv[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (has_pre && ((pfok >> u) & 1u) && pch * CI + (tid % CI4) * 4 < a.Cin) {
+                            if (a.pre.scale) {
+                                v.x = fmaf(v.x, psc.x, psh.x); v.y = fmaf(v.y, psc.y, psh.y);
+                                v.z = fmaf(v.z, psc.z, psh.z); v.w = fmaf(v.w, psc.w, psh.w);
+                            }
+                            v.x = th_act(v.x, a.pre.act, a.pre.alpha); v.y = th_act(v.y, a.pre.act, a.pre.alpha);
+                            v.z = th_act(v.z, a.pre.act, a.pre.alpha); v.w = th_act(v.w, a.pre.act, a.pre.alpha);
+                        }
+                        pfv[u] = v;
+                    }
                     __syncthreads();   // every wave is done reading chunk ch
 #pragma unroll
-                    for (int u = 0; u < PF; ++u)
-                        store_vec(pch, tid + u * NTHREADS, ((pfld >> u) & 1u) ? pfv[u] : make_float4(0.f, 0.f, 0.f, 0.f), (pfok >> u) & 1u);
+                    for (int u = 0; u < PF; ++u) {
+                        const int i = tid + u * NTHREADS;
+                        if (i < nvec) A4[(size_t)(i / CI4) * CS4 + (i % CI4)] = pfv[u];
+                    }
                 }
             }
             // ---- epilogue in registers: C layout col = lane&15, row = 4*(lane>>4) + reg --------------------
