@@ -51,6 +51,7 @@ struct ConvMfmaArgs {
     PostOps post;
     float* out; int64_t out_fs; int out_cs, out_coff, Ho, Wo;
     int64_t nframes;
+    const float* wx;   // k_conv_n16 XC > 0: weights of output channels 16..16+XC-1, [chunk][tap][q][c][4]
 };
 
 template <int WAVES, int TM, int TN, int NT, int CI, int BRES, int POOL>
@@ -570,12 +571,18 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
 // pinned by sched_barrier.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int WAVES, int TM, int POOL>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// XC > 0: output channels 16..16+XC-1 (Cout = 17..20, e.g. the 20 amino-acid classes of a TIMED head) are
+// accumulated on the VALU pipe from the SAME A registers, interleaved under the MFMAs (two v_pk_fma_f32
+// per MFMA): the matrix pipe only runs the 16-wide tile instead of a 32-wide one padded with 12 zero columns.
+template <int WAVES, int TM, int POOL, int XC = 0>
 __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(const ConvMfmaArgs a) {
+    static_assert(XC == 0 || (XC == 4 && TM <= 4 && POOL == 0), "VALU side channels: 4 channels, ping-pong variant, no pooling");
     constexpr int NTHREADS = WAVES * 64;
     constexpr int CI = 16, CI4 = 4, NTAPS = 27;
     constexpr int BR = 9;                       // weight-ring depth (taps in flight)
-    constexpr int PF = (TM <= 4) ? 11 : 14;     // float4 per thread of next-chunk prefetch
+    constexpr int PF = XC ? 1 : ((TM <= 4) ? 11 : 14);   // float4 per thread of next-chunk prefetch (XC: registers go to the side channels)
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -640,7 +647,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
     // next-chunk prefetch: when the whole staged image is <= PF float4 per thread, the global loads of the
     // NEXT chunk (or of chunk 0 of this workgroup's next frame group) are issued before the MFMA phase of the
     // current chunk and land in registers underneath it
-    const bool can_pf = rounds == 1 && nvec <= PF * NTHREADS && a.vec_ok && (a.Cin & 3) == 0 && !(a.dbg & 64);
+    const bool can_pf = !XC && rounds == 1 && nvec <= PF * NTHREADS && a.vec_ok && (a.Cin & 3) == 0 && !(a.dbg & 64);
 
     // nvalid: frames of the group that exist (the last group of a batch may be ragged)
     auto load_vec = [&](const float* inb, int nvalid, int ch, int i, bool* okp) -> float4 {
@@ -686,9 +693,17 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
     // use; the packed image is [chunk][tap][lane], the index runs on into the next chunk and wraps to chunk 0
     // for the next frame group
     float4 breg[BR];
+    // XC: this lane's (k-slot q) weights of the extra channels for the CURRENT tap, refilled for the next tap
+    // right after use: xw[c] = W[4q..4q+3][16 + c]
+    const f32x4* wx4 = reinterpret_cast<const f32x4*>(a.wx) + q * (XC ? XC : 1);
+    f32x4 xw[XC ? XC : 1];
     if (wave < total_blocks) {
 #pragma unroll
         for (int t = 0; t < BR; ++t) breg[t] = wpk4[(size_t)(t % wcount) * 64];
+        if (XC) {
+#pragma unroll
+            for (int c = 0; c < XC; ++c) xw[c] = wx4[c];
+        }
     }
 
     bool staged = false;   // chunk 0 of the current group was already written to LDS from the prefetch registers
@@ -708,6 +723,13 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
             f32x4 acc[TM];
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) acc[tm] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // partial sums of row i16 over this lane's channels (4q, 4q+1) and (4q+2, 4q+3): two independent
+            // accumulator pairs so that no FMA depends on the one issued just before it
+            f32x2 xacc[XC ? TM : 1][XC ? XC : 1], xacb[XC ? TM : 1][XC ? XC : 1];
+#pragma unroll
+            for (int tm = 0; tm < (XC ? TM : 1); ++tm)
+#pragma unroll
+                for (int c = 0; c < (XC ? XC : 1); ++c) xacc[tm][c] = xacb[tm][c] = f32x2{0.f, 0.f};
             int aidx[TM];
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
@@ -769,9 +791,10 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
                     // ds_read has 16 MFMAs (512 cycles) of cover without a second register set.
                     constexpr bool PING = (TM <= 4);
                     constexpr int HT = PING ? TM : TM / 2;
-                    float4 av[PING ? 2 : 1][TM];
+                    f32x4 av[PING ? 2 : 1][TM];
+                    const f32x4* A4v = reinterpret_cast<const f32x4*>(A4);
 #pragma unroll
-                    for (int tm = 0; tm < TM; ++tm) av[0][tm] = A4[aidx[tm]];
+                    for (int tm = 0; tm < TM; ++tm) av[0][tm] = A4v[aidx[tm]];
 #pragma unroll
                     for (int t = 0; t < NTAPS; ++t) {
                         const int nt = t + 1;
@@ -781,27 +804,55 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
                         asm volatile("" : "+s"(noff));
                         if (PING && nt < NTAPS) {
 #pragma unroll
-                            for (int tm = 0; tm < TM; ++tm) av[nt & 1][tm] = A4[aidx[tm] + noff];
+                            for (int tm = 0; tm < TM; ++tm) av[nt & 1][tm] = A4v[aidx[tm] + noff];
                         }
                         __builtin_amdgcn_sched_barrier(0);
+                        if (!XC) {
 #pragma unroll
-                        for (int tm = 0; tm < HT; ++tm) {
-                            const float4 aq = av[PING ? (t & 1) : 0][tm];
-                            acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.x, breg[t % BR].x, acc[tm], 0, 0, 0);
-                            acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.y, breg[t % BR].y, acc[tm], 0, 0, 0);
-                            acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.z, breg[t % BR].z, acc[tm], 0, 0, 0);
-                            acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.w, breg[t % BR].w, acc[tm], 0, 0, 0);
+                            for (int tm = 0; tm < HT; ++tm) {
+                                const f32x4 aq = av[PING ? (t & 1) : 0][tm];
+                                acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.x, breg[t % BR].x, acc[tm], 0, 0, 0);
+                                acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.y, breg[t % BR].y, acc[tm], 0, 0, 0);
+                                acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.z, breg[t % BR].z, acc[tm], 0, 0, 0);
+                                acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.w, breg[t % BR].w, acc[tm], 0, 0, 0);
+                            }
+                        } else {
+                            // k-major MFMA order (4 independent tiles between dependent accumulations); MFMA (k, tm) is
+                            // followed by the two packed FMAs of (tile tm, side channel k), pinned by sched_group_barrier
+                            const float bk[4] = {breg[t % BR].x, breg[t % BR].y, breg[t % BR].z, breg[t % BR].w};
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                                for (int tm = 0; tm < TM; ++tm) {
+                                    const f32x4 aq = av[t & 1][tm];
+                                    acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[k], bk[k], acc[tm], 0, 0, 0);
+                                    const f32x4 wv = xw[k < XC ? k : 0];
+                                    xacc[tm][k < XC ? k : 0] = __builtin_elementwise_fma(aq.xy, wv.xy, xacc[tm][k < XC ? k : 0]);
+                                    xacb[tm][k < XC ? k : 0] = __builtin_elementwise_fma(aq.zw, wv.zw, xacb[tm][k < XC ? k : 0]);
+                                }
+                            }
+#pragma unroll
+                            for (int k = 0; k < 4 * TM; ++k) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                            }
                         }
                         __builtin_amdgcn_sched_barrier(0);
+                        if (XC) {
+                            int widx = ch * NTAPS + t + 1;
+                            widx = widx >= wcount ? widx - wcount : widx;
+#pragma unroll
+                            for (int c = 0; c < XC; ++c) xw[c] = wx4[(size_t)min(widx, wcount - 1) * 4 * XC + c];
+                        }
                         if (!PING) {
                             if (nt < NTAPS) {
 #pragma unroll
-                                for (int tm = 0; tm < HT; ++tm) av[0][tm] = A4[aidx[tm] + noff];
+                                for (int tm = 0; tm < HT; ++tm) av[0][tm] = A4v[aidx[tm] + noff];
                             }
                             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                             for (int tm = HT; tm < TM; ++tm) {
-                                const float4 aq = av[0][tm];
+                                const f32x4 aq = av[0][tm];
                                 acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.x, breg[t % BR].x, acc[tm], 0, 0, 0);
                                 acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.y, breg[t % BR].y, acc[tm], 0, 0, 0);
                                 acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.z, breg[t % BR].z, acc[tm], 0, 0, 0);
@@ -816,7 +867,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
                         }
                         if (!PING && nt < NTAPS) {
 #pragma unroll
-                            for (int tm = HT; tm < TM; ++tm) av[0][tm] = A4[aidx[tm] + noff];
+                            for (int tm = HT; tm < TM; ++tm) av[0][tm] = A4v[aidx[tm] + noff];
                         }
                     }
                 }
@@ -875,6 +926,29 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
                             const int oo = ok ? rowout[mt * 2 + (q >> 1)] : -1;
                             if (oo >= 0 && (q & 1) == 0) outb[oo + co] = m;
                         }
+                    }
+                }
+                if (XC) {
+                    // VALU side channels: lane (i16, q) holds row i16's partial sums over channels 4q..4q+3 of every
+                    // chunk; add the four k-slot lanes, then lane q finishes output channel 16 + q
+                    const int cx = 16 + q;
+                    const bool xvalid = cx < a.Cout;
+                    const float bx = (a.bias && xvalid) ? a.bias[cx] : 0.f;
+#pragma unroll
+                    for (int tm = 0; tm < (XC ? TM : 1); ++tm) {
+                        float mine = 0.f;
+#pragma unroll
+                        for (int c = 0; c < (XC ? XC : 1); ++c) {
+                            float v = (xacc[tm][c][0] + xacc[tm][c][1]) + (xacb[tm][c][0] + xacb[tm][c][1]);
+                            v += __shfl_xor(v, 16);
+                            v += __shfl_xor(v, 32);
+                            mine = (q == c) ? v : mine;
+                        }
+                        const int mt = blk * TM + tm;
+                        const int row = mt * 16 + i16;
+                        const bool ok = xvalid && mt < n_mt && (nvalid == a.FB || row / a.rows_pf < nvalid);
+                        const int oo = ok ? rowout[row] : -1;
+                        if (oo >= 0) outb[oo + cx] = th_post(mine + bx, cx, a.post);
                     }
                 }
             }
@@ -1004,11 +1078,12 @@ static bool plan_with_cfg(int cfg, size_t lds_limit, bool whole_frames_only, con
 // ---- narrow-output (Cout <= 16) kernel: planning, packing, launch ------------------------------------------
 namespace {
 struct N16Cfg { int WAVES, TM; };
-const N16Cfg kN16[] = {{8, 8}, {4, 4}};
+const N16Cfg kN16[] = {{8, 8}, {4, 4}, {4, 4}};   // [2] = {4,4} with 4 VALU side channels (Cout 17..20)
 typedef void (*ConvKernelN16)(const ConvMfmaArgs);
-const ConvKernelN16 kN16Kernels[2][3] = {
+const ConvKernelN16 kN16Kernels[3][3] = {
     {k_conv_n16<8, 8, 0>, k_conv_n16<8, 8, 1>, k_conv_n16<8, 8, 2>},
     {k_conv_n16<4, 4, 0>, k_conv_n16<4, 4, 1>, k_conv_n16<4, 4, 2>},
+    {k_conv_n16<4, 4, 0, 4>, nullptr, nullptr},
 };
 bool plan_n16(int variant, size_t lds_limit, const TView& in, const TView& oc, const ConvGeom& g, int Cin, int Cout, int pool,
               ConvMfmaPlan* p) {
@@ -1035,12 +1110,16 @@ bool plan_n16(int variant, size_t lds_limit, const TView& in, const TView& oc, c
     p->rows_pf = rows_for(p->Dc);
     p->lds_bytes = lds_for(FB, p->Dc);
     p->tab_off = p->lds_bytes - tab_bytes(FB, p->Dc);
-    p->wpk_floats = (size_t)p->nchunks * 27 * 64 * 4;
-    p->exec_flops = 2.0 * (double)p->rows_pf * 16.0 * (double)(p->nchunks * 16) * 27;
+    const int xc = variant == 2 ? 4 : 0;   // VALU side channels
+    if (xc && pool) return false;
+    p->BN = 16 + xc;
+    p->wpk_floats = (size_t)p->nchunks * 27 * 64 * 4 + (size_t)p->nchunks * 27 * 4 * xc * 4;
+    p->exec_flops = 2.0 * (double)p->rows_pf * 16.0 * (double)(p->nchunks * 16) * 27;   // MFMA only
     if ((int64_t)FB * oc.fs > 0x7fffffffLL || (int64_t)FB * in.D * in.H * in.W * std::max(in.cs, in.C) > 0x7fffffffLL) return false;
     char buf[224];
-    snprintf(buf, sizeof buf, "conv_n16<w%d,tm%d,pool%d> FB%d rows%d lds%zuK (16x16x4 MFMA, weights in VGPRs) [k_conv_n16<%d,%d,%d>]",
-             c.WAVES, c.TM, pool, FB, p->rows_pf, p->lds_bytes / 1024, c.WAVES, c.TM, pool);
+    snprintf(buf, sizeof buf, "conv_n16<w%d,tm%d,pool%d%s> FB%d rows%d lds%zuK (16x16x4 MFMA, weight ring%s) [k_conv_n16<%d,%d,%d%s>]",
+             c.WAVES, c.TM, pool, xc ? ",xc4" : "", FB, p->rows_pf, p->lds_bytes / 1024,
+             xc ? ", channels 16.. on the VALU pipe" : "", c.WAVES, c.TM, pool, xc ? ",4" : "");
     p->label = buf;
     return true;
 }
@@ -1058,9 +1137,16 @@ bool conv_mfma_plan(const TView& in, const TView& oc, const ConvGeom& g, int Cin
     const char* mode = getenv("TH_CONV_BMODE");
     const bool dbuf = mode && std::strcmp(mode, "dbuf") == 0;
     const bool stream8 = mode && std::strcmp(mode, "stream8") == 0;
-    if (!dbuf && !stream8 && Cout <= 16 && Cin > 8 && g.kd == 3 && g.kh == 3 && g.kw == 3 && !(mode && std::strcmp(mode, "no16") == 0)) {
+    const bool no16 = mode && std::strcmp(mode, "no16") == 0;
+    if (!dbuf && !stream8 && Cout <= 16 && Cin > 8 && g.kd == 3 && g.kh == 3 && g.kw == 3 && !no16) {
         if (plan_n16(1, kLdsLimit / 2, in, oc, g, Cin, Cout, pool, p)) return true;   // two 4-wave workgroups per CU
         if (plan_n16(0, kLdsLimit, in, oc, g, Cin, Cout, pool, p)) return true;       // one 8-wave workgroup
+    }
+    // Cout 17..20 (a 20-class head): 16 channels on the matrix pipe + up to 4 on the VALU pipe underneath,
+    // instead of a 32-wide tile with 12 zero columns
+    if (!dbuf && !stream8 && Cout > 16 && Cout <= 20 && Cin > 8 && pool == 0 && g.kd == 3 && g.kh == 3 && g.kw == 3 && !no16 &&
+        !getenv("TH_CONV_NOXC")) {
+        if (plan_n16(2, kLdsLimit / 2, in, oc, g, Cin, Cout, pool, p)) return true;
     }
     if (!dbuf && cfg >= 1 && cfg <= 3) {
         if (!stream8 && plan_with_cfg(cfg + 7, kLdsLimit / 2, true, in, oc, g, Cin, Cout, pool, p)) return true;
@@ -1080,6 +1166,17 @@ void conv_mfma_pack_weights(const ConvMfmaPlan& p, const ConvGeom& g, int Cin, i
                         for (int e = 0; e < 4; ++e) {
                             const int ci = ch * 16 + 4 * q + e;
                             if (ci < Cin) dst[((((size_t)ch * ntaps + t) * 4 + q) * 16 + j) * 4 + e] = w[((size_t)t * Cin + ci) * Cout + j];
+                        }
+        // VALU side channels (BN = 16 + xc): [chunk][tap][q][c][e] appended after the MFMA image
+        const int xc = p.BN - 16;
+        float* wx = dst + (size_t)p.nchunks * ntaps * 256;
+        for (int ch = 0; ch < p.nchunks; ++ch)
+            for (int t = 0; t < ntaps; ++t)
+                for (int q = 0; q < 4; ++q)
+                    for (int c = 0; c < xc; ++c)
+                        for (int e = 0; e < 4; ++e) {
+                            const int ci = ch * 16 + 4 * q + e, co = 16 + c;
+                            if (ci < Cin && co < Cout) wx[((((size_t)ch * ntaps + t) * 4 + q) * xc + c) * 4 + e] = w[((size_t)t * Cin + ci) * Cout + co];
                         }
         return;
     }
@@ -1122,7 +1219,7 @@ void conv_mfma_pack_weights(const ConvMfmaPlan& p, const ConvGeom& g, int Cin, i
 
 int launch_conv_mfma(hipStream_t s, int64_t n, const ConvMfmaPlan& p, TView in, TView out, ConvGeom g, int Cin, int Cout,
                      const float* wpk, const float* bias, PreOp pre, PostOps post) {
-    const bool n16 = p.cfg >= 200 && p.cfg < 202;
+    const bool n16 = p.cfg >= 200 && p.cfg < 203;
     if (!n16 && (p.cfg < 0 || p.cfg >= kNumCfgs)) TH_FAIL(TH_EINVAL, "conv_mfma: bad plan");
     const CfgDesc c16 = {n16 ? kN16[p.cfg - 200].WAVES : 0, 0, 0, 0, 16, 3};
     const CfgDesc& c = n16 ? c16 : kCfgs[p.cfg];
@@ -1140,6 +1237,7 @@ int launch_conv_mfma(hipStream_t s, int64_t n, const ConvMfmaPlan& p, TView in, 
     { static const bool nozm = getenv("TH_CONV_NOZMAJOR") != nullptr; a.zmajor = (!nozm && !n16 && p.pool == 0 && p.bres == 2 && c.CI == 16) ? 1 : 0; }
     { static const int dbg = getenv("TH_CONV_DBG") ? atoi(getenv("TH_CONV_DBG")) : 0; a.dbg = dbg; }
     a.wpk = wpk; a.Cout = Cout; a.bias = bias; a.pre = pre; a.post = post;
+    a.wx = n16 ? wpk + (size_t)p.nchunks * 27 * 256 : wpk;
     a.out = out.p; a.out_fs = out.fs; a.out_cs = out.cs; a.out_coff = out.coff; a.Ho = out.H; a.Wo = out.W;
     a.nframes = n;
     const int64_t groups = (n + p.FB - 1) / p.FB;
