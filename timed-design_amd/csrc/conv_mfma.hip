@@ -693,16 +693,18 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
     // use; the packed image is [chunk][tap][lane], the index runs on into the next chunk and wraps to chunk 0
     // for the next frame group
     float4 breg[BR];
-    // XC: this lane's (k-slot q) weights of the extra channels for the CURRENT tap, refilled for the next tap
-    // right after use: xw[c] = W[4q..4q+3][16 + c]
+    // XC: this lane's (k-slot q) weights of the extra channels, xw[t % 3][c] = W_t[4q..4q+3][16 + c]; a slot is
+    // refilled with tap t + 3 right after use (27 taps = 9 turns of the ring, so slots line up across chunks)
     const f32x4* wx4 = reinterpret_cast<const f32x4*>(a.wx) + q * (XC ? XC : 1);
-    f32x4 xw[XC ? XC : 1];
+    f32x4 xw[3][XC ? XC : 1];
     if (wave < total_blocks) {
 #pragma unroll
         for (int t = 0; t < BR; ++t) breg[t] = wpk4[(size_t)(t % wcount) * 64];
         if (XC) {
 #pragma unroll
-            for (int c = 0; c < XC; ++c) xw[c] = wx4[c];
+            for (int c = 0; c < XC; ++c)
+#pragma unroll
+                for (int r = 0; r < 3; ++r) xw[r][c] = wx4[(size_t)(r % wcount) * 4 * XC + c];
         }
     }
 
@@ -723,13 +725,11 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
             f32x4 acc[TM];
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) acc[tm] = f32x4{0.f, 0.f, 0.f, 0.f};
-            // partial sums of row i16 over this lane's channels (4q, 4q+1) and (4q+2, 4q+3): two independent
-            // accumulator pairs so that no FMA depends on the one issued just before it
-            f32x2 xacc[XC ? TM : 1][XC ? XC : 1], xacb[XC ? TM : 1][XC ? XC : 1];
+            f32x2 xacc[XC ? TM : 1][XC ? XC : 1];   // (even, odd) k partial sums of row i16 over this lane's 4 channels
 #pragma unroll
             for (int tm = 0; tm < (XC ? TM : 1); ++tm)
 #pragma unroll
-                for (int c = 0; c < (XC ? XC : 1); ++c) xacc[tm][c] = xacb[tm][c] = f32x2{0.f, 0.f};
+                for (int c = 0; c < (XC ? XC : 1); ++c) xacc[tm][c] = f32x2{0.f, 0.f};
             int aidx[TM];
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
@@ -826,9 +826,9 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
                                 for (int tm = 0; tm < TM; ++tm) {
                                     const f32x4 aq = av[t & 1][tm];
                                     acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[k], bk[k], acc[tm], 0, 0, 0);
-                                    const f32x4 wv = xw[k < XC ? k : 0];
+                                    const f32x4 wv = xw[t % 3][k < XC ? k : 0];
                                     xacc[tm][k < XC ? k : 0] = __builtin_elementwise_fma(aq.xy, wv.xy, xacc[tm][k < XC ? k : 0]);
-                                    xacb[tm][k < XC ? k : 0] = __builtin_elementwise_fma(aq.zw, wv.zw, xacb[tm][k < XC ? k : 0]);
+                                    xacc[tm][k < XC ? k : 0] = __builtin_elementwise_fma(aq.zw, wv.zw, xacc[tm][k < XC ? k : 0]);
                                 }
                             }
 #pragma unroll
@@ -839,10 +839,10 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
                         }
                         __builtin_amdgcn_sched_barrier(0);
                         if (XC) {
-                            int widx = ch * NTAPS + t + 1;
+                            int widx = ch * NTAPS + t + 3;
                             widx = widx >= wcount ? widx - wcount : widx;
 #pragma unroll
-                            for (int c = 0; c < XC; ++c) xw[c] = wx4[(size_t)min(widx, wcount - 1) * 4 * XC + c];
+                            for (int c = 0; c < XC; ++c) xw[t % 3][c] = wx4[(size_t)min(widx, wcount - 1) * 4 * XC + c];
                         }
                         if (!PING) {
                             if (nt < NTAPS) {
@@ -939,7 +939,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
                         float mine = 0.f;
 #pragma unroll
                         for (int c = 0; c < (XC ? XC : 1); ++c) {
-                            float v = (xacc[tm][c][0] + xacc[tm][c][1]) + (xacb[tm][c][0] + xacb[tm][c][1]);
+                            float v = xacc[tm][c][0] + xacc[tm][c][1];
                             v += __shfl_xor(v, 16);
                             v += __shfl_xor(v, 32);
                             mine = (q == c) ? v : mine;
