@@ -83,7 +83,9 @@ int th_predict_device(th_model* m, const void* d_frames, int dtype, int64_t n, f
  * layers only): out is [n, D,H,W,C] or [n,F] fp32.  Debug/parity aid. */
 int th_model_fetch(th_model* m, const char* layer_name, int64_t n, float* out, int64_t out_floats);
 
-/* per-launch timing of the last th_predict_device call, HIP events on the model's stream */
+/* per-launch timing with HIP events on the model's stream, accumulated over th_predict* calls until the
+ * next th_model_profile call: enable = 0 off, 1 every step of the plan, 2 only the step with the most
+ * algorithmic FLOPs (2 events per chunk: negligible cost inside a timed region) */
 int th_model_profile(th_model* m, int enable);
 /* step i of the plan: kernel label, accumulated ms and launch count since profiling was enabled,
  * algorithmic FLOPs and bytes per frame attributed to the step */

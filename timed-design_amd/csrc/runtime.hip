@@ -107,7 +107,9 @@ struct th_model {
     int n_classes = 0;
     int chunk = 1024;
     int chunk_alloc = 0;
-    bool profiling = false;
+    int profiling = 0;            // 0 off, 1 every step, 2 only the step with the most algorithmic FLOPs
+    int dominant_step = -1;
+    std::vector<hipEvent_t> ev_pool;
     double algo_flops = 0, exec_flops = 0;
     void* d_in_stage = nullptr;   // host->device staging for th_predict
     size_t in_stage_bytes = 0;
@@ -678,8 +680,21 @@ int run_device(th_model* m, const void* d_frames, int dtype, int64_t n, float* d
     const int Vin = in.D * in.H * in.W;
     const size_t frame_bytes = (size_t)Vin * in.C * esz;
     const int out_node = logits ? m->logits_node : m->output_node;
-    std::vector<hipEvent_t> evs;
+    // profiling: events come from a pool owned by the model and consecutive steps share their boundary event
+    std::vector<hipEvent_t> evs;      // evs[k], evs[k+1] bracket ev_step[k] when ev_step[k] >= 0
     std::vector<int> ev_step;
+    size_t ev_used = 0;
+    bool at_event = false;        // the last recorded event marks the current end of the stream
+    auto next_event = [&](hipEvent_t* e) -> int {
+        if (ev_used == m->ev_pool.size()) {
+            hipEvent_t ne;
+            HIP_TRY(hipEventCreate(&ne));
+            m->ev_pool.push_back(ne);
+        }
+        *e = m->ev_pool[ev_used++];
+        HIP_TRY(hipEventRecord(*e, m->stream));
+        return TH_OK;
+    };
     for (int64_t off = 0; off < n; off += m->chunk) {
         const int64_t cnt = std::min<int64_t>(m->chunk, n - off);
         m->cur_in = (const char*)d_frames + (size_t)off * frame_bytes;
@@ -691,22 +706,25 @@ int run_device(th_model* m, const void* d_frames, int dtype, int64_t n, float* d
         for (size_t si = 0; si < m->steps.size(); ++si) {
             Step& st = m->steps[si];
             if (logits && st.is_final_softmax) continue;
-            if (m->profiling) {
+            const bool timed = m->profiling == 1 || (m->profiling == 2 && (int)si == m->dominant_step);
+            if (timed && !at_event) {   // interval k = (evs[k], evs[k+1]); a fresh start event opens a gap interval
                 hipEvent_t e0;
-                HIP_TRY(hipEventCreate(&e0));
-                HIP_TRY(hipEventRecord(e0, m->stream));
+                if ((rc = next_event(&e0))) return rc;
+                if (!evs.empty()) ev_step.push_back(-1);
                 evs.push_back(e0);
             }
             rc = st.run(m->stream, cnt);
             if (rc) return rc;
-            if (m->profiling) {
+            at_event = false;
+            if (timed) {
                 hipEvent_t e1;
-                HIP_TRY(hipEventCreate(&e1));
-                HIP_TRY(hipEventRecord(e1, m->stream));
+                if ((rc = next_event(&e1))) return rc;
                 evs.push_back(e1);
                 ev_step.push_back((int)si);
+                at_event = true;    // the next step can use e1 as its start
             }
         }
+        at_event = false;           // the output copy (and the next chunk's convert) are not steps
         TView o;
         o.p = d_probs + (size_t)off * m->nodes[out_node].C;
         o.C = o.cs = m->nodes[out_node].C;
@@ -717,13 +735,13 @@ int run_device(th_model* m, const void* d_frames, int dtype, int64_t n, float* d
     }
     if (!sync && !m->profiling) return TH_OK;  // caller overlaps its next host->device copy and synchronises itself
     HIP_TRY(hipStreamSynchronize(m->stream));
-    for (size_t k = 0; k < ev_step.size(); ++k) {
+    for (size_t k = 0; k < ev_step.size() && k + 1 < evs.size(); ++k) {
+        if (ev_step[k] < 0) continue;
         float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, evs[2 * k], evs[2 * k + 1]));
+        HIP_TRY(hipEventElapsedTime(&ms, evs[k], evs[k + 1]));
         m->steps[ev_step[k]].ms += ms;
         m->steps[ev_step[k]].launches += 1;
     }
-    for (hipEvent_t e : evs) (void)hipEventDestroy(e);
     return TH_OK;
 }
 
@@ -794,6 +812,7 @@ void th_model_free(th_model* m) {
     for (Buffer& b : m->bufs) if (b.dev) (void)hipFree(b.dev);
     if (m->d_in_stage) (void)hipFree(m->d_in_stage);
     if (m->d_out_stage) (void)hipFree(m->d_out_stage);
+    for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
 }
@@ -904,7 +923,12 @@ int th_model_fetch(th_model* m, const char* layer_name, int64_t n, float* out, i
 
 int th_model_profile(th_model* m, int enable) {
     if (!m) TH_FAIL(TH_EINVAL, "null model");
-    m->profiling = enable != 0;
+    if (enable < 0 || enable > 2) TH_FAIL(TH_EINVAL, "profile mode must be 0, 1 or 2");
+    m->profiling = enable;
+    m->dominant_step = -1;
+    double best = -1;
+    for (size_t i = 0; i < m->steps.size(); ++i)
+        if (m->steps[i].flops > best) { best = m->steps[i].flops; m->dominant_step = (int)i; }
     for (Step& s : m->steps) { s.ms = 0; s.launches = 0; }
     return TH_OK;
 }

@@ -101,8 +101,9 @@ class HipFrameModel:
         _lib.check(self._lib.th_model_cost(self._h, C.byref(a), C.byref(e), C.byref(n)))
         return dict(algo_flops=a.value, exec_flops=e.value, n_steps=n.value)
 
-    def profile(self, enable: bool = True):
-        _lib.check(self._lib.th_model_profile(self._h, int(enable)))
+    def profile(self, mode=True):
+        """0/False off; 1/True time every plan step; 2 time only the step with the most FLOPs (cheap)."""
+        _lib.check(self._lib.th_model_profile(self._h, int(mode)))
 
     def steps(self) -> List[dict]:
         out = []
