@@ -99,6 +99,11 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP events (roofline omitted)")
     args = ap.parse_args()
 
+    # stdout carries exactly one JSON line: gloo / RCCL banners written to fd 1 by native code go to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -248,7 +253,8 @@ def main():
                                    for s in warm_steps]
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(cfg, weights, f"{model.name}-synth")
-        print(json.dumps(line))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if comm is not None:
         lib.th_comm_free(comm)
     if dist is not None:
