@@ -69,6 +69,9 @@ def load() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950). "
             "There is no CPU fallback.")
+    # the host driver only supports dmabuf IPC: RCCL (and any cross-process device-memory sharing) needs this set
+    # before the HIP runtime initialises; an explicit setting in the environment wins
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export the symbol
