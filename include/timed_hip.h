@@ -126,6 +126,13 @@ int th_sample_ex(const double* probs, int64_t n_res, int n_cls, int64_t n_sample
                  int rng_mode, uint64_t seed, uint64_t rng_offset, const double* uniforms, int32_t* idx_out,
                  double* r_out, const char* cat_letters, char* letters_out, double* q_out, int device);
 
+/* ---- text output: replaces np.savetxt(f, matrix, delimiter=",") — design_utils/utils.py:768-771 (float16
+ * probabilities) and predict.py:145-146 (full-precision rotamer matrix).  Host code only.  Formats the row-major
+ * [n, k] matrix exactly as NumPy does (every value '%.18e', ',' between columns, '\n' after each row, NaN as
+ * 'nan') into out; dtype is TH_F16 (preformatted table), TH_F32 or TH_F64.  Returns the number of bytes written,
+ * or a negative TH_E* code (cap too small: 28 bytes per value always suffice). */
+int64_t th_format_csv(const void* data, int dtype, int64_t n, int64_t k, char* out, int64_t cap);
+
 /* ---- multi-GPU reassembly (no reference counterpart: the reference is single-process) ----- */
 /* one process per GPU; rank 0 creates the id and ships it to the others out of band */
 #define TH_COMM_ID_BYTES 128

@@ -18,6 +18,8 @@ from pathlib import Path
 
 import numpy as np
 
+from timed_hip import textio
+
 from .amino_acids import UNCOMMON_RESIDUE_DICT, side_chain_dihedrals, standard_amino_acids
 
 
@@ -270,15 +272,31 @@ def save_outputs_to_file(
     np.savetxt's default '%.18e' (so the file holds float16-rounded values)."""
     path_to_output = Path(path_to_output)
     if model == 0:
-        with open(path_to_output / "encoded_labels.csv", "a") as f:
-            np.savetxt(f, np.asarray(y_true), delimiter=",", fmt="%i")
+        with open(path_to_output / "encoded_labels.csv", "ab") as f:
+            _savetxt_small_ints(f, np.asarray(y_true))
     path_to_datasetmap = path_to_output / "datasetmap.txt"
     if not path_to_datasetmap.exists():
         with open(path_to_datasetmap, "a") as f:
             np.savetxt(f, np.asarray(flat_dataset_map), delimiter=",", fmt="%s")
     predictions = np.array(y_pred[model], dtype=np.float16)
-    with open(path_to_output / f"{model_name}.csv", "a") as f:
-        np.savetxt(f, predictions, delimiter=",")
+    with open(path_to_output / f"{model_name}.csv", "ab") as f:
+        textio.savetxt_csv(f, predictions)     # same bytes as np.savetxt(f, predictions, delimiter=","), formatted natively
+
+
+def _savetxt_small_ints(f, a: np.ndarray) -> None:
+    """np.savetxt(f, a, delimiter=",", fmt="%i") for the one-hot label matrix: single digits are laid out as bytes
+    directly; anything else goes through NumPy."""
+    a = np.atleast_2d(np.asarray(a))
+    if a.ndim == 2 and a.size and np.all(np.isfinite(a)):
+        ai = a.astype(np.int64)          # '%i' truncates towards zero like this cast
+        if ai.min() >= 0 and ai.max() <= 9:
+            out = np.empty((ai.shape[0], 2 * ai.shape[1]), dtype=np.uint8)
+            out[:, 0::2] = ai + ord("0")
+            out[:, 1::2] = ord(",")
+            out[:, -1] = ord("\n")
+            f.write(out.tobytes())
+            return
+    np.savetxt(f, a, delimiter=",", fmt="%i")
 
 
 def convert_dataset_map_for_srb(flat_dataset_map: list, model_name: str, path_to_output: Path = Path.cwd()):

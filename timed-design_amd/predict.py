@@ -34,7 +34,7 @@ from design_utils.utils import (
     save_dict_to_fasta,
     save_outputs_to_file,
 )
-from timed_hip import engine
+from timed_hip import engine, textio
 
 
 def load_dataset_and_predict(
@@ -79,15 +79,15 @@ def load_dataset_and_predict(
             X_batch, y_true_batch = load_batch(dataset_path, current_batch_map)
             y_pred_batch = frame_model.predict(X_batch)
             if predict_rotamers:
-                with open(model_out, "a") as f:
-                    np.savetxt(f, y_pred_batch, delimiter=",")
+                with open(model_out, "ab") as f:
+                    textio.savetxt_csv(f, y_pred_batch)    # = np.savetxt(f, y_pred_batch, delimiter=","), full precision
                 current_batch = np.argmax(y_pred_batch, axis=1)
                 y_pred_batch = np.array([codec[c] for c in current_batch])
             save_outputs_to_file(list(y_true_batch), {i: list(y_pred_batch)}, flat_dataset_map, i, model_name, path_to_output)
         frame_model.close()
         flat_dataset_map = np.array(flat_dataset_map)
         convert_dataset_map_for_srb(flat_dataset_map, model_name, path_to_output)
-        prediction_matrix = np.atleast_2d(genfromtxt(model_out, delimiter=",", dtype=np.float16))
+        prediction_matrix = textio.loadtxt_f16(model_out)   # = np.atleast_2d(genfromtxt(..., dtype=np.float16)), C parser
         (pdb_to_sequence, pdb_to_probability, pdb_to_real_sequence, pdb_to_consensus,
          pdb_to_consensus_prob) = extract_sequence_from_pred_matrix(
             flat_dataset_map, prediction_matrix,

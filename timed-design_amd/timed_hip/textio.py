@@ -1,0 +1,68 @@
+"""Native text output for the prediction writers: byte-identical to
+``np.savetxt(f, matrix, delimiter=",")`` (reference design_utils/utils.py:768-771, predict.py:145-146),
+formatted by libtimedhip's host-side ``th_format_csv`` instead of Python's per-row ``%`` operator."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+_DTYPES = {np.dtype(np.float16): _lib.TH_F16, np.dtype(np.float32): _lib.TH_F32, np.dtype(np.float64): _lib.TH_F64}
+
+
+_BLOCK_VALUES = 1 << 18      # values formatted per native call: ~7 MB of text, stays cache/TLB friendly
+
+
+def _check(matrix) -> np.ndarray:
+    a = np.asarray(matrix)
+    if a.ndim == 1:
+        a = a.reshape(-1, 1)
+    if a.ndim != 2 or a.dtype not in _DTYPES:
+        raise TypeError("format_csv takes a 1-D or 2-D float16/float32/float64 array")
+    return np.ascontiguousarray(a)
+
+
+def _blocks(a: np.ndarray):
+    """memoryviews of the text of consecutive row blocks; the scratch buffer is reused between blocks"""
+    n, k = a.shape
+    if n == 0:
+        return
+    if k == 0:
+        yield memoryview(b"\n" * n)
+        return
+    rows = max(1, min(n, _BLOCK_VALUES // k))
+    cap = rows * k * 28 + 32
+    buf = np.empty(cap, dtype=np.uint8)          # not zero-filled
+    lib = _lib.load()
+    for lo in range(0, n, rows):
+        blk = a[lo:lo + rows]
+        got = lib.th_format_csv(blk.ctypes.data_as(C.c_void_p), _DTYPES[a.dtype], blk.shape[0], k,
+                                buf.ctypes.data_as(C.c_void_p), cap)
+        if got < 0:
+            raise _lib.TimedHipError(int(got), lib.th_last_error().decode(errors="replace"))
+        yield memoryview(buf)[:got]
+
+
+def format_csv(matrix: np.ndarray) -> bytes:
+    """'%.18e' / ',' / '\\n' text of a 2-D float16/32/64 matrix (a 1-D array is one value per line, as np.savetxt)."""
+    return b"".join(bytes(m) for m in _blocks(_check(matrix)))
+
+
+def savetxt_csv(f, matrix: np.ndarray) -> None:
+    """Drop-in for ``np.savetxt(f, matrix, delimiter=",")`` on a file opened in text or binary mode."""
+    for m in _blocks(_check(matrix)):
+        try:
+            f.write(m)
+        except TypeError:       # text-mode handle
+            f.write(bytes(m).decode("ascii"))
+
+
+def loadtxt_f16(path) -> np.ndarray:
+    """What ``np.genfromtxt(path, delimiter=",", dtype=np.float16)`` returns for a probability CSV (reference
+    predict.py:163), read with NumPy's C parser: text -> float64 -> float16 is the same double rounding."""
+    try:
+        return np.loadtxt(path, delimiter=",", dtype=np.float64, ndmin=2).astype(np.float16)
+    except ValueError:      # ragged / missing fields: let genfromtxt apply its own rules
+        return np.atleast_2d(np.genfromtxt(path, delimiter=",", dtype=np.float16))
