@@ -52,6 +52,10 @@ struct PostOps {
     float alpha[TH_MAX_POST] = {0, 0, 0, 0};
     const float* scale[TH_MAX_POST] = {nullptr, nullptr, nullptr, nullptr};  // per output channel
     const float* shift[TH_MAX_POST] = {nullptr, nullptr, nullptr, nullptr};
+    // every op is monotone non-decreasing (ReLU/ELU/LeakyReLU with alpha >= 0, sigmoid, tanh, BN-affine with
+    // scale >= 0 on every channel): max-pooling then commutes with the whole chain, so a kernel may pool the raw
+    // accumulators first and run the chain on 1/8 of the values (set by the planner, runtime.hip)
+    int monotone = 0;
 };
 // elementwise prologue applied to the conv input when it is staged (BN->ReLU->Conv chains)
 struct PreOp {

@@ -53,8 +53,12 @@ __device__ __forceinline__ float load_elem(const void* base, int dtype, int64_t 
     }
 }
 
-template <int WAVES, int NST, int POOL>
+// PMODE: 0 no pool, 1 max 2x2x2, 2 avg 2x2x2, 3 max 2x2x2 taken BEFORE the epilogue chain (planner proved the chain
+// monotone non-decreasing: PostOps::monotone)
+template <int WAVES, int NST, int PMODE>
 __global__ void __launch_bounds__(WAVES * 64, 3) k_conv_first(const ConvFirstArgs a) {
+    constexpr int POOL = PMODE == 3 ? 1 : PMODE;
+    constexpr bool POOL_FIRST = PMODE == 3;
     constexpr int NTHREADS = WAVES * 64;
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     const int tid = threadIdx.x;
@@ -209,6 +213,24 @@ __global__ void __launch_bounds__(WAVES * 64, 3) k_conv_first(const ConvFirstArg
         float x[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) x[i] = acc[i] + bv;
+        if (POOL_FIRST) {
+            // max-pooling commutes with a monotone non-decreasing chain (ELU/ReLU/BN with scale >= 0 ...): pool the raw
+            // sums and evaluate the chain on the 4 pooled values of this lane instead of all 16 (TIMED block 1: 8x fewer
+            // ELU exponentials)
+            float m4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float m = fmaxf(fmaxf(x[4 * q], x[4 * q + 1]), fmaxf(x[4 * q + 2], x[4 * q + 3]));
+                m4[q] = fmaxf(m, __shfl_xor(m, 32));
+            }
+            // lanes of half h own pooled voxels 2h and 2h+1 of the tile
+            float y0 = h ? m4[2] : m4[0], y1 = h ? m4[3] : m4[1];
+            th_post2(y0, y1, cc, a.post);
+            const int o0 = cok ? rowout[mt * 4 + 2 * h] : -1, o1 = cok ? rowout[mt * 4 + 2 * h + 1] : -1;
+            if (o0 >= 0) outb[o0 + co] = y0;
+            if (o1 >= 0) outb[o1 + co] = y1;
+            continue;
+        }
         th_post16(x, cc, a.post);
         if (POOL == 0) {
 #pragma unroll
@@ -233,8 +255,8 @@ __global__ void __launch_bounds__(WAVES * 64, 3) k_conv_first(const ConvFirstArg
 
 typedef void (*FirstKernel)(const ConvFirstArgs);
 constexpr int kWaves = 4;
-#define ROW(NST) { k_conv_first<kWaves, NST, 0>, k_conv_first<kWaves, NST, 1>, k_conv_first<kWaves, NST, 2> }
-const FirstKernel kFirstKernels[4][3] = {ROW(1), ROW(2), ROW(3), ROW(4)};
+#define ROW(NST) { k_conv_first<kWaves, NST, 0>, k_conv_first<kWaves, NST, 1>, k_conv_first<kWaves, NST, 2>, k_conv_first<kWaves, NST, 3> }
+const FirstKernel kFirstKernels[4][4] = {ROW(1), ROW(2), ROW(3), ROW(4)};
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
@@ -319,7 +341,8 @@ int launch_conv_first(hipStream_t s, int64_t n, const ConvMfmaPlan& p, const voi
     const int64_t grid = n * p.nzb;
     if (grid > 0x7fffffffLL) TH_FAIL(TH_EINVAL, "conv_first: grid too large");
     const int nst = (Cin + 1) / 2;
-    FirstKernel k = kFirstKernels[nst - 1][p.pool];
+    const bool no_pool_first = getenv("TH_NO_POOL_FIRST") != nullptr;   // A/B comparisons and tests
+    FirstKernel k = kFirstKernels[nst - 1][(p.pool == 1 && post.monotone && !no_pool_first) ? 3 : p.pool];
     HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kWaves * 64), p.lds_bytes, s, a);
     hipError_t e = hipGetLastError();

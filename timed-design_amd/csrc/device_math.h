@@ -28,6 +28,29 @@ __device__ __forceinline__ float th_post(float x, int c, const PostOps& ops) {
     return x;
 }
 
+// Two values of one channel (the pooled outputs a lane owns after a pool-first epilogue): op list decoded once.
+__device__ __forceinline__ void th_post2(float& x0, float& x1, int c, const PostOps& ops) {
+    for (int i = 0; i < ops.n; ++i) {
+        if (ops.type[i] == POP_AFFINE) {
+            const float sc = ops.scale[i][c], sh = ops.shift[i][c];
+            x0 = fmaf(x0, sc, sh);
+            x1 = fmaf(x1, sc, sh);
+        } else {
+            const float alpha = ops.alpha[i];
+            switch (ops.act[i]) {
+                case ACT_RELU: x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f); break;
+                case ACT_ELU:
+                    x0 = x0 > 0.f ? x0 : alpha * (__expf(x0) - 1.f);
+                    x1 = x1 > 0.f ? x1 : alpha * (__expf(x1) - 1.f);
+                    break;
+                case ACT_LEAKY: x0 = x0 > 0.f ? x0 : alpha * x0; x1 = x1 > 0.f ? x1 : alpha * x1; break;
+                case ACT_LINEAR: break;
+                default: x0 = th_act(x0, ops.act[i], alpha); x1 = th_act(x1, ops.act[i], alpha);
+            }
+        }
+    }
+}
+
 // Same epilogue for the 16 accumulator values a lane holds for ONE output channel c: the op list is
 // decoded once (op-outer, element-inner), so the per-element cost is the bare arithmetic
 // (ELU: exp2-path exp + select; affine: one fma) instead of a switch per element.

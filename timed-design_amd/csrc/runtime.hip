@@ -238,14 +238,22 @@ int bn_affine(th_model* m, const Node& bn, const float** scale, const float** sh
 int add_post(th_model* m, PostOps* po, const Node& n) {
     if (po->n >= TH_MAX_POST) return 1;
     const int i = po->n;
+    if (i == 0) po->monotone = 1;
     if (n.op == OP_BN) {
         po->type[i] = POP_AFFINE;
         int rc = bn_affine(m, n, &po->scale[i], &po->shift[i]);
         if (rc) return rc;
+        // scale = gamma * rsqrt(var + eps): its sign is gamma's
+        const float* g = n.w[0] >= 0 ? m->blob_host[n.w[0]] : nullptr;
+        for (int c = 0; g && c < n.ip[0]; ++c) if (!(g[c] >= 0.f)) po->monotone = 0;
     } else {
         po->type[i] = POP_ACT;
         po->act[i] = n.ip[0];
         po->alpha[i] = n.fp[0];
+        const int a = po->act[i];
+        const bool mono = a == ACT_LINEAR || a == ACT_RELU || a == ACT_SIGMOID || a == ACT_TANH ||
+                          ((a == ACT_ELU || a == ACT_LEAKY) && po->alpha[i] >= 0.f);
+        if (!mono) po->monotone = 0;
     }
     po->n++;
     return TH_OK;
@@ -444,7 +452,11 @@ int plan(th_model* m) {
                 const int own_act = n.op == OP_CONV3D ? n.ip[13] : n.ip[3];
                 bool split_softmax = false;
                 if (own_act == ACT_SOFTMAX) split_softmax = true;
-                else if (own_act != ACT_LINEAR) { po.type[0] = POP_ACT; po.act[0] = own_act; po.alpha[0] = n.fp[0]; po.n = 1; }
+                else if (own_act != ACT_LINEAR) {
+                    po.type[0] = POP_ACT; po.act[0] = own_act; po.alpha[0] = n.fp[0]; po.n = 1;
+                    po.monotone = (own_act == ACT_RELU || own_act == ACT_SIGMOID || own_act == ACT_TANH ||
+                                   ((own_act == ACT_ELU || own_act == ACT_LEAKY) && n.fp[0] >= 0.f)) ? 1 : 0;
+                }
                 for (int x : f.post) if ((rc = add_post(M, &po, N[x]))) return rc < 0 ? rc : TH_EUNSUP;
                 for (int x : f.pre) {
                     if (N[x].op == OP_BN) { if ((rc = bn_affine(M, N[x], &pre.scale, &pre.shift))) return rc; }
