@@ -150,26 +150,26 @@ def test_narrow_conv_persistent_workgroups_walk_several_groups(gpu, monkeypatch,
 
 
 @pytest.mark.parametrize("negative_gamma", [False, True])
-@pytest.mark.parametrize("act", ["elu", "relu", "leaky"])
-def test_first_block_pools_before_a_monotone_epilogue_only(gpu, monkeypatch, negative_gamma, act):
-    """Conv -> act -> BN -> MaxPool on the input: when every BN scale is >= 0 the first-layer kernel max-pools the
-    raw sums and runs act+BN on the pooled values (max commutes with a non-decreasing chain); a negative gamma
+@pytest.mark.parametrize("act,cin,cout", [("elu", 6, 32), ("relu", 6, 32), ("leaky", 6, 32), ("elu", 24, 64), ("relu", 40, 128)])
+def test_first_block_pools_before_a_monotone_epilogue_only(gpu, monkeypatch, negative_gamma, act, cin, cout):
+    """Conv -> act -> BN -> MaxPool (first-layer kernel for cin=6, brick kernel otherwise): when every BN scale is
+    >= 0 the kernel max-pools the raw sums and runs act+BN on the pooled values (max commutes with a non-decreasing chain); a negative gamma
     on any channel must keep the original order.  Both orders are checked against the oracle, and against each
     other with the rewrite switched off."""
     def build(b, x):
-        x = b.conv3d(x, 32, 3, padding="same")
+        x = b.conv3d(x, cout, 3, padding="same")
         x = {"elu": b.elu, "relu": b.relu, "leaky": lambda t: b.leaky_relu(t, 0.2)}[act](x)
         return b.maxpool(b.batchnorm(x), 2)
 
-    cfg, weights = _net((9, 8, 7), 6, build, seed=31)
+    cfg, weights = _net((9, 8, 7), cin, build, seed=31)
     bn = [k for k in weights if k.startswith("batch_normalization")][0]
     if negative_gamma:
         g = weights[bn][0].copy()
         g[::5] *= -1.0
         weights[bn] = [g] + list(weights[bn][1:])
-    frames = _frames(6, (9, 8, 7), 6, 5)
+    frames = _frames(6, (9, 8, 7), cin, 5)
     labels = _check(cfg, weights, frames)
-    assert any("conv_first" in l and "pool1" in l for l in labels), labels
+    assert any(("conv_first" if cin == 6 else "conv_mfma") in l and "pool1" in l for l in labels), labels
     got = engine.HipFrameModel.from_keras(cfg, weights).predict(frames)
     monkeypatch.setenv("TH_NO_POOL_FIRST", "1")
     ref = engine.HipFrameModel.from_keras(cfg, weights).predict(frames)

@@ -536,15 +536,26 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
                             for (int k = 0; k < 2; ++k)
 #pragma unroll
                                 for (int e = 0; e < 8; ++e) x[8 * k + e] = T[(8 * (2 * k + h) + e) * 33 + j] + bv;
-                            th_post16(x, cc, a.post);
+                            if (POOL == 1 && a.post.monotone) {
+                                // max-pool first, then the (monotone non-decreasing) chain on the two pooled values only
+                                float m0 = x[0], m1 = x[8];
 #pragma unroll
-                            for (int k = 0; k < 2; ++k) {
-                                float m = x[8 * k];
+                                for (int e = 1; e < 8; ++e) { m0 = fmaxf(m0, x[e]); m1 = fmaxf(m1, x[8 + e]); }
+                                th_post2(m0, m1, cc, a.post);
+                                const int o0 = cok ? rowout[mt * 4 + h] : -1, o1 = cok ? rowout[mt * 4 + 2 + h] : -1;
+                                if (o0 >= 0) outb[o0 + co] = m0;
+                                if (o1 >= 0) outb[o1 + co] = m1;
+                            } else {
+                                th_post16(x, cc, a.post);
 #pragma unroll
-                                for (int e = 1; e < 8; ++e) m = (POOL == 1) ? fmaxf(m, x[8 * k + e]) : m + x[8 * k + e];
-                                if (POOL == 2) m *= 0.125f;
-                                const int oo = cok ? rowout[mt * 4 + 2 * k + h] : -1;
-                                if (oo >= 0) outb[oo + co] = m;
+                                for (int k = 0; k < 2; ++k) {
+                                    float m = x[8 * k];
+#pragma unroll
+                                    for (int e = 1; e < 8; ++e) m = (POOL == 1) ? fmaxf(m, x[8 * k + e]) : m + x[8 * k + e];
+                                    if (POOL == 2) m *= 0.125f;
+                                    const int oo = cok ? rowout[mt * 4 + 2 * k + h] : -1;
+                                    if (oo >= 0) outb[oo + co] = m;
+                                }
                             }
                         }
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

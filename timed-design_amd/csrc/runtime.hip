@@ -458,6 +458,7 @@ int plan(th_model* m) {
                                    ((own_act == ACT_ELU || own_act == ACT_LEAKY) && n.fp[0] >= 0.f)) ? 1 : 0;
                 }
                 for (int x : f.post) if ((rc = add_post(M, &po, N[x]))) return rc < 0 ? rc : TH_EUNSUP;
+                if (getenv("TH_NO_POOL_FIRST")) po.monotone = 0;   // A/B comparisons and tests: keep act/BN before the max-pool
                 for (int x : f.pre) {
                     if (N[x].op == OP_BN) { if ((rc = bn_affine(M, N[x], &pre.scale, &pre.shift))) return rc; }
                     else { pre.act = N[x].ip[0]; pre.alpha = N[x].fp[0]; }
