@@ -42,6 +42,72 @@ struct ConvPwArgs {
     unsigned ntiles;
 };
 
+// this lane's input row for a tile: lane j supplies GEMM row tile*32 + j (POOL: pooled voxel tile*4 + j/8, mate j%8);
+// rows past the end are clamped to the last one (their results are never stored)
+template <int POOL>
+__device__ __forceinline__ const float* pw_row_ptr(const ConvPwArgs& a, unsigned tile, int j, int h) {
+    const float* src;
+    if (POOL == 0) {
+        const unsigned r = tile * 32 + j;
+        const unsigned rc = r < a.nrows ? r : a.nrows - 1;
+        if (a.in_dense) src = a.in + (int64_t)rc * a.in_cs;
+        else { const unsigned f = rc / (unsigned)a.V; src = a.in + (int64_t)f * a.in_fs + (int64_t)(rc - f * a.V) * a.in_cs; }
+    } else {
+        const unsigned p = tile * 4 + (j >> 3), m = j & 7;
+        const unsigned pc = p * 8 < a.nrows ? p : a.nrows / 8 - 1;
+        const unsigned f = pc / (unsigned)a.Vo, vo = pc - f * a.Vo;
+        const unsigned zo = vo / (unsigned)(a.Ho * a.Wo), rem = vo - zo * (a.Ho * a.Wo);
+        const unsigned yo = rem / (unsigned)a.Wo, xo = rem - yo * a.Wo;
+        const unsigned v = ((2 * zo + (m >> 2)) * a.H + 2 * yo + ((m >> 1) & 1)) * a.W + 2 * xo + (m & 1);
+        src = a.in + (int64_t)f * a.in_fs + (int64_t)v * a.in_cs;
+    }
+    return src + a.in_coff + 4 * h;
+}
+
+// epilogue: lane holds output channel (nt*32 + j) of rows (r&3) + 8*(r>>2) + 4h
+template <int NT, int POOL>
+__device__ __forceinline__ void pw_epilogue(const ConvPwArgs& a, unsigned tile, const f32x16 (&acc)[NT], int j, int h) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int co = nt * 32 + j;
+        const bool cok = co < a.Cout;
+        const int cc = cok ? co : 0;
+        float x[16];
+        const float bv = a.bias ? a.bias[cc] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = acc[nt][r] + bv;
+        th_post16(x, cc, a.post);
+        if (POOL == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned row = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (cok && row < a.nrows) {
+                    int64_t off;
+                    if (a.out_dense) off = (int64_t)row * a.out_cs;
+                    else { const unsigned f = row / (unsigned)a.V; off = (int64_t)f * a.out_fs + (int64_t)(row - f * a.V) * a.out_cs; }
+                    a.out[off + a.out_coff + co] = x[r];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                float s;
+                if (POOL == 1) s = fmaxf(fmaxf(x[4 * o], x[4 * o + 1]), fmaxf(x[4 * o + 2], x[4 * o + 3]));
+                else s = (x[4 * o] + x[4 * o + 1]) + (x[4 * o + 2] + x[4 * o + 3]);
+                const float t = __shfl_xor(s, 32, 64);
+                s = POOL == 1 ? fmaxf(s, t) : (s + t) * 0.125f;
+                const unsigned p = tile * 4 + o;
+                if (h == 0 && cok && p * 8 < a.nrows) {
+                    int64_t off;
+                    if (a.out_dense) off = (int64_t)p * a.out_cs;
+                    else { const unsigned f = p / (unsigned)a.Vo; off = (int64_t)f * a.out_fs + (int64_t)(p - f * a.Vo) * a.out_cs; }
+                    a.out[off + a.out_coff + co] = s;
+                }
+            }
+        }
+    }
+}
+
 // KMAX: float4 A-slots a lane keeps per K pass (8 channels each); NT: 32-wide output tiles; POOL 0/1 max/2 avg
 template <int KMAX, int NT, int POOL>
 __global__ void __launch_bounds__(256, NT == 4 ? 2 : (KMAX == 16 && NT == 2 ? 3 : 4)) k_conv_pw(const ConvPwArgs a) {
@@ -69,26 +135,7 @@ __global__ void __launch_bounds__(256, NT == 4 ? 2 : (KMAX == 16 && NT == 2 ? 3 
 
     const unsigned wstride = gridDim.x * 4;
     for (unsigned tile = blockIdx.x * 4 + wave; tile < a.ntiles; tile += wstride) {
-        // ---- this lane's input row ---------------------------------------------------------------------
-        const float* src;
-        bool rok;
-        if (POOL == 0) {
-            const unsigned r = tile * 32 + j;
-            rok = r < a.nrows;
-            const unsigned rc = rok ? r : a.nrows - 1;
-            if (a.in_dense) src = a.in + (int64_t)rc * a.in_cs;
-            else { const unsigned f = rc / (unsigned)a.V; src = a.in + (int64_t)f * a.in_fs + (int64_t)(rc - f * a.V) * a.in_cs; }
-        } else {
-            const unsigned p = tile * 4 + (j >> 3), m = j & 7;
-            rok = p * 8 < a.nrows;
-            const unsigned pc = rok ? p : a.nrows / 8 - 1;
-            const unsigned f = pc / (unsigned)a.Vo, vo = pc - f * a.Vo;
-            const unsigned zo = vo / (unsigned)(a.Ho * a.Wo), rem = vo - zo * (a.Ho * a.Wo);
-            const unsigned yo = rem / (unsigned)a.Wo, xo = rem - yo * a.Wo;
-            const unsigned v = ((2 * zo + (m >> 2)) * a.H + 2 * yo + ((m >> 1) & 1)) * a.W + 2 * xo + (m & 1);
-            src = a.in + (int64_t)f * a.in_fs + (int64_t)v * a.in_cs;
-        }
-        src += a.in_coff + 4 * h;
+        const float* src = pw_row_ptr<POOL>(a, tile, j, h);
 
         f32x16 acc[NT];
 #pragma unroll
@@ -138,46 +185,7 @@ __global__ void __launch_bounds__(256, NT == 4 ? 2 : (KMAX == 16 && NT == 2 ? 3 
             }
         }
 
-        // ---- epilogue: lane holds output channel (nt*32 + j) of rows (r&3) + 8*(r>>2) + 4h ------------
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int co = nt * 32 + j;
-            const bool cok = co < a.Cout;
-            const int cc = cok ? co : 0;
-            float x[16];
-            const float bv = a.bias ? a.bias[cc] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) x[r] = acc[nt][r] + bv;
-            th_post16(x, cc, a.post);
-            if (POOL == 0) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const unsigned row = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (cok && row < a.nrows) {
-                        int64_t off;
-                        if (a.out_dense) off = (int64_t)row * a.out_cs;
-                        else { const unsigned f = row / (unsigned)a.V; off = (int64_t)f * a.out_fs + (int64_t)(row - f * a.V) * a.out_cs; }
-                        a.out[off + a.out_coff + co] = x[r];
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int o = 0; o < 4; ++o) {
-                    float s;
-                    if (POOL == 1) s = fmaxf(fmaxf(x[4 * o], x[4 * o + 1]), fmaxf(x[4 * o + 2], x[4 * o + 3]));
-                    else s = (x[4 * o] + x[4 * o + 1]) + (x[4 * o + 2] + x[4 * o + 3]);
-                    const float t = __shfl_xor(s, 32, 64);
-                    s = POOL == 1 ? fmaxf(s, t) : (s + t) * 0.125f;
-                    const unsigned p = tile * 4 + o;
-                    if (h == 0 && cok && p * 8 < a.nrows) {
-                        int64_t off;
-                        if (a.out_dense) off = (int64_t)p * a.out_cs;
-                        else { const unsigned f = p / (unsigned)a.Vo; off = (int64_t)f * a.out_fs + (int64_t)(p - f * a.Vo) * a.out_cs; }
-                        a.out[off + a.out_coff + co] = s;
-                    }
-                }
-            }
-        }
+        pw_epilogue<NT, POOL>(a, tile, acc, j, h);
     }
 }
 
