@@ -1,0 +1,83 @@
+#!/usr/bin/env python
+"""Pin the CNN path to the real reference arithmetic: run a released Keras .h5 through TensorFlow
+(`tf.keras.models.load_model(...).predict(X)`, exactly the calls at reference predict.py:121 and :142)
+and compare with (a) oracle/cnn_oracle.py and (b) the HIP engine when a GPU is present.
+
+NOT runnable in the build image (no TensorFlow, no released .h5 — SURVEY.md §8c: the CNN oracle is
+"parity unpinned" against TF for that reason).  Anyone who has both can close that gap:
+
+    pip install tensorflow==2.13.0 h5py
+    python tools/validate_against_keras.py --model TIMED.h5 [--frames data.hdf5 | --synthetic 64] [--save-golden out.npz]
+
+Exit status 0 when max |p_keras - p_oracle| <= 1e-4 and the argmax agrees on every frame whose top-2 margin
+exceeds 1e-4 (the north-star tolerance), for the oracle and, if available, for the HIP engine.
+`--save-golden` writes inputs + Keras outputs as a fixture that tests can pin to afterwards."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "timed-design_amd"))
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--model", required=True, help="Keras legacy .h5 (e.g. a released TIMED model)")
+    ap.add_argument("--frames", help="aposteriori .hdf5 frame dataset; default: synthetic frames")
+    ap.add_argument("--synthetic", type=int, default=64, help="number of synthetic frames when --frames is not given")
+    ap.add_argument("--save-golden", help="write inputs and Keras probabilities to this .npz")
+    ap.add_argument("--tol", type=float, default=1e-4)
+    args = ap.parse_args()
+
+    try:
+        import tensorflow as tf
+    except ImportError:
+        sys.exit("TensorFlow is not installed: this tool needs the reference's own stack (tensorflow==2.13.0)")
+
+    from timed_hip import h5model, synth
+    from oracle import cnn_oracle
+
+    def top_3_cat_acc(y_true, y_pred):   # the custom metric the reference registers (predict.py:24-25, :88)
+        return tf.keras.metrics.top_k_categorical_accuracy(y_true, y_pred, k=3)
+
+    tf.keras.utils.get_custom_objects()["top_3_cat_acc"] = top_3_cat_acc
+    keras_model = tf.keras.models.load_model(args.model)                 # predict.py:121
+    cfg, weights = h5model.read_keras_h5(args.model)                     # our reader of the same file
+    in_shape = tuple(int(d) for d in keras_model.input_shape[1:])
+
+    if args.frames:
+        from design_utils import utils
+        flat, _ = utils.create_flat_dataset_map(args.frames)
+        X, _ = utils.load_batch(args.frames, flat[: max(1, args.synthetic)])
+    else:
+        X = synth.synthetic_frames(args.synthetic, seed=1234, side=in_shape[0], channels=in_shape[-1])
+    X = np.ascontiguousarray(X)
+    want = np.asarray(keras_model.predict(X), dtype=np.float32)          # predict.py:142
+
+    results = {"oracle": cnn_oracle.forward(cfg, weights, X, np.float32)}
+    try:
+        from timed_hip import _lib, engine
+        if _lib.device_count() > 0:
+            results["hip"] = engine.HipFrameModel.from_keras(cfg, weights).predict(X)
+    except Exception as e:   # no library / no GPU: oracle-only validation is still meaningful
+        print(f"[validate] HIP engine not available here ({e}); validating the oracle only")
+
+    ok = True
+    top2 = np.sort(want, axis=1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > args.tol
+    for name, got in results.items():
+        err = float(np.abs(got - want).max())
+        agree = bool(np.array_equal(got.argmax(1)[clear], want.argmax(1)[clear]))
+        print(f"[validate] {name:6s}: max |dp| = {err:.3e} (tolerance {args.tol:g}); argmax agrees on {int(clear.sum())} clear frames: {agree}")
+        ok &= err <= args.tol and agree
+    if args.save_golden:
+        np.savez_compressed(args.save_golden, frames=X, keras_probs=want, model=os.path.basename(args.model))
+        print(f"[validate] wrote {args.save_golden}: drop it under tests/golden/ to pin the oracle to Keras")
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()
