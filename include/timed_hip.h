@@ -133,6 +133,17 @@ int th_sample_ex(const double* probs, int64_t n_res, int n_cls, int64_t n_sample
  * or a negative TH_E* code (cap too small: 28 bytes per value always suffice). */
 int64_t th_format_csv(const void* data, int dtype, int64_t n, int64_t k, char* out, int64_t cap);
 
+/* ---- frame ingest: replaces the per-residue h5py reads of load_batch — design_utils/utils.py:514-529.  Host code
+ * only.  `file` is the whole HDF5 file in memory (an mmap), `base` its superblock offset.  For n_datasets chunked
+ * datasets that share one geometry (shape[rank], chunk[rank], element size, filter pipeline ids in write order:
+ * 1 deflate, 2 shuffle, 3 fletcher32) and whose chunk B-trees (version 1) start at btree_addrs[i], inflate every
+ * chunk and scatter it into dests[i] (C order, shape[] elements of esz bytes) on nthreads host threads (0 = all
+ * cores, at most 32).  Unallocated chunks read as zeros.  TH_EUNSUP when the file uses something else (the
+ * caller then reads through its generic path). */
+int th_h5_read_chunked(const void* file, int64_t file_len, int64_t base, int64_t n_datasets, const int64_t* btree_addrs,
+                       void* const* dests, int rank, const int64_t* shape, const int64_t* chunk, int esz, int n_filters,
+                       const int* filter_ids, int nthreads);
+
 /* ---- multi-GPU reassembly (no reference counterpart: the reference is single-process) ----- */
 /* one process per GPU; rank 0 creates the id and ships it to the others out of band */
 #define TH_COMM_ID_BYTES 128

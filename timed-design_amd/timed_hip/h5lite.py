@@ -543,21 +543,90 @@ class Dataset(_Object):
             raise H5FormatError("expected a chunk B-tree")
         ksz = 8 + 8 * rank
         p = a + 24
+        nel = 1
+        for c in chunk:
+            nel *= c
+        written = 0
         for _ in range(used):
             csize, mask = struct.unpack_from("<II", m, p)
             offs = struct.unpack_from(f"<{rank}Q", m, p + 8)
             child = struct.unpack_from("<Q", m, p + ksz)[0]
             p += ksz + 8
             if level > 0:
-                self._walk_chunks(child, rank, chunk, esz, out)
+                written += self._walk_chunks(child, rank, chunk, esz, out)
                 continue
-            raw = self._unfilter(bytes(m[f._base + child:f._base + child + csize]), mask, esz)
-            block = np.frombuffer(raw, dtype=out.dtype, count=int(np.prod(chunk))).reshape(chunk)
+            raw = self._unfilter(m[f._base + child:f._base + child + csize], mask, esz)
+            block = np.frombuffer(raw, dtype=out.dtype, count=nel).reshape(chunk)
             sl_out, sl_in = [], []
             for o, c, s in zip(offs[:-1], chunk, out.shape):
                 hi = min(o + c, s)
                 sl_out.append(slice(o, hi)); sl_in.append(slice(0, hi - o))
             out[tuple(sl_out)] = block[tuple(sl_in)]
+            written += 1
+        return written
+
+    def chunked_geometry(self):
+        """(btree address, shape, chunk dims, element size, filter ids) of a plain numeric chunked dataset whose
+        bytes can be placed directly (layout v3, B-tree v1, little-endian), else None.  Input of
+        ``read_many_direct`` / the native th_h5_read_chunked."""
+        d = self._layout
+        if self._shape is None or not self._shape or self._dt.vlen_str or d is None or d[0] != 3 or d[1] != 2:
+            return None
+        npdt = np.dtype(bool) if self._dt.enum_bool else self._dt.np
+        if npdt is None or npdt.byteorder == ">" or npdt.kind not in "fiub":
+            return None
+        rank = d[2]
+        btree = struct.unpack_from("<Q", d, 3)[0]
+        cdims = struct.unpack_from(f"<{rank}I", d, 11)
+        if rank - 1 != len(self._shape) or cdims[-1] != self._dt.size:
+            return None
+        return btree, tuple(self._shape), tuple(cdims[:-1]), self._dt.size, tuple(fid for fid, _cd in self._filters)
+
+    def read_direct(self, dest: np.ndarray) -> bool:
+        """Fill the C-contiguous array ``dest`` (same shape and item size as the dataset) straight from the file:
+        chunks are decompressed into their place, no intermediate whole-dataset copies.  Returns False when the
+        dataset needs the general path (strings, byte-swapped or compact storage, shape mismatch); thread-safe
+        (read-only mmap; zlib and the NumPy copies release the GIL), which is what load_batch uses to inflate
+        many residues' frames in parallel."""
+        shape = self._shape
+        if shape is None or self._dt.vlen_str or tuple(dest.shape) != tuple(shape) or not dest.flags.c_contiguous:
+            return False
+        esz = self._dt.size
+        npdt = np.dtype(bool) if self._dt.enum_bool else self._dt.np
+        if dest.dtype.itemsize != esz or npdt.byteorder == ">" or (dest.dtype != npdt and dest.dtype.kind != npdt.kind):
+            return False
+        d = self._layout
+        if d[0] != 3:
+            return False
+        f, m = self._f, self._f._m
+        raw_view = dest.view(np.dtype(f"V{esz}")) if esz > 1 else dest.view(np.uint8)
+        if d[1] == 1:                                   # contiguous
+            addr, size = struct.unpack_from("<QQ", d, 2)
+            if addr == UNDEF:
+                dest.view(np.uint8).fill(0)
+            else:
+                np.copyto(dest.view(np.uint8).reshape(-1), np.frombuffer(m, dtype=np.uint8, count=size, offset=f._base + addr))
+            return True
+        if d[1] != 2:
+            return False
+        rank = d[2]
+        btree = struct.unpack_from("<Q", d, 3)[0]
+        cdims = struct.unpack_from(f"<{rank}I", d, 11)
+        if cdims[-1] != esz:
+            raise H5FormatError(f"{self.name}: chunk element size")
+        chunk = cdims[:-1]
+        n_chunks = 1
+        for s, c in zip(shape, chunk):
+            n_chunks *= -(-s // c)
+        if btree == UNDEF:
+            dest.view(np.uint8).fill(0)
+            return True
+        out = raw_view if esz > 1 else dest.view(np.dtype("V1"))
+        written = self._walk_chunks(btree, rank, chunk, esz, out)
+        if written != n_chunks:                         # unallocated chunks hold the fill value: start from zeros
+            dest.view(np.uint8).fill(0)
+            self._walk_chunks(btree, rank, chunk, esz, out)
+        return True
 
     def __getitem__(self, key):
         if self._shape is None:
@@ -573,3 +642,47 @@ class Dataset(_Object):
 
     def __len__(self):
         return self._shape[0]
+
+
+def read_many_direct(datasets, dests) -> List[bool]:
+    """Fill ``dests[i]`` (C-contiguous arrays) from ``datasets[i]`` for a whole batch.  Datasets that are plain
+    chunked numeric arrays of one file and one geometry go to libtimedhip's ``th_h5_read_chunked`` in a single call
+    (B-tree walk, inflate and placement on host threads, no interpreter work per chunk); the rest use
+    ``Dataset.read_direct``.  Returns, per dataset, whether it was filled (False: caller must use ``ds[()]``)."""
+    import ctypes as C
+    done = [False] * len(datasets)
+    groups: Dict[tuple, List[int]] = {}
+    for i, (ds, dest) in enumerate(zip(datasets, dests)):
+        geo = ds.chunked_geometry() if isinstance(ds, Dataset) else None
+        if (geo is not None and tuple(dest.shape) == geo[1] and dest.flags.c_contiguous and dest.dtype.itemsize == geo[3]
+                and dest.flags.writeable):
+            groups.setdefault((id(ds._f),) + geo[1:], []).append(i)
+    if groups:
+        try:
+            from . import _lib
+            lib = _lib.load()
+        except Exception:          # no native library: the pure-Python chunk walk below still works
+            lib = None
+        for key, idx in groups.items():
+            if lib is None:
+                break
+            f = datasets[idx[0]]._f
+            _fid, shape, chunk, esz, filters = key
+            whole = np.frombuffer(f._m, dtype=np.uint8)
+            try:
+                n, rank = len(idx), len(shape)
+                addrs = (C.c_int64 * n)(*[datasets[i].chunked_geometry()[0] if datasets[i].chunked_geometry()[0] != UNDEF else -1
+                                          for i in idx])
+                ptrs = (C.c_void_p * n)(*[dests[i].ctypes.data for i in idx])
+                rc = lib.th_h5_read_chunked(whole.ctypes.data_as(C.c_void_p), whole.size, f._base, n, addrs, ptrs, rank,
+                                            (C.c_int64 * rank)(*shape), (C.c_int64 * rank)(*chunk), esz, len(filters),
+                                            (C.c_int * max(1, len(filters)))(*filters), 0)
+            finally:
+                del whole                      # release the exported buffer so the file can be closed
+            if rc == 0:
+                for i in idx:
+                    done[i] = True
+    for i, (ds, dest) in enumerate(zip(datasets, dests)):
+        if not done[i] and isinstance(ds, Dataset):
+            done[i] = ds.read_direct(dest)
+    return done
