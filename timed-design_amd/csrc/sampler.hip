@@ -15,6 +15,9 @@
 // np.random.seed(seed); np.random.rand(...) exactly (init_genrand + genrand_res53).
 #include "common.h"
 
+#include <algorithm>
+#include <mutex>
+
 #include <rocrand/rocrand_kernel.h>
 
 namespace {
@@ -150,12 +153,31 @@ __global__ void __launch_bounds__(256) k_mt19937_uniforms(uint32_t seed, uint64_
     }
 }
 
+// Device scratch for one call.  hipMalloc/hipFree cost more than the kernels of a config-5 sized call (a few
+// hundred microseconds each vs ~10 us), so the buffers are kept in a small grow-only pool: one cached allocation per
+// DevBuf declared in sampler_run (claimed in declaration order), guarded by a mutex that serialises sampler calls.
+struct Pool {
+    std::mutex mu;
+    struct Slot { void* p = nullptr; size_t cap = 0; int dev = -1; } slot[16];
+    int next = 0;
+};
+Pool g_pool;
+
 struct DevBuf {
     void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    Pool::Slot* s = nullptr;
     int alloc(size_t bytes) {
-        hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
-        if (e != hipSuccess) { th_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return TH_ENOMEM; }
+        if (!s) s = &g_pool.slot[g_pool.next++ % 16];
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (s->cap < bytes || s->dev != dev || !s->p) {
+            if (s->p) { (void)hipSetDevice(s->dev); (void)hipFree(s->p); (void)hipSetDevice(dev); s->p = nullptr; s->cap = 0; }
+            const size_t want = std::max<size_t>(bytes, 1 << 16);
+            hipError_t e = hipMalloc(&s->p, want);
+            if (e != hipSuccess) { s->p = nullptr; th_set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); return TH_ENOMEM; }
+            s->cap = want; s->dev = dev;
+        }
+        p = s->p;
         return TH_OK;
     }
 };
@@ -171,6 +193,8 @@ int sampler_run(int device, const double* h_probs, int64_t n_res, int n_cls, int
     if (rng_mode < TH_RNG_HOST || rng_mode > TH_RNG_MT19937) TH_FAIL(TH_EINVAL, "th_sample: rng_mode %d", rng_mode);
     if (rng_mode == TH_RNG_MT19937 && seed > 0xffffffffULL) TH_FAIL(TH_EINVAL, "th_sample: MT19937 seed must fit 32 bits");
     if (h_letters && !cat_letters) TH_FAIL(TH_EINVAL, "th_sample: letters_out needs cat_letters");
+    std::lock_guard<std::mutex> pool_lock(g_pool.mu);
+    g_pool.next = 0;
     HIP_TRY(hipSetDevice(device));
     const int64_t total = n_samples * n_res;
     const size_t pbytes = (size_t)n_res * n_cls * sizeof(double);
