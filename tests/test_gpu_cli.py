@@ -168,3 +168,41 @@ def test_predict_from_frame_pack_equals_hdf5(gpu, tmp_path):
                                          dataset_map_path=b / "datasetmap.txt", path_to_output=b)
     for fn in ("keras_tiny.csv", "keras_tiny.fasta", "keras_tiny.txt", "dataset.fasta", "datasetmap.txt", "encoded_labels.csv"):
         assert (a / fn).read_bytes() == (b / fn).read_bytes(), fn
+
+
+def test_predict_rotamer_mode_end_to_end(gpu, tmp_path):
+    """predict_rotamers=True (reference predict.py:90,143-151): the raw 338-way matrix goes to <model>_rot.csv at full
+    precision, <model>.csv holds the one-hot residue of the arg-max rotamer (float16 text), the FASTA is read off the
+    rotamer matrix; a 20-class model is refused."""
+    import warnings
+    from pathlib import Path
+    import predict
+    from design_utils import utils
+    from timed_hip import pack, synth, textio
+    data_path = os.path.join(G, "frames_tiny.hdf5")
+    cfg, weights = synth.timed_synth(338, widths=(8, 16), side=7, in_channels=5, seed=4, bias_std=0.1)
+    mp = tmp_path / "ROT.pack"
+    mp.write_bytes(pack.keras_to_pack(cfg, weights))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = predict.load_dataset_and_predict([mp], data_path, batch_size=9, predict_rotamers=True,
+                                               dataset_map_path=tmp_path / "datasetmap.txt", path_to_output=tmp_path)
+        flat, _ = utils.create_flat_dataset_map(data_path)
+    X, _y = utils.load_batch(data_path, flat)
+    want = cnn_oracle.forward(cfg, weights, X)
+    raw = np.loadtxt(tmp_path / "ROT_rot.csv", delimiter=",")
+    assert raw.shape == (26, 338)
+    np.testing.assert_allclose(raw, want, atol=1e-5)
+    assert np.array_equal(raw.astype(np.float32).astype(np.float64), raw)        # full fp32 precision survived the text
+    codec, cats = utils.get_rotamer_codec()
+    onehot = np.loadtxt(tmp_path / "ROT.csv", delimiter=",")
+    assert onehot.shape == (26, 20) and np.array_equal(onehot, np.array([codec[c] for c in raw.argmax(1)]))
+    fasta = (tmp_path / "ROT.fasta").read_text().split("\n")
+    res_to_r = dict(zip(["ALA", "CYS", "ASP", "GLU", "PHE", "GLY", "HIS", "ILE", "LYS", "LEU", "MET", "ASN", "PRO", "GLN", "ARG", "SER",
+                         "THR", "VAL", "TRP", "TYR"], "ACDEFGHIKLMNPQRSTVWY"))
+    seq16 = textio.loadtxt_f16(tmp_path / "ROT_rot.csv").argmax(1)                 # the reference re-reads the file as float16
+    assert fasta[1] + fasta[3] + fasta[5] == "".join(res_to_r[cats[i].split("_")[0]] for i in seq16)
+    assert res[1] is not None and set(res[1]) == {"1ubqA", "2xyz_0A", "2xyz_0B"}
+    with pytest.raises(ValueError):
+        predict.load_dataset_and_predict([Path(os.path.join(G, "keras_tiny.h5"))], data_path, batch_size=9, predict_rotamers=True,
+                                         dataset_map_path=tmp_path / "datasetmap.txt", path_to_output=tmp_path)
