@@ -81,7 +81,6 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
     float4* A4 = smem;
     float4* B4 = A4 + (size_t)nvox * CS4;
     const int bslab4 = BN * CS4;  // one tap's weights
-    const int nbslabs = BRES ? a.ntaps : 2;
     int* rowvox = (int*)(reinterpret_cast<char*>(smem) + a.tab_off);
     int* rowout = rowvox + a.nrows;
     int* tapoff = rowout + (POOL ? a.nrows / 8 : a.nrows);  // staged-voxel offset of every tap
