@@ -93,7 +93,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=100_000, help="frames per GPU per step (BASELINE config: 100k)")
-    ap.add_argument("--topology", default="timed", choices=["timed", "timed_rotamer", "densecpd"])
+    ap.add_argument("--topology", default="timed", choices=["timed", "timed_rotamer", "densecpd", "prodconn"])
     ap.add_argument("--chunk", type=int, default=4096, help="frames per launch (activation arenas are sized for this many frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP events (roofline omitted)")

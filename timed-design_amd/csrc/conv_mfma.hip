@@ -981,6 +981,8 @@ const CfgDesc kCfgs[] = {
     {4, 4, 2, 2, 16, 2},  // 8: 4-wave workgroups (two per CU: one's staging hides under the other's MFMAs)
     {4, 4, 2, 4, 16, 2},  // 9
     {4, 2, 1, 1, 16, 2},  // 10
+    {8, 2, 1, 1, 8, 2},   // 11: Cin<=8 with weights streamed (large kernels on the input, e.g. 5^3: 125 taps do not fit LDS)
+    {8, 2, 2, 2, 8, 2},   // 12: same, BN=64
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -992,6 +994,7 @@ const ConvKernel kKernels[kNumCfgs][3] = {
     CFG_ROW(8, 2, 1, 1, 16, 0), CFG_ROW(8, 2, 2, 2, 8, 1),
     CFG_ROW(8, 4, 2, 2, 16, 2), CFG_ROW(8, 4, 2, 4, 16, 2), CFG_ROW(8, 2, 1, 1, 16, 2),
     CFG_ROW(4, 4, 2, 2, 16, 2), CFG_ROW(4, 4, 2, 4, 16, 2), CFG_ROW(4, 2, 1, 1, 16, 2),
+    CFG_ROW(8, 2, 1, 1, 8, 2), CFG_ROW(8, 2, 2, 2, 8, 2),
 };
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -1162,7 +1165,10 @@ bool conv_mfma_plan(const TView& in, const TView& oc, const ConvGeom& g, int Cin
         if (!stream8 && plan_with_cfg(cfg + 7, kLdsLimit / 2, true, in, oc, g, Cin, Cout, pool, p)) return true;
         cfg += 4;
     }
-    return plan_with_cfg(cfg, kLdsLimit, false, in, oc, g, Cin, Cout, pool, p);
+    if (plan_with_cfg(cfg, kLdsLimit, false, in, oc, g, Cin, Cout, pool, p)) return true;
+    // Cin <= 8 with a kernel too large for LDS-resident weights: stream them
+    if (cfg == 0 || cfg == 4) return plan_with_cfg(cfg == 0 ? 11 : 12, kLdsLimit, false, in, oc, g, Cin, Cout, pool, p);
+    return false;
 }
 
 void conv_mfma_pack_weights(const ConvMfmaPlan& p, const ConvGeom& g, int Cin, int Cout, const float* w, float* dst) {
