@@ -179,6 +179,23 @@ def test_first_block_pools_before_a_monotone_epilogue_only(gpu, monkeypatch, neg
         np.testing.assert_allclose(got, ref, rtol=0, atol=2e-6 * max(1.0, float(np.abs(ref).max())))
 
 
+@pytest.mark.parametrize("shape,cin,cout,k,stride,padding", [
+    ((9, 9, 9), 16, 20, 3, 2, "same"), ((10, 9, 8), 24, 48, 3, 2, "valid"), ((11, 11, 11), 6, 32, 3, 2, "same"),
+    ((12, 10, 9), 5, 40, 5, 2, "same"), ((9, 9, 9), 32, 64, 3, 3, "same"), ((8, 8, 8), 48, 16, 1, 2, "same"),
+])
+def test_strided_convolutions_on_the_brick_kernel(gpu, shape, cin, cout, k, stride, padding):
+    """stride > 1 (ProDCoNN-style down-sampling convolutions): the brick kernel's row table carries the stride, the
+    staged brick covers (n-1)*s + k input planes; Keras 'same' padding with a stride is asymmetric."""
+    def build(b, x):
+        return b.elu(b.conv3d(x, cout, k, strides=stride, padding=padding))
+
+    cfg, weights = _net(shape, cin, build, seed=41)
+    frames = _frames(5, shape, cin, 9)
+    labels = _check(cfg, weights, frames)
+    assert any("conv_mfma" in l for l in labels), labels
+    _check(cfg, weights, frames, chunk=2)
+
+
 def test_branches_add_and_strided_fallback(gpu):
     def build(b, x):
         a = b.conv3d(x, 16, 3, padding="same", activation="relu")

@@ -52,6 +52,7 @@ struct ConvMfmaArgs {
     float* out; int64_t out_fs; int out_cs, out_coff, Ho, Wo;
     int64_t nframes;
     const float* wx;   // k_conv_n16 XC > 0: weights of output channels 16..16+XC-1, [chunk][tap][q][c][4]
+    int sd, sh, sw;    // convolution stride (k_conv_mfma only; 1 elsewhere)
 };
 
 template <int WAVES, int TM, int TN, int NT, int CI, int BRES, int POOL>
@@ -93,7 +94,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
         const int xl = v % a.Wp; int t = v / a.Wp;
         const int yl = t % a.Hp; t /= a.Hp;
         const int zl = t % a.Zp; const int f = t / a.Zp;
-        const int zi = z0 + zl - a.pz, yi = yl - a.py, xi = xl - a.px;
+        const int zi = z0 * a.sd + zl - a.pz, yi = yl - a.py, xi = xl - a.px;   // staged plane zl of the brick = input plane z0*sd + zl - pz
         const bool ok = (f0 + f) < a.nframes && zi >= 0 && zi < a.Din && yi >= 0 && yi < a.Hin && xi >= 0 && xi < a.Win;
         voxsrc[v] = ok ? f * (int)a.in_fs + ((zi * a.Hin + yi) * a.Win + xi) * a.in_cs : -1;
     }
@@ -137,7 +138,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
                 }
                 if (fok && rok) {
                     const int zl = q / hw, rem = q - zl * hw, y = rem / a.Wc, x = rem - y * a.Wc;
-                    vox = ((f * a.Zp + zl) * a.Hp + y) * a.Wp + x;
+                    vox = ((f * a.Zp + zl * a.sd) * a.Hp + y * a.sh) * a.Wp + x * a.sw;   // window origin of output voxel (zl, y, x)
                     oo = f * (int)a.out_fs + (((z0 + zl) * a.Ho + y) * a.Wo + x) * a.out_cs;
                 }
                 rowout[r] = oo;
@@ -1015,8 +1016,8 @@ static bool plan_with_cfg(int cfg, size_t lds_limit, bool whole_frames_only, con
     p->Dc = pool ? (oc.D / 2) * 2 : oc.D;
     p->Hc = pool ? (oc.H / 2) * 2 : oc.H;
     p->Wc = pool ? (oc.W / 2) * 2 : oc.W;
-    p->Hp = p->Hc + g.kh - 1;
-    p->Wp = p->Wc + g.kw - 1;
+    p->Hp = (p->Hc - 1) * g.sh + g.kh;   // staged (haloed) extent: windows of Hc outputs at stride sh
+    p->Wp = (p->Wc - 1) * g.sw + g.kw;
     const int ntaps = g.kd * g.kh * g.kw;
     const size_t bbytes = c.BRES == 2 ? 0 : (size_t)(c.BRES ? ntaps : 2) * p->BN * p->CS * 4;
     auto rows_for = [&](int zb) {
@@ -1024,12 +1025,12 @@ static bool plan_with_cfg(int cfg, size_t lds_limit, bool whole_frames_only, con
         return round_up(r, 32);
     };
     auto tab_bytes = [&](int fb, int zb) {
-        const size_t nvox = (size_t)fb * (zb + g.kd - 1) * p->Hp * p->Wp;
+        const size_t nvox = (size_t)fb * ((zb - 1) * g.sd + g.kd) * p->Hp * p->Wp;
         const int nrows = fb * rows_for(zb);
         return (size_t)nrows * 4 + (size_t)(pool ? nrows / 8 : nrows) * 4 + (size_t)ntaps * 4 + nvox * 4 + (size_t)(nrows / 32) * 4;
     };
     auto lds_for = [&](int fb, int zb) {
-        const size_t nvox = (size_t)fb * (zb + g.kd - 1) * p->Hp * p->Wp;
+        const size_t nvox = (size_t)fb * ((zb - 1) * g.sd + g.kd) * p->Hp * p->Wp;
         return std::max(nvox * p->CS * 4 + bbytes, (size_t)c.WAVES * 32 * 33 * 4) + tab_bytes(fb, zb);
     };
     const int max_mt = c.WAVES * c.TM * c.TN / c.NT;  // m-tiles one round covers
@@ -1054,14 +1055,14 @@ static bool plan_with_cfg(int cfg, size_t lds_limit, bool whole_frames_only, con
     p->FB = FB;
     p->ZB = ZB;
     p->nzb = (p->Dc + ZB - 1) / ZB;
-    p->Zp = ZB + g.kd - 1;
+    p->Zp = (ZB - 1) * g.sd + g.kd;
     p->rows_pf = rows_for(ZB);
     p->lds_bytes = lds_for(FB, ZB);
     p->tab_off = p->lds_bytes - tab_bytes(FB, ZB);
     p->wpk_floats = (size_t)p->nnb * p->nchunks * ntaps * p->BN * (c.BRES == 2 ? c.CI : p->CS);
     const double rows_exec = (double)p->nzb * p->rows_pf;  // per frame
     p->exec_flops = 2.0 * rows_exec * (double)(p->nnb * p->BN) * (double)(p->nchunks * c.CI) * ntaps;
-    if (p->pool == 0 && c.BRES == 2 && c.CI == 16 && g.kd <= 8) {
+    if (p->pool == 0 && c.BRES == 2 && c.CI == 16 && g.kd <= 8 && g.sd == 1 && g.sh == 1 && g.sw == 1) {
         // z-major rows: m-tiles whose rows all read the zero halo for a dz skip that dz's taps
         // (same rule as the kernel's tskip table); exec_flops counts what is actually issued
         const int n_mtiles = FB * p->rows_pf / 32, fhw = FB * p->Hc * p->Wc;
@@ -1139,7 +1140,9 @@ bool plan_n16(int variant, size_t lds_limit, const TView& in, const TView& oc, c
 }  // namespace
 
 bool conv_mfma_plan(const TView& in, const TView& oc, const ConvGeom& g, int Cin, int Cout, int pool, ConvMfmaPlan* p) {
-    if (g.sd != 1 || g.sh != 1 || g.sw != 1 || g.dd != 1 || g.dh != 1 || g.dw != 1) return false;
+    if (g.dd != 1 || g.dh != 1 || g.dw != 1) return false;
+    const bool strided = g.sd != 1 || g.sh != 1 || g.sw != 1;
+    if (strided && pool) return false;   // strided convolutions run on the brick kernel (row table carries the stride), unpooled
     if (pool && (oc.D < 2 || oc.H < 2 || oc.W < 2)) return false;
     int cfg;
     if (Cin <= 8) cfg = Cout <= 32 ? 0 : (Cout <= 64 ? 4 : 2);
@@ -1151,13 +1154,13 @@ bool conv_mfma_plan(const TView& in, const TView& oc, const ConvGeom& g, int Cin
     const bool dbuf = mode && std::strcmp(mode, "dbuf") == 0;
     const bool stream8 = mode && std::strcmp(mode, "stream8") == 0;
     const bool no16 = mode && std::strcmp(mode, "no16") == 0;
-    if (!dbuf && !stream8 && Cout <= 16 && Cin > 8 && g.kd == 3 && g.kh == 3 && g.kw == 3 && !no16) {
+    if (!dbuf && !stream8 && !strided && Cout <= 16 && Cin > 8 && g.kd == 3 && g.kh == 3 && g.kw == 3 && !no16) {
         if (plan_n16(1, kLdsLimit / 2, in, oc, g, Cin, Cout, pool, p)) return true;   // two 4-wave workgroups per CU
         if (plan_n16(0, kLdsLimit, in, oc, g, Cin, Cout, pool, p)) return true;       // one 8-wave workgroup
     }
     // Cout 17..20 (a 20-class head): 16 channels on the matrix pipe + up to 4 on the VALU pipe underneath,
     // instead of a 32-wide tile with 12 zero columns
-    if (!dbuf && !stream8 && Cout > 16 && Cout <= 20 && Cin > 8 && pool == 0 && g.kd == 3 && g.kh == 3 && g.kw == 3 && !no16 &&
+    if (!dbuf && !stream8 && !strided && Cout > 16 && Cout <= 20 && Cin > 8 && pool == 0 && g.kd == 3 && g.kh == 3 && g.kw == 3 && !no16 &&
         !getenv("TH_CONV_NOXC")) {
         if (plan_n16(2, kLdsLimit / 2, in, oc, g, Cin, Cout, pool, p)) return true;
     }
@@ -1245,12 +1248,13 @@ int launch_conv_mfma(hipStream_t s, int64_t n, const ConvMfmaPlan& p, TView in, 
     a.Din = in.D; a.Hin = in.H; a.Win = in.W; a.Cin = Cin;
     a.vec_ok = (in.cs % 4 == 0 && in.coff % 4 == 0 && in.fs % 4 == 0 && ((uintptr_t)in.p % 16) == 0) ? 1 : 0;
     a.kd = g.kd; a.kh = g.kh; a.kw = g.kw; a.pz = g.pz; a.py = g.py; a.px = g.px; a.ntaps = g.kd * g.kh * g.kw;
+    a.sd = g.sd; a.sh = g.sh; a.sw = g.sw;
     a.Dc = p.Dc; a.Hc = p.Hc; a.Wc = p.Wc;
     a.FB = p.FB; a.ZB = p.ZB; a.nzb = p.nzb; a.Zp = p.Zp; a.Hp = p.Hp; a.Wp = p.Wp;
     a.rows_pf = p.rows_pf; a.nrows = p.FB * p.rows_pf; a.n_mtiles = a.nrows / 32;
     a.CS = p.CS; a.nchunks = p.nchunks; a.nnb = p.nnb;
     a.tab_off = (int)p.tab_off;
-    { static const bool nozm = getenv("TH_CONV_NOZMAJOR") != nullptr; a.zmajor = (!nozm && !n16 && p.pool == 0 && p.bres == 2 && c.CI == 16) ? 1 : 0; }
+    { static const bool nozm = getenv("TH_CONV_NOZMAJOR") != nullptr; a.zmajor = (!nozm && !n16 && p.pool == 0 && p.bres == 2 && c.CI == 16 && g.sd == 1 && g.sh == 1 && g.sw == 1) ? 1 : 0; }
     { static const int dbg = getenv("TH_CONV_DBG") ? atoi(getenv("TH_CONV_DBG")) : 0; a.dbg = dbg; }
     a.wpk = wpk; a.Cout = Cout; a.bias = bias; a.pre = pre; a.post = post;
     a.wx = n16 ? wpk + (size_t)p.nchunks * 27 * 256 : wpk;
