@@ -206,3 +206,37 @@ def test_predict_rotamer_mode_end_to_end(gpu, tmp_path):
     with pytest.raises(ValueError):
         predict.load_dataset_and_predict([Path(os.path.join(G, "keras_tiny.h5"))], data_path, batch_size=9, predict_rotamers=True,
                                          dataset_map_path=tmp_path / "datasetmap.txt", path_to_output=tmp_path)
+
+
+def test_grouping_batches_per_gpu_call_keeps_every_output_byte(gpu, tmp_path):
+    """predict.py hands several reference batches to the GPU at once (frames_per_call): the per-batch appends
+    concatenate to the same files, whatever the batch size and wherever a resume starts."""
+    import warnings
+    from pathlib import Path
+    import predict
+    model_path = Path(os.path.join(G, "keras_tiny.h5"))
+    src = os.path.join(G, "frames_tiny.hdf5")
+    outs = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for name, bs, fpc in (("one_by_one", 5, 5), ("grouped", 5, 1024), ("big", 26, 1024), ("odd", 3, 7)):
+            d = tmp_path / name
+            d.mkdir()
+            predict.load_dataset_and_predict([model_path], src, batch_size=bs, frames_per_call=fpc,
+                                             dataset_map_path=d / "datasetmap.txt", path_to_output=d)
+            outs[name] = d
+        # resume from batch 3 of 5-frame batches in a directory that already holds batches 0..2
+        r = tmp_path / "resume"
+        r.mkdir()
+        predict.load_dataset_and_predict([model_path], src, batch_size=5, dataset_map_path=r / "datasetmap.txt", path_to_output=r)
+        full = (r / "keras_tiny.csv").read_text()
+        (r / "keras_tiny.csv").write_text("".join(full.splitlines(True)[:15]))
+        lab = (r / "encoded_labels.csv").read_text()
+        (r / "encoded_labels.csv").write_text("".join(lab.splitlines(True)[:15]))
+        predict.load_dataset_and_predict([model_path], src, batch_size=5, start_batch=3, dataset_map_path=r / "datasetmap.txt",
+                                         path_to_output=r)
+        outs["resume"] = r
+    ref = outs["one_by_one"]
+    for name, d in outs.items():
+        for fn in ("keras_tiny.csv", "keras_tiny.fasta", "keras_tiny.txt", "dataset.fasta", "datasetmap.txt", "encoded_labels.csv"):
+            assert (d / fn).read_bytes() == (ref / fn).read_bytes(), (name, fn)

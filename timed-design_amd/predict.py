@@ -49,11 +49,15 @@ def load_dataset_and_predict(
     is_consensus: bool = False,
     path_to_output: Path = Path.cwd(),
     device: int = 0,
+    frames_per_call: int = 1024,
 ) -> (np.ndarray, np.ndarray, np.ndarray, np.ndarray, np.ndarray, np.ndarray):
     """reference predict.py:28-194 — same parameters and return tuple
     (flat_dataset_map, pdb_to_sequence, pdb_to_probability, pdb_to_real_sequence, pdb_to_consensus,
     pdb_to_consensus_prob).  ``start_batch`` keeps the reference's resume semantics: batches before it
-    are skipped and outputs are appended."""
+    are skipped and outputs are appended.  ``batch_size`` keeps its meaning for resuming, but consecutive
+    batches are handed to the GPU together (about ``frames_per_call`` frames per launch): the per-batch appends
+    of the reference concatenate to exactly the same files, and the CLI default of 12 frames per batch no longer
+    costs one 1.7 ms launch sequence per 12 frames."""
     path_to_output = Path(path_to_output)
     n_classes = 338 if predict_rotamers else 20
     print(f"Running model on {n_classes} classes. Rotamer Mode is {predict_rotamers}")
@@ -74,8 +78,9 @@ def load_dataset_and_predict(
             raise ValueError(f"{m}: model has {frame_model.n_classes} outputs but predict_rotamers={predict_rotamers} "
                              f"expects {n_classes}")
         model_out = path_to_output / (f"{model_name}_rot.csv" if predict_rotamers else f"{model_name}.csv")
-        for index in range(start_batch, n_batches):
-            current_batch_map = flat_dataset_map[index * batch_size: (index + 1) * batch_size]
+        group = max(1, int(frames_per_call) // max(1, batch_size))    # reference batches per GPU call
+        for index in range(start_batch, n_batches, group):
+            current_batch_map = flat_dataset_map[index * batch_size: (index + group) * batch_size]
             X_batch, y_true_batch = load_batch(dataset_path, current_batch_map)
             y_pred_batch = frame_model.predict(X_batch)
             if predict_rotamers:
