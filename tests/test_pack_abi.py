@@ -81,3 +81,31 @@ def test_no_gpu_is_an_error_not_a_fallback(lib):
     cfg, w = synth.timed_synth(20, widths=(4,), side=5, in_channels=2)
     with pytest.raises(_lib.TimedHipError):
         engine.HipFrameModel.from_keras(cfg, w)
+
+
+def test_per_channel_ops_and_pooling_are_pushed_through_branch_concats():
+    """keras_config.push_through_concat: BN / activation / pooling that is the only consumer of a Concatenate of
+    convolution branches is applied per branch with the BatchNorm vectors sliced (exact rewrite, lets the engine
+    fuse them into each branch's convolution); DenseNet-style concatenations are left alone."""
+    from timed_hip import keras_config as kc, synth
+    cfg, w = synth.TOPOLOGIES["prodconn"]()
+    layers = kc.parse_keras_model(cfg, w)
+    names = [l.name for l in layers]
+    assert "batch_normalization__b0" in names and "batch_normalization__b1" in names
+    assert "max_pooling3d__b0" in names and "max_pooling3d__b1" in names
+    by = {l.name: l for l in layers}
+    bn_all = [np.asarray(a, np.float32) for a in w["batch_normalization"]]          # gamma, beta, mean, var over 32 channels
+    for k, (lo, hi) in enumerate(((0, 16), (16, 32))):
+        b = by[f"batch_normalization__b{k}"]
+        assert b.ip["c"] == 16 and b.out_shape[-1] == 16
+        for key, full in zip(("gamma", "beta", "mean", "var"), bn_all):
+            assert np.array_equal(b.weights[key], full[lo:hi])
+    merged = by["max_pooling3d"]                       # the concat now carries the name downstream layers refer to
+    assert merged.op == kc.OP_CONCAT and merged.inputs == ["max_pooling3d__b0", "max_pooling3d__b1"]
+    assert merged.out_shape == (10, 10, 10, 32)
+    assert not any(l.op == kc.OP_CONCAT and l.name == "concatenate" for l in layers)
+    # DenseCPD: every concat has several consumers or a concat branch -> untouched
+    cfg, w = synth.TOPOLOGIES["densecpd"]()
+    layers = kc.parse_keras_model(cfg, w)
+    assert not any("__b" in l.name for l in layers)
+    assert sum(l.op == kc.OP_CONCAT for l in layers) == 12

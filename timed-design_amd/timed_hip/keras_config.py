@@ -293,6 +293,57 @@ def parse_keras_model(model_config, weights: Dict[str, Sequence[np.ndarray]]) ->
     layers = layers[: idx + 1]
     if sum(1 for l in layers if l.op == OP_INPUT) != 1:
         raise UnsupportedLayer("exactly one model input is supported")
+    return push_through_concat(layers)
+
+
+def push_through_concat(layers: List[Layer]) -> List[Layer]:
+    """Graph rewrite (exact): a per-channel op or a pooling layer that is the ONLY consumer of a channel
+    Concatenate is applied to each branch instead — ``BN(concat(a, b)) == concat(BN_a(a), BN_b(b))`` with the
+    BatchNorm vectors sliced, likewise activations and Max/AveragePooling.  The engine can then fuse the op into
+    each branch's convolution (epilogue / pooled store at a channel offset) instead of running separate
+    elementwise and pooling kernels over the concatenated tensor (Inception/ProDCoNN-style parallel branches).
+    Only done when every branch ends in a convolution chain, so DenseNet-style concatenations (a branch is itself
+    a concatenation, and the concat has several consumers) are left alone."""
+    by_name = {l.name: l for l in layers}
+
+    def ends_in_conv(name: str) -> bool:
+        l = by_name[name]
+        while l.op in (OP_BN, OP_ACT) and len(l.inputs) == 1:
+            l = by_name[l.inputs[0]]
+        return l.op == OP_CONV3D
+
+    changed = True
+    while changed:
+        changed = False
+        for ci, c in enumerate(layers):
+            if c.op != OP_CONCAT or ci == len(layers) - 1:
+                continue
+            users = [l for l in layers if c.name in l.inputs]
+            if len(users) != 1:
+                continue
+            x = users[0]
+            if x.inputs != [c.name] or x.op not in (OP_BN, OP_ACT, OP_MAXPOOL, OP_AVGPOOL):
+                continue
+            if x.op == OP_ACT and x.ip.get("act") == ACT_SOFTMAX:
+                continue
+            if not all(ends_in_conv(b) for b in c.inputs) or len(set(c.inputs)) != len(c.inputs):
+                continue
+            xi_list, off = [], 0
+            for k, b in enumerate(c.inputs):
+                cb = by_name[b].out_shape[-1]
+                ws = {kk: np.ascontiguousarray(v[off:off + cb]) for kk, v in x.weights.items()}
+                ip = dict(x.ip)
+                if x.op == OP_BN:
+                    ip["c"] = cb
+                xi_list.append(Layer(name=f"{x.name}__b{k}", op=x.op, inputs=[b], ip=ip, fp=dict(x.fp), weights=ws,
+                                     out_shape=tuple(x.out_shape[:-1]) + (cb,)))
+                off += cb
+            merged = Layer(name=x.name, op=OP_CONCAT, inputs=[l.name for l in xi_list], out_shape=tuple(x.out_shape))
+            xpos = layers.index(x)
+            layers = layers[:ci] + layers[ci + 1:xpos] + xi_list + [merged] + layers[xpos + 1:]
+            by_name = {l.name: l for l in layers}
+            changed = True
+            break
     return layers
 
 
