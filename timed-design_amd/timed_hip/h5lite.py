@@ -143,6 +143,7 @@ class File:
             raise H5FormatError(f"{path}: empty file")
         self.filename = str(path)
         self._gheap: Dict[int, Dict[int, bytes]] = {}
+        self._groups: Dict[int, "Group"] = {}
         base = self._find_superblock()
         self._base = base
         m = self._m
@@ -433,9 +434,17 @@ class Group(_Object):
             if part not in links:
                 raise KeyError(f"{name!r} not found in {self.name}")
             addr = links[part]
+            cached = self._f._groups.get(addr)     # groups are reused: their link tables are parsed once per file
+            if cached is not None:
+                obj = cached
+                continue
             child_name = (obj.name.rstrip("/") + "/" + part)
             kinds = {t for t, _f, _d in self._f._messages(addr)}
-            obj = Dataset(self._f, addr, child_name) if 0x08 in kinds else Group(self._f, addr, child_name)
+            if 0x08 in kinds:
+                obj = Dataset(self._f, addr, child_name)
+            else:
+                obj = Group(self._f, addr, child_name)
+                self._f._groups[addr] = obj
         return obj
 
     def items(self):
