@@ -59,6 +59,16 @@ def _random_net(seed):
             a1 = post(b.conv3d(x, c, 3, padding="same"))
             a2 = b.conv3d(x, c, 1, padding="same", activation="relu")
             x = b.add([a1, a2])
+        elif form == 3 and rng.random() < 0.5:   # Inception/ProDCoNN-style: parallel branches, concat, then BN (+ pool)
+            c1, c2 = int(rng.choice([8, 16, 24])), int(rng.choice([8, 16]))
+            a1 = b.conv3d(x, c1, 3, padding="same", activation="relu")
+            a2 = b.conv3d(x, c2, int(rng.choice([1, 3, 5])) if min(spatial(x)) >= 5 else 3, padding="same", activation="relu")
+            x = b.batchnorm(b.concat([a1, a2]))
+            if min(spatial(x)) >= 4 and rng.random() < 0.6:
+                x = b.maxpool(x, 2)
+            if min(spatial(x)) >= 3 and rng.random() < 0.5:   # strided down-sampling convolution
+                x = b.conv3d(x, int(rng.choice([16, 32, 48])), 3, strides=2, padding=str(rng.choice(["same", "valid"])),
+                             activation="elu")
         else:              # transition: 1x1 conv then pool
             x = b.conv3d(b.relu(b.batchnorm(x)), max(4, b.shapes[x][3] // 2), 1, padding="same", use_bias=False)
             if min(spatial(x)) >= 2:
