@@ -32,6 +32,7 @@ extern "C" {
 #define TH_EUNSUP (-4)   /* layer/option outside the supported op set        */
 #define TH_ENOMEM (-5)
 #define TH_ECOMM (-6)    /* RCCL failure / librccl.so not loadable           */
+#define TH_EBUSY (-7)    /* every async ticket of the model is in flight     */
 
 /* element types accepted for frames (what load_batch can hand to Model.predict,
  * design_utils/utils.py:518-521: float64 when voxels_as_gaussian else bool) */
@@ -77,6 +78,22 @@ int th_model_set_chunk(th_model* m, int frames_per_chunk);
 /* ---- forward: replaces frame_model.predict(X_batch) — predict.py:142 --------------------- */
 /* host frames [n,D,H,W,C] of `dtype` -> host probs_out [n,n_classes] fp32 (rows sum to 1) */
 int th_predict(th_model* m, const void* frames, int dtype, int64_t n, float* probs_out, unsigned flags);
+/* The same call split in two so that the caller's loop (the per-batch loop of predict.py:125-155, whose load_batch
+ * — design_utils/utils.py:487-530 — re-opens the dataset and gathers the next batch on the host) overlaps with the GPU:
+ * th_predict_async queues host->device copy, kernels and the device->host copy of the probabilities and returns a
+ * ticket; th_predict_wait blocks until that batch is complete and only then writes probs_out.  Up to 4 tickets per
+ * model may be in flight (TH_EBUSY beyond that); they complete in submission order.  `frames` must stay valid and
+ * unmodified until the matching th_predict_wait returns.  Frames in page-locked memory (th_host_alloc /
+ * th_host_register) are copied by the DMA engine without blocking the caller; with pageable memory the copy of a piece
+ * blocks the caller (the kernels of earlier pieces and tickets still run underneath it).  th_predict ==
+ * th_predict_async + th_predict_wait. */
+int th_predict_async(th_model* m, const void* frames, int dtype, int64_t n, float* probs_out, unsigned flags, int* ticket);
+int th_predict_wait(th_model* m, int ticket);
+/* page-locked host memory for frame batches (what load_batch fills): allocate, or pin an existing range in place */
+int th_host_alloc(size_t bytes, void** out);
+int th_host_free(void* p);
+int th_host_register(void* p, size_t bytes);
+int th_host_unregister(void* p);
 /* same with frames and probabilities already resident in this model's device memory */
 int th_predict_device(th_model* m, const void* d_frames, int dtype, int64_t n, float* d_probs, unsigned flags);
 /* copy a layer's output for the first n frames of the LAST chunk run (TH_LOAD_KEEP_ALL / unfused

@@ -52,7 +52,20 @@ def _same_pads(n, k, s, d):
     return total // 2, total - total // 2
 
 
-def _activation(x, name, alpha=1.0):
+def _activation(x, name, alpha=None):
+    # `name` is what Keras serialises for a layer's `activation` argument: a function name (Keras applies that
+    # function's default parameters: elu alpha=1.0, leaky_relu negative_slope=0.2) or a serialized object whose
+    # config carries alpha / negative_slope.  An explicit `alpha` argument (ELU / LeakyReLU / ReLU layers) wins.
+    if isinstance(name, dict):
+        conf = name.get("config") if isinstance(name.get("config"), dict) else {}
+        if alpha is None:
+            alpha = conf.get("negative_slope", conf.get("alpha"))
+        cls = name.get("class_name")
+        name = {"LeakyReLU": "leaky_relu", "ELU": "elu", "ReLU": "relu", "Softmax": "softmax"}.get(cls) or conf.get("name", cls)
+        if name == "leaky_relu" and alpha is None:
+            alpha = 0.3 if cls == "LeakyReLU" else 0.2
+    if alpha is None:
+        alpha = {"leaky_relu": 0.2}.get(name, 1.0)
     if name in (None, "linear"):
         return x
     if name == "relu":

@@ -101,6 +101,7 @@ int th_comm_init(const char id[TH_COMM_ID_BYTES], int n_ranks, int rank, int dev
     if (r != 0) { th_set_error("ncclCommInitRank failed: %s", R->GetErrorString(r)); delete c; return TH_ECOMM; }
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc(&c->d_token, sizeof(float));
+    if (e == hipSuccess) e = hipMemset(c->d_token, 0, sizeof(float));   // the barrier all-reduces it: keep it finite
     if (e != hipSuccess) { th_set_error("th_comm_init: %s", hipGetErrorString(e)); th_comm_free(c); return TH_EHIP; }
     *out = c;
     return TH_OK;
@@ -122,23 +123,35 @@ int th_comm_gather_rows(th_comm* c, const float* d_local, const int64_t* counts,
     if (!R) return TH_ECOMM;
     HIP_TRY(hipSetDevice(c->device));
     if (c->rank == root && !d_out) TH_FAIL(TH_EINVAL, "root needs an output buffer");
-    NCCL_TRY(R->GroupStart());
+    if (counts[c->rank] > 0 && !d_local) TH_FAIL(TH_EINVAL, "rank %d has %lld rows but no local buffer", c->rank, (long long)counts[c->rank]);
+    int64_t my_row = 0;
+    for (int r = 0; r < c->rank; ++r) my_row += counts[r];
+    // the root's own block is a plain device copy: issued before (outside) the RCCL group
+    if (c->rank == root && counts[root] > 0)
+        HIP_TRY(hipMemcpyAsync(d_out + (size_t)my_row * width, d_local, (size_t)counts[root] * width * sizeof(float),
+                               hipMemcpyDeviceToDevice, c->stream));
+    // Inside the group nothing may return early: an error is remembered, the group is always closed, and the first
+    // failure is reported afterwards (an open group would poison every later collective on this thread).
+    int first_err = 0;
+    const char* what = "";
+    int rc = R->GroupStart();
+    if (rc != 0) { th_set_error("ncclGroupStart failed: %s", R->GetErrorString(rc)); return TH_ECOMM; }
     if (c->rank == root) {
         int64_t row = 0;
         for (int r = 0; r < c->n_ranks; ++r) {
-            float* dst = d_out + (size_t)row * width;
-            if (r == root) {
-                if (counts[r] > 0)
-                    HIP_TRY(hipMemcpyAsync(dst, d_local, (size_t)counts[r] * width * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
-            } else if (counts[r] > 0) {
-                NCCL_TRY(R->Recv(dst, (size_t)counts[r] * width, kNcclFloat32, r, c->comm, c->stream));
+            if (r != root && counts[r] > 0 && !first_err) {
+                rc = R->Recv(d_out + (size_t)row * width, (size_t)counts[r] * width, kNcclFloat32, r, c->comm, c->stream);
+                if (rc != 0) { first_err = rc; what = "ncclRecv"; }
             }
             row += counts[r];
         }
     } else if (counts[c->rank] > 0) {
-        NCCL_TRY(R->Send(d_local, (size_t)counts[c->rank] * width, kNcclFloat32, root, c->comm, c->stream));
+        rc = R->Send(d_local, (size_t)counts[c->rank] * width, kNcclFloat32, root, c->comm, c->stream);
+        if (rc != 0) { first_err = rc; what = "ncclSend"; }
     }
-    NCCL_TRY(R->GroupEnd());
+    rc = R->GroupEnd();
+    if (first_err) { th_set_error("%s failed: %s", what, R->GetErrorString(first_err)); return TH_ECOMM; }
+    if (rc != 0) { th_set_error("ncclGroupEnd failed: %s", R->GetErrorString(rc)); return TH_ECOMM; }
     HIP_TRY(hipStreamSynchronize(c->stream));
     return TH_OK;
 }

@@ -111,10 +111,27 @@ struct th_model {
     int dominant_step = -1;
     std::vector<hipEvent_t> ev_pool;
     double algo_flops = 0, exec_flops = 0;
-    void* d_in_stage = nullptr;   // host->device staging for th_predict
-    size_t in_stage_bytes = 0;
-    float* d_out_stage = nullptr;
-    size_t out_stage_floats = 0;
+    // ---- host-buffer pipeline (th_predict / th_predict_async) ----
+    // frames travel host -> device in pieces of <= chunk frames through a ring of kRing device buffers on a copy
+    // stream; piece g's kernels (model stream) wait for its copy, the copy into a ring slot waits for the kernels
+    // that last read it; probabilities return through a pinned host buffer per ticket on a third stream.
+    static constexpr int kRing = 3;
+    static constexpr int kTickets = 4;
+    hipStream_t copy_stream = nullptr, d2h_stream = nullptr;
+    void* d_in_ring[kRing] = {nullptr, nullptr, nullptr};
+    size_t in_ring_bytes = 0;          // capacity of EACH ring buffer
+    hipEvent_t ev_h2d[kRing] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_free[kRing] = {nullptr, nullptr, nullptr};
+    bool ring_used[kRing] = {false, false, false};
+    uint64_t piece_counter = 0;
+    struct Ticket {
+        bool busy = false;
+        hipEvent_t computed = nullptr, done = nullptr;
+        float* d_out = nullptr;  size_t d_out_floats = 0;
+        float* h_out = nullptr;  size_t h_out_floats = 0;   // pinned
+        float* user_out = nullptr;
+        size_t floats = 0;
+    } tickets[kTickets];
     int64_t last_n = 0;
     const void* cur_in = nullptr;  // caller's frames for the chunk in flight (first-layer kernel reads them directly)
     int cur_dtype = TH_F32;
@@ -761,6 +778,16 @@ int run_device(th_model* m, const void* d_frames, int dtype, int64_t n, float* d
 int load_common(th_model* m) {
     HIP_TRY(hipSetDevice(m->device));
     HIP_TRY(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&m->d2h_stream, hipStreamNonBlocking));
+    for (int r = 0; r < th_model::kRing; ++r) {
+        HIP_TRY(hipEventCreateWithFlags(&m->ev_h2d[r], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&m->ev_free[r], hipEventDisableTiming));
+    }
+    for (th_model::Ticket& t : m->tickets) {
+        HIP_TRY(hipEventCreateWithFlags(&t.computed, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&t.done, hipEventDisableTiming));
+    }
     int rc = parse_pack(m);
     if (rc) return rc;
     return plan(m);
@@ -823,8 +850,22 @@ void th_model_free(th_model* m) {
     (void)hipSetDevice(m->device);
     for (float* p : m->dev_allocs) (void)hipFree(p);
     for (Buffer& b : m->bufs) if (b.dev) (void)hipFree(b.dev);
-    if (m->d_in_stage) (void)hipFree(m->d_in_stage);
-    if (m->d_out_stage) (void)hipFree(m->d_out_stage);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    if (m->copy_stream) (void)hipStreamSynchronize(m->copy_stream);
+    if (m->d2h_stream) (void)hipStreamSynchronize(m->d2h_stream);
+    for (int r = 0; r < th_model::kRing; ++r) {
+        if (m->d_in_ring[r]) (void)hipFree(m->d_in_ring[r]);
+        if (m->ev_h2d[r]) (void)hipEventDestroy(m->ev_h2d[r]);
+        if (m->ev_free[r]) (void)hipEventDestroy(m->ev_free[r]);
+    }
+    for (th_model::Ticket& t : m->tickets) {
+        if (t.d_out) (void)hipFree(t.d_out);
+        if (t.h_out) (void)hipHostFree(t.h_out);
+        if (t.computed) (void)hipEventDestroy(t.computed);
+        if (t.done) (void)hipEventDestroy(t.done);
+    }
+    if (m->copy_stream) (void)hipStreamDestroy(m->copy_stream);
+    if (m->d2h_stream) (void)hipStreamDestroy(m->d2h_stream);
     for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
@@ -857,9 +898,17 @@ int th_predict_device(th_model* m, const void* d_frames, int dtype, int64_t n, f
     return run_device(m, d_frames, dtype, n, d_probs, flags);
 }
 
-int th_predict(th_model* m, const void* frames, int dtype, int64_t n, float* probs_out, unsigned flags) {
+// Is `p` page-locked host memory the runtime knows (th_host_alloc / th_host_register / hipHostMalloc)?  Copies from
+// such memory are truly asynchronous; anything else is pageable and the copy call itself blocks the host.
+static bool host_ptr_is_pinned(const void* p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+
+int th_predict_async(th_model* m, const void* frames, int dtype, int64_t n, float* probs_out, unsigned flags, int* ticket) {
     if (n < 0) TH_FAIL(TH_EINVAL, "negative frame count");
-    if (!m || (n > 0 && (!frames || !probs_out))) TH_FAIL(TH_EINVAL, "null argument");
+    if (!m || !ticket || (n > 0 && (!frames || !probs_out))) TH_FAIL(TH_EINVAL, "null argument");
     const size_t esz = dtype_size(dtype);
     if (!esz) TH_FAIL(TH_EINVAL, "unknown frame dtype %d", dtype);
     HIP_TRY(hipSetDevice(m->device));
@@ -868,43 +917,106 @@ int th_predict(th_model* m, const void* frames, int dtype, int64_t n, float* pro
     const bool logits = (flags & TH_PREDICT_LOGITS) != 0;
     if (logits && m->logits_node < 0) TH_FAIL(TH_EINVAL, "model does not end in a Softmax: no logits to return");
     const int width = logits ? m->nodes[m->logits_node].C : m->n_classes;
-    // Host memory of any size streams through two bounded device staging buffers.  Piece k's kernels are
-    // launched asynchronously on the model's (non-blocking) stream, then the blocking copy of piece k+1 is
-    // issued: the copy engine moves the next frames while the CUs work on the current ones.  (A batch that
-    // fits one chunk is NOT cut further: measured, 125-frame pieces under-fill the 256 CUs and lose more
-    // than the overlap wins — 60 k vs 86 k frames/s at predict.py's batch of 500.)
+    int ti = -1;
+    for (int k = 0; k < th_model::kTickets; ++k) if (!m->tickets[k].busy) { ti = k; break; }
+    if (ti < 0) TH_FAIL(TH_EBUSY, "all %d tickets of this model are in flight: call th_predict_wait first", th_model::kTickets);
+    th_model::Ticket& t = m->tickets[ti];
+    // A batch that fits one chunk is NOT cut further: measured, 125-frame pieces under-fill the 256 CUs and lose
+    // more than the overlap wins.  Overlap across small batches comes from submitting the next ticket early.
     const int64_t piece = std::min<int64_t>(m->chunk, std::max<int64_t>(n, 1));
-    const size_t need_in = 2 * frame_bytes * (size_t)piece;
-    if (m->in_stage_bytes < need_in) {
-        if (m->d_in_stage) HIP_TRY(hipFree(m->d_in_stage));
-        m->d_in_stage = nullptr; m->in_stage_bytes = 0;
-        HIP_TRY(hipMalloc(&m->d_in_stage, need_in));
-        m->in_stage_bytes = need_in;
-    }
-    const size_t need_out = 2 * (size_t)width * piece;
-    if (m->out_stage_floats < need_out) {
-        if (m->d_out_stage) HIP_TRY(hipFree(m->d_out_stage));
-        m->d_out_stage = nullptr; m->out_stage_floats = 0;
-        HIP_TRY(hipMalloc(&m->d_out_stage, need_out * sizeof(float)));
-        m->out_stage_floats = need_out;
-    }
-    char* in_stage[2] = {(char*)m->d_in_stage, (char*)m->d_in_stage + frame_bytes * (size_t)piece};
-    float* out_stage[2] = {m->d_out_stage, m->d_out_stage + (size_t)width * piece};
-    if (n > 0)
-        HIP_TRY(hipMemcpy(in_stage[0], frames, (size_t)std::min<int64_t>(piece, n) * frame_bytes, hipMemcpyHostToDevice));
-    int k = 0;
-    for (int64_t off = 0; off < n; off += piece, ++k) {
-        const int64_t cnt = std::min<int64_t>(piece, n - off);
-        int rc = run_device(m, in_stage[k & 1], dtype, cnt, out_stage[k & 1], flags, /*sync=*/false);
-        if (rc) return rc;
-        const int64_t noff = off + piece;
-        if (noff < n)
-            HIP_TRY(hipMemcpy(in_stage[(k + 1) & 1], (const char*)frames + (size_t)noff * frame_bytes,
-                              (size_t)std::min<int64_t>(piece, n - noff) * frame_bytes, hipMemcpyHostToDevice));
+    const size_t need_in = frame_bytes * (size_t)piece;
+    if (m->in_ring_bytes < need_in) {
+        // growing the ring: nothing may still be reading the old buffers
+        HIP_TRY(hipStreamSynchronize(m->copy_stream));
         HIP_TRY(hipStreamSynchronize(m->stream));
-        HIP_TRY(hipMemcpy(probs_out + (size_t)off * width, out_stage[k & 1], (size_t)cnt * width * sizeof(float),
-                          hipMemcpyDeviceToHost));
+        for (int r = 0; r < th_model::kRing; ++r) {
+            if (m->d_in_ring[r]) HIP_TRY(hipFree(m->d_in_ring[r]));
+            m->d_in_ring[r] = nullptr;
+            m->ring_used[r] = false;
+        }
+        m->in_ring_bytes = 0;
+        for (int r = 0; r < th_model::kRing; ++r) HIP_TRY(hipMalloc(&m->d_in_ring[r], need_in));
+        m->in_ring_bytes = need_in;
     }
+    const size_t floats = (size_t)n * width;
+    if (t.d_out_floats < floats) {
+        if (t.d_out) HIP_TRY(hipFree(t.d_out));
+        t.d_out = nullptr; t.d_out_floats = 0;
+        HIP_TRY(hipMalloc(&t.d_out, std::max<size_t>(floats, 1024) * sizeof(float)));
+        t.d_out_floats = std::max<size_t>(floats, 1024);
+    }
+    if (t.h_out_floats < floats) {
+        if (t.h_out) HIP_TRY(hipHostFree(t.h_out));
+        t.h_out = nullptr; t.h_out_floats = 0;
+        HIP_TRY(hipHostMalloc((void**)&t.h_out, std::max<size_t>(floats, 1024) * sizeof(float), hipHostMallocDefault));
+        t.h_out_floats = std::max<size_t>(floats, 1024);
+    }
+    const bool pinned = n > 0 && host_ptr_is_pinned(frames);
+    for (int64_t off = 0; off < n; off += piece) {
+        const int64_t cnt = std::min<int64_t>(piece, n - off);
+        const int r = (int)(m->piece_counter % th_model::kRing);
+        if (m->ring_used[r]) {
+            // the kernels of the piece that used this ring buffer three pieces ago must have finished with it
+            if (pinned) HIP_TRY(hipStreamWaitEvent(m->copy_stream, m->ev_free[r], 0));
+            else HIP_TRY(hipEventSynchronize(m->ev_free[r]));
+        }
+        HIP_TRY(hipMemcpyAsync(m->d_in_ring[r], (const char*)frames + (size_t)off * frame_bytes, (size_t)cnt * frame_bytes,
+                               hipMemcpyHostToDevice, m->copy_stream));
+        HIP_TRY(hipEventRecord(m->ev_h2d[r], m->copy_stream));
+        HIP_TRY(hipStreamWaitEvent(m->stream, m->ev_h2d[r], 0));
+        int rc = run_device(m, m->d_in_ring[r], dtype, cnt, t.d_out + (size_t)off * width, flags, /*sync=*/false);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(m->ev_free[r], m->stream));
+        m->ring_used[r] = true;
+        m->piece_counter++;
+    }
+    HIP_TRY(hipEventRecord(t.computed, m->stream));
+    HIP_TRY(hipStreamWaitEvent(m->d2h_stream, t.computed, 0));
+    if (floats) HIP_TRY(hipMemcpyAsync(t.h_out, t.d_out, floats * sizeof(float), hipMemcpyDeviceToHost, m->d2h_stream));
+    HIP_TRY(hipEventRecord(t.done, m->d2h_stream));
+    t.user_out = probs_out;
+    t.floats = floats;
+    t.busy = true;
+    *ticket = ti;
+    return TH_OK;
+}
+
+int th_predict_wait(th_model* m, int ticket) {
+    if (!m || ticket < 0 || ticket >= th_model::kTickets) TH_FAIL(TH_EINVAL, "bad ticket");
+    th_model::Ticket& t = m->tickets[ticket];
+    if (!t.busy) TH_FAIL(TH_EINVAL, "ticket %d is not in flight", ticket);
+    HIP_TRY(hipSetDevice(m->device));
+    t.busy = false;      // whatever happens below, the slot is returned
+    HIP_TRY(hipEventSynchronize(t.done));
+    if (t.floats) std::memcpy(t.user_out, t.h_out, t.floats * sizeof(float));
+    return TH_OK;
+}
+
+int th_predict(th_model* m, const void* frames, int dtype, int64_t n, float* probs_out, unsigned flags) {
+    int ticket = -1;
+    int rc = th_predict_async(m, frames, dtype, n, probs_out, flags, &ticket);
+    if (rc) return rc;
+    return th_predict_wait(m, ticket);
+}
+
+// ---- page-locked host memory --------------------------------------------------------------------
+int th_host_alloc(size_t bytes, void** out) {
+    if (!out) TH_FAIL(TH_EINVAL, "null argument");
+    HIP_TRY(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return TH_OK;
+}
+int th_host_free(void* p) {
+    if (p) HIP_TRY(hipHostFree(p));
+    return TH_OK;
+}
+int th_host_register(void* p, size_t bytes) {
+    if (!p || !bytes) TH_FAIL(TH_EINVAL, "null argument");
+    HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return TH_OK;
+}
+int th_host_unregister(void* p) {
+    if (!p) TH_FAIL(TH_EINVAL, "null argument");
+    HIP_TRY(hipHostUnregister(p));
     return TH_OK;
 }
 

@@ -16,7 +16,10 @@
 #include "common.h"
 
 #include <algorithm>
+#include <cmath>
+#include <memory>
 #include <mutex>
+#include <vector>
 
 #include <rocrand/rocrand_kernel.h>
 
@@ -47,41 +50,68 @@ __device__ double np_pairwise_sum(const double* a, int n) {
     }
 }
 
-// one thread per residue row: temper, normalise, running sum
-__global__ void k_temper_cumsum(const double* __restrict__ p, int64_t n_res, int n_cls, double t, int force_norm,
-                                double* __restrict__ q, double* __restrict__ c) {
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= n_res) return;
-    const double* pr = p + i * n_cls;
-    double* qr = q + i * n_cls;
-    double* cr = c + i * n_cls;
-    // sample.py:40 skips apply_temp_to_probs when t == 1 (rows stay un-normalised); the function
-    // itself (force_norm) always renormalises, also at t == 1 where x**1.0 is x.
-    if (t != 1.0 || force_norm) {
-        const double e = 1.0 / t;
-        for (int j = 0; j < n_cls; ++j) {
-            const double x = pr[j];
-            qr[j] = (e == 1.0) ? x : (e == 2.0) ? x * x : (e == 0.5) ? sqrt(x) : pow(x, e);
+// temper + normalise + running sum.  Each row is inherently sequential (NumPy's pairwise normaliser order and a
+// strictly left-to-right cumsum are what make the result bit-identical), so the parallelism is across rows: a
+// workgroup stages ROWS rows through LDS with coalesced loads/stores (a thread walking its own row in global memory
+// would touch one 8-byte word per 8*n_cls-byte stride), thread r then owns row r in LDS.  The LDS row stride is odd
+// in doubles so the 64 row-walkers hit distinct banks.
+//   mode 0 (TH_TEMPER_NONE): rows used as they are;   1: q = x**e here (e in {1, 2, 0.5} — exact IEEE ops, the same
+//   fast paths NumPy takes);   2: rows already hold x**e (host pow);   modes 1, 2 renormalise.
+// flags[row] bit 0: the running sum is finite and non-decreasing (k_draw may then bisect instead of scanning).
+__global__ void __launch_bounds__(64) k_temper_cumsum(const double* __restrict__ p, int64_t n_res, int n_cls, double e, int mode,
+                                                      int rows_per_wg, double* __restrict__ q, double* __restrict__ c,
+                                                      unsigned char* __restrict__ flags) {
+    extern __shared__ double lds[];
+    const int ld = n_cls | 1;
+    const int64_t row0 = (int64_t)blockIdx.x * rows_per_wg;
+    const int rows = (int)min<int64_t>(rows_per_wg, n_res - row0);
+    const int64_t base = row0 * n_cls;
+    for (int k = threadIdx.x; k < rows * n_cls; k += 64) lds[(k / n_cls) * ld + k % n_cls] = p[base + k];
+    __syncthreads();
+    double* qr = lds + (size_t)threadIdx.x * ld;
+    double* cr = lds + (size_t)rows_per_wg * ld + (size_t)threadIdx.x * ld;
+    if ((int)threadIdx.x < rows) {
+        if (mode != 0) {
+            if (mode == 1 && e != 1.0)
+                for (int j = 0; j < n_cls; ++j) { const double x = qr[j]; qr[j] = (e == 2.0) ? x * x : sqrt(x); }
+            const double s = np_pairwise_sum<8>(qr, n_cls);
+            for (int j = 0; j < n_cls; ++j) qr[j] = qr[j] / s;
         }
-        const double s = np_pairwise_sum<8>(qr, n_cls);
-        for (int j = 0; j < n_cls; ++j) qr[j] = qr[j] / s;
-    } else {
-        for (int j = 0; j < n_cls; ++j) qr[j] = pr[j];
+        double run = 0.;
+        bool mono = true;
+        for (int j = 0; j < n_cls; ++j) {
+            const double nx = (j == 0) ? qr[0] : run + qr[j];
+            mono = mono && (nx >= run || j == 0) && (nx - nx == 0.0);   // finite and not decreasing
+            run = nx;
+            cr[j] = run;
+        }
+        flags[row0 + threadIdx.x] = mono ? 1 : 0;
     }
-    double run = 0.;
-    for (int j = 0; j < n_cls; ++j) {
-        run = (j == 0) ? qr[0] : run + qr[j];
-        cr[j] = run;
+    __syncthreads();
+    for (int k = threadIdx.x; k < rows * n_cls; k += 64) {
+        q[base + k] = lds[(k / n_cls) * ld + k % n_cls];
+        c[base + k] = lds[(size_t)rows_per_wg * ld + (k / n_cls) * ld + k % n_cls];
     }
 }
 
-// one thread per draw (sample s, residue i)
-__global__ void k_draw(const double* __restrict__ c, int64_t n_res, int n_cls, int64_t n_samples, int rng_mode,
-                       uint64_t seed, uint64_t rng_offset, const double* __restrict__ uniforms, int32_t* __restrict__ idx,
-                       double* __restrict__ r_out, const char* __restrict__ letters, char* __restrict__ letters_out) {
-    const int64_t total = n_samples * n_res;
+// One thread per draw.  Draws are numbered in the reference's consumption order
+//   for key in keys: for s in range(n_samples): r = np.random.rand(n_res[key])      (sampling_utils.py:118-125)
+// so draw d of key k (rows row_off[k] .. row_off[k+1]) is d = n_samples*row_off[k] + s*n_res_k + i, which is also where
+// its uniform sits in the caller's / the device generator's stream and where its index / letter is written.
+__global__ void __launch_bounds__(256) k_draw(const double* __restrict__ c, const unsigned char* __restrict__ flags, int n_cls,
+                                              const int64_t* __restrict__ row_off, int n_keys, int64_t n_samples, int rng_mode,
+                                              uint64_t seed, uint64_t rng_offset, const double* __restrict__ uniforms,
+                                              int32_t* __restrict__ idx, double* __restrict__ r_out,
+                                              const char* __restrict__ letters, char* __restrict__ letters_out) {
+    const int64_t total = n_samples * row_off[n_keys];
     for (int64_t d = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; d < total; d += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t i = d % n_res;
+        int lo = 0, hi = n_keys;                       // last key whose first draw is <= d
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (n_samples * row_off[mid] <= d) lo = mid; else hi = mid;
+        }
+        const int64_t r0 = row_off[lo], n_res = row_off[lo + 1] - r0;
+        const int64_t i = (d - n_samples * r0) % n_res;
         double r;
         if (rng_mode == TH_RNG_PHILOX) {
             rocrand_state_philox4x32_10 st;
@@ -90,14 +120,97 @@ __global__ void k_draw(const double* __restrict__ c, int64_t n_res, int n_cls, i
         } else {
             r = uniforms[d];
         }
-        const double* cr = c + i * n_cls;
+        const double* cr = c + (r0 + i) * n_cls;
         int first = 0;
-        for (int j = 0; j < n_cls; ++j) {
-            if (cr[j] > r) { first = j; break; }
+        if (flags[r0 + i] && n_cls > 32) {             // monotone finite running sum: first index with cr[j] > r by bisection
+            int a = 0, b = n_cls;                      // invariant: cr[<a] <= r, cr[>=b] > r
+            while (a < b) {
+                const int mid = (a + b) >> 1;
+                if (cr[mid] > r) b = mid; else a = mid + 1;
+            }
+            first = a < n_cls ? a : 0;
+        } else {
+            for (int j = 0; j < n_cls; ++j) {
+                if (cr[j] > r) { first = j; break; }
+            }
         }
         idx[d] = first;
         if (r_out) r_out[d] = r;
         if (letters_out) letters_out[d] = letters[first];
+    }
+}
+
+// ---- sequence metrics (reference design_utils/analyse_utils.py:351-371, called per drawn sequence at
+// sampling_utils.py:132) — one wavefront per sampled sequence: 20-bin residue histogram in LDS, then
+//   charge(pH) = sum_c n_c * tab[pH][c] + term[pH]   (tab = signed Henderson-Hasselbalch partial charges, host-built)
+//   out = (charge at pH 7.4, pI = first grid pH of minimum |charge| on np.arange(1, 13, 0.1), mass, eps280)
+// Sums run over the 20 classes in alphabetical one-letter order, fp64, so the host restatement can be matched
+// bit for bit.  Letters outside the 20 standard residues are not counted.
+constexpr int kGrid = 120;
+struct MetricTables {
+    double tab74[20], term74;
+    double mass[20], water;
+    double ext[20];
+    double grid[kGrid];
+    double tab[kGrid][20];
+    double term[kGrid];
+};
+
+__global__ void __launch_bounds__(256) k_seq_metrics(const char* __restrict__ letters, const int64_t* __restrict__ row_off,
+                                                     int n_keys, int64_t n_samples, const MetricTables* __restrict__ T,
+                                                     double* __restrict__ out) {
+    __shared__ int hist[4][20];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t seq = (int64_t)blockIdx.x * 4 + wave;          // sequence number: key-major, then sample
+    const int64_t n_seq = (int64_t)n_keys * n_samples;
+    if (lane < 20) hist[wave][lane] = 0;
+    __syncthreads();
+    if (seq < n_seq) {
+        const int k = (int)(seq / n_samples);
+        const int64_t s = seq % n_samples;
+        const int64_t r0 = row_off[k], n_res = row_off[k + 1] - r0;
+        const char* L = letters + n_samples * r0 + s * n_res;
+        for (int64_t i = lane; i < n_res; i += 64) {
+            int cls = -1;
+            switch (L[i]) {
+                case 'A': cls = 0; break;  case 'C': cls = 1; break;  case 'D': cls = 2; break;  case 'E': cls = 3; break;
+                case 'F': cls = 4; break;  case 'G': cls = 5; break;  case 'H': cls = 6; break;  case 'I': cls = 7; break;
+                case 'K': cls = 8; break;  case 'L': cls = 9; break;  case 'M': cls = 10; break; case 'N': cls = 11; break;
+                case 'P': cls = 12; break; case 'Q': cls = 13; break; case 'R': cls = 14; break; case 'S': cls = 15; break;
+                case 'T': cls = 16; break; case 'V': cls = 17; break; case 'W': cls = 18; break; case 'Y': cls = 19; break;
+                default: break;
+            }
+            if (cls >= 0) atomicAdd(&hist[wave][cls], 1);
+        }
+    }
+    __syncthreads();
+    if (seq >= n_seq) return;
+    double n[20];
+    for (int c = 0; c < 20; ++c) n[c] = (double)hist[wave][c];
+    // isoelectric point: lanes take grid points g = lane, lane + 64; first minimum of |charge| wins (np.argmin / min())
+    double best = 1e300;
+    int best_g = kGrid;
+    for (int g = lane; g < kGrid; g += 64) {
+        double ch = 0.;
+        for (int c = 0; c < 20; ++c) ch += n[c] * T->tab[g][c];
+        ch += T->term[g];
+        const double a = fabs(ch);
+        if (a < best) { best = a; best_g = g; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ob = __shfl_xor(best, off);
+        const int og = __shfl_xor(best_g, off);
+        if (ob < best || (ob == best && og < best_g)) { best = ob; best_g = og; }
+    }
+    if (lane == 0) {
+        double ch = 0., mw = 0., ex = 0.;
+        for (int c = 0; c < 20; ++c) ch += n[c] * T->tab74[c];
+        ch += T->term74;
+        for (int c = 0; c < 20; ++c) mw += n[c] * T->mass[c];
+        mw += T->water;
+        for (int c = 0; c < 20; ++c) ex += n[c] * T->ext[c];
+        double* o = out + seq * 4;
+        o[0] = ch; o[1] = T->grid[best_g < kGrid ? best_g : 0]; o[2] = mw; o[3] = ex;
     }
 }
 
@@ -153,36 +266,246 @@ __global__ void __launch_bounds__(256) k_mt19937_uniforms(uint32_t seed, uint64_
     }
 }
 
-// Device scratch for one call.  hipMalloc/hipFree cost more than the kernels of a config-5 sized call (a few
-// hundred microseconds each vs ~10 us), so the buffers are kept in a small grow-only pool: one cached allocation per
-// DevBuf declared in sampler_run (claimed in declaration order), guarded by a mutex that serialises sampler calls.
-struct Pool {
-    std::mutex mu;
-    struct Slot { void* p = nullptr; size_t cap = 0; int dev = -1; } slot[16];
-    int next = 0;
-};
-Pool g_pool;
-
-struct DevBuf {
+// grow-only device / pinned-host scratch
+struct Scratch {
     void* p = nullptr;
-    Pool::Slot* s = nullptr;
-    int alloc(size_t bytes) {
-        if (!s) s = &g_pool.slot[g_pool.next++ % 16];
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (s->cap < bytes || s->dev != dev || !s->p) {
-            if (s->p) { (void)hipSetDevice(s->dev); (void)hipFree(s->p); (void)hipSetDevice(dev); s->p = nullptr; s->cap = 0; }
-            const size_t want = std::max<size_t>(bytes, 1 << 16);
-            hipError_t e = hipMalloc(&s->p, want);
-            if (e != hipSuccess) { s->p = nullptr; th_set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); return TH_ENOMEM; }
-            s->cap = want; s->dev = dev;
-        }
-        p = s->p;
+    size_t cap = 0;
+    bool host = false;
+    int ensure(size_t bytes) {
+        if (cap >= bytes && p) return TH_OK;
+        if (p) { if (host) (void)hipHostFree(p); else (void)hipFree(p); p = nullptr; cap = 0; }
+        const size_t want = std::max<size_t>(bytes + bytes / 4, 1 << 16);
+        hipError_t e = host ? hipHostMalloc(&p, want, hipHostMallocDefault) : hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; th_set_error("sampler: allocating %zu bytes failed: %s", want, hipGetErrorString(e)); return TH_ENOMEM; }
+        cap = want;
         return TH_OK;
     }
+    void release() { if (p) { if (host) (void)hipHostFree(p); else (void)hipFree(p); } p = nullptr; cap = 0; }
 };
 
+// ampal's tables as restated in design_utils/analyse_utils.py (PARITY UNPINNED: ampal 1.5.1 is not in the reference
+// tree); class order = alphabetical one-letter codes ACDEFGHIKLMNPQRSTVWY.
+const double kMass[20] = {71.0779, 103.1429, 115.0874, 129.114, 147.1739, 57.0513, 137.1393, 113.1576, 128.1723, 113.1576,
+                          131.1961, 114.1026, 97.1152, 128.1292, 156.1857, 87.0773, 101.1039, 99.1311, 186.2099, 163.1733};
+const double kWater = 18.01528;
+const double kExt[20] = {0, 120, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 5690, 1280};
+const int kSign[20] = {0, -1, -1, -1, 0, 0, +1, 0, +1, 0, 0, 0, 0, 0, +1, 0, 0, 0, 0, -1};
+const double kPka[20] = {0, 8.3, 3.65, 4.25, 0, 0, 6.1, 0, 10.53, 0, 0, 0, 0, 0, 12.48, 0, 0, 0, 0, 10.1};
+const double kPkaNterm = 8.0, kPkaCterm = 3.1;
+
+double partial_charge(double pka, int sign, double ph) {
+    double diff = ph - pka;
+    if (sign > 0) diff = -diff;
+    const double r = std::pow(10.0, diff);
+    return r / (1.0 + r);
+}
+
+void build_metric_tables(MetricTables* T) {
+    auto fill = [](double ph, double* tab, double* term) {
+        for (int c = 0; c < 20; ++c) tab[c] = kSign[c] ? partial_charge(kPka[c], kSign[c], ph) * kSign[c] : 0.0;
+        *term = partial_charge(kPkaNterm, +1, ph) * (+1) + partial_charge(kPkaCterm, -1, ph) * (-1);
+    };
+    fill(7.4, T->tab74, &T->term74);
+    for (int c = 0; c < 20; ++c) { T->mass[c] = kMass[c]; T->ext[c] = kExt[c]; }
+    T->water = kWater;
+    for (int g = 0; g < kGrid; ++g) {
+        T->grid[g] = 1.0 + g * 0.1;            // np.arange(1, 13, 0.1)[g] = start + g*step
+        fill(T->grid[g], T->tab[g], &T->term[g]);
+    }
+}
+
 }  // namespace
+
+// A sampler keeps the probability rows of a whole run resident on one device (tempered, normalised, with their
+// running sums) and draws any number of sequences for any subset of keys in ONE launch sequence on its own stream.
+struct th_sampler {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int64_t n_rows = 0;
+    int n_cls = 0;
+    Scratch dp, dq, dc, dflags, drow, du, di, dr, dlet, dcat, dmet, dtab;
+    Scratch hq;                     // host buffer for the powered rows
+    bool tables = false;
+    std::mutex mu;
+};
+
+namespace {
+
+int sampler_load(th_sampler* S, const double* probs, int64_t n_rows, int n_cls, double t, int mode, double* q_out) {
+    if (!S || !probs || n_rows <= 0 || n_cls <= 0) TH_FAIL(TH_EINVAL, "th_sampler_load: bad shape");
+    if (mode < TH_TEMPER_NONE || mode > TH_TEMPER_PREPOWERED) TH_FAIL(TH_EINVAL, "th_sampler_load: temper mode %d", mode);
+    if (mode != TH_TEMPER_NONE && t == 0.0)
+        TH_FAIL(TH_EINVAL, "th_sample: temperature 0 (the reference divides by it: sampling_utils.py:159)");
+    HIP_TRY(hipSetDevice(S->device));
+    const size_t cells = (size_t)n_rows * n_cls, bytes = cells * sizeof(double);
+    int rc;
+    if ((rc = S->dp.ensure(bytes)) || (rc = S->dq.ensure(bytes)) || (rc = S->dc.ensure(bytes)) ||
+        (rc = S->dflags.ensure((size_t)n_rows)))
+        return rc;
+    const double e = mode == TH_TEMPER_POW ? 1.0 / t : 1.0;
+    const double* src = probs;
+    int kmode = mode;
+    if (mode == TH_TEMPER_POW && e != 1.0 && e != 2.0 && e != 0.5) {
+        // generic exponent: the power runs on the host with libm's pow — the function NumPy's float64 `**` loop calls
+        // element by element (its AVX-512 SVML loop may differ from it in the last bit; callers that must match a
+        // particular NumPy build pass rows they powered themselves, TH_TEMPER_PREPOWERED).  Device pow() is not
+        // correctly rounded and an ulp in q can move a residue index when r lands on a CDF boundary.
+        S->hq.host = true;
+        if ((rc = S->hq.ensure(bytes))) return rc;
+        double* h = (double*)S->hq.p;
+        for (size_t k = 0; k < cells; ++k) h[k] = std::pow(probs[k], e);
+        src = h;
+        kmode = TH_TEMPER_PREPOWERED;
+    }
+    HIP_TRY(hipMemcpyAsync(S->dp.p, src, bytes, hipMemcpyHostToDevice, S->stream));
+    // rows per workgroup: as many as fit 64 row-walkers and ~60 KB of LDS (two images: q and its running sum)
+    const int ld = n_cls | 1;
+    int rows = (int)std::min<int64_t>(64, std::max<int64_t>(1, (60 * 1024) / ((size_t)2 * ld * sizeof(double))));
+    const size_t lds = (size_t)2 * rows * ld * sizeof(double);
+    if (lds > 64 * 1024 + 0 && rows == 1) {
+        // a single row wider than the LDS budget: raise the dynamic limit (160 KB per CU on gfx950)
+        HIP_TRY(hipFuncSetAttribute((const void*)k_temper_cumsum, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    if (lds > 160 * 1024) TH_FAIL(TH_EUNSUP, "th_sampler_load: %d categories per row exceed the LDS budget", n_cls);
+    hipLaunchKernelGGL(k_temper_cumsum, dim3((unsigned)((n_rows + rows - 1) / rows)), dim3(64), lds, S->stream,
+                       (const double*)S->dp.p, n_rows, n_cls, e, kmode, rows, (double*)S->dq.p, (double*)S->dc.p,
+                       (unsigned char*)S->dflags.p);
+    HIP_TRY(hipGetLastError());
+    if (q_out) HIP_TRY(hipMemcpyAsync(q_out, S->dq.p, bytes, hipMemcpyDeviceToHost, S->stream));
+    HIP_TRY(hipStreamSynchronize(S->stream));      // `probs` / the host pow buffer may be reused by the caller now
+    S->n_rows = n_rows;
+    S->n_cls = n_cls;
+    return TH_OK;
+}
+
+int sampler_draw(th_sampler* S, int64_t n_keys, const int64_t* row_off, int64_t n_samples, int rng_mode, uint64_t seed,
+                 uint64_t rng_offset, const double* uniforms, const char* cat_letters, int32_t* idx_out, double* r_out,
+                 char* letters_out, double* metrics_out) {
+    if (!S || !row_off || n_keys <= 0 || n_samples < 0) TH_FAIL(TH_EINVAL, "th_sampler_draw: bad argument");
+    if (S->n_rows <= 0) TH_FAIL(TH_EINVAL, "th_sampler_draw: no probabilities loaded (th_sampler_load)");
+    if (n_keys > 0x7fffffff) TH_FAIL(TH_EINVAL, "th_sampler_draw: too many keys");
+    if (row_off[0] < 0) TH_FAIL(TH_EINVAL, "th_sampler_draw: negative row offset");
+    for (int64_t k = 0; k < n_keys; ++k)
+        if (row_off[k + 1] <= row_off[k]) TH_FAIL(TH_EINVAL, "th_sampler_draw: key %lld has no rows", (long long)k);
+    if (row_off[n_keys] > S->n_rows) TH_FAIL(TH_EINVAL, "th_sampler_draw: rows beyond the loaded matrix");
+    if (rng_mode < TH_RNG_HOST || rng_mode > TH_RNG_MT19937) TH_FAIL(TH_EINVAL, "th_sample: rng_mode %d", rng_mode);
+    if (rng_mode == TH_RNG_HOST && n_samples > 0 && !uniforms) TH_FAIL(TH_EINVAL, "th_sample: rng_mode 0 needs uniforms");
+    if (rng_mode == TH_RNG_MT19937 && seed > 0xffffffffULL) TH_FAIL(TH_EINVAL, "th_sample: MT19937 seed must fit 32 bits");
+    if ((letters_out || metrics_out) && !cat_letters) TH_FAIL(TH_EINVAL, "th_sample: letters_out / metrics_out need cat_letters");
+    HIP_TRY(hipSetDevice(S->device));
+    // draws are numbered from the first requested row: shift the offsets so that key 0 starts at draw 0
+    std::vector<int64_t> off(n_keys + 1);
+    const int64_t base_row = row_off[0];
+    for (int64_t k = 0; k <= n_keys; ++k) off[k] = row_off[k] - base_row;
+    const int64_t total = n_samples * off[n_keys];
+    if (total == 0) return TH_OK;
+    int rc;
+    if ((rc = S->drow.ensure((size_t)(n_keys + 1) * sizeof(int64_t)))) return rc;
+    HIP_TRY(hipMemcpyAsync(S->drow.p, off.data(), (size_t)(n_keys + 1) * sizeof(int64_t), hipMemcpyHostToDevice, S->stream));
+    const bool need_u = rng_mode != TH_RNG_PHILOX;
+    if (need_u) {
+        if ((rc = S->du.ensure((size_t)total * sizeof(double)))) return rc;
+        if (rng_mode == TH_RNG_HOST) {
+            HIP_TRY(hipMemcpyAsync(S->du.p, uniforms, (size_t)total * sizeof(double), hipMemcpyHostToDevice, S->stream));
+        } else {
+            hipLaunchKernelGGL(k_mt19937_uniforms, dim3(1), dim3(256), 0, S->stream, (uint32_t)seed, rng_offset, total, (double*)S->du.p);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    if ((rc = S->di.ensure((size_t)total * sizeof(int32_t)))) return rc;
+    if (r_out && (rc = S->dr.ensure((size_t)total * sizeof(double)))) return rc;
+    const bool want_letters = letters_out || metrics_out;
+    if (want_letters) {
+        if ((rc = S->dcat.ensure((size_t)S->n_cls)) || (rc = S->dlet.ensure((size_t)total))) return rc;
+        HIP_TRY(hipMemcpyAsync(S->dcat.p, cat_letters, (size_t)S->n_cls, hipMemcpyHostToDevice, S->stream));
+    }
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    const size_t row_shift = (size_t)base_row * S->n_cls;
+    hipLaunchKernelGGL(k_draw, dim3((unsigned)blocks), dim3(256), 0, S->stream, (const double*)S->dc.p + row_shift,
+                       (const unsigned char*)S->dflags.p + base_row, S->n_cls, (const int64_t*)S->drow.p, (int)n_keys, n_samples,
+                       rng_mode, seed, rng_offset, (const double*)S->du.p, (int32_t*)S->di.p, r_out ? (double*)S->dr.p : nullptr,
+                       (const char*)S->dcat.p, want_letters ? (char*)S->dlet.p : nullptr);
+    HIP_TRY(hipGetLastError());
+    if (metrics_out) {
+        if (!S->tables) {
+            std::unique_ptr<MetricTables> T(new MetricTables);
+            build_metric_tables(T.get());
+            if ((rc = S->dtab.ensure(sizeof(MetricTables)))) return rc;
+            HIP_TRY(hipMemcpy(S->dtab.p, T.get(), sizeof(MetricTables), hipMemcpyHostToDevice));
+            S->tables = true;
+        }
+        const int64_t n_seq = n_keys * n_samples;
+        if ((rc = S->dmet.ensure((size_t)n_seq * 4 * sizeof(double)))) return rc;
+        hipLaunchKernelGGL(k_seq_metrics, dim3((unsigned)((n_seq + 3) / 4)), dim3(256), 0, S->stream, (const char*)S->dlet.p,
+                           (const int64_t*)S->drow.p, (int)n_keys, n_samples, (const MetricTables*)S->dtab.p, (double*)S->dmet.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(metrics_out, S->dmet.p, (size_t)n_seq * 4 * sizeof(double), hipMemcpyDeviceToHost, S->stream));
+    }
+    if (idx_out) HIP_TRY(hipMemcpyAsync(idx_out, S->di.p, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost, S->stream));
+    if (r_out) HIP_TRY(hipMemcpyAsync(r_out, S->dr.p, (size_t)total * sizeof(double), hipMemcpyDeviceToHost, S->stream));
+    if (letters_out) HIP_TRY(hipMemcpyAsync(letters_out, S->dlet.p, (size_t)total, hipMemcpyDeviceToHost, S->stream));
+    HIP_TRY(hipStreamSynchronize(S->stream));
+    return TH_OK;
+}
+
+// one lazily created sampler per device behind the one-shot entry points (th_apply_temp / th_sample / th_sample_ex)
+std::mutex g_default_mu;
+std::vector<th_sampler*> g_default;
+
+th_sampler* default_sampler(int device) {
+    std::lock_guard<std::mutex> lock(g_default_mu);
+    if (device < 0 || device >= 1024) { th_set_error("bad device index %d", device); return nullptr; }
+    if ((int)g_default.size() <= device) g_default.resize(device + 1, nullptr);
+    if (!g_default[device]) {
+        th_sampler* s = nullptr;
+        if (th_sampler_create(device, &s) != TH_OK) return nullptr;
+        g_default[device] = s;
+    }
+    return g_default[device];
+}
+
+}  // namespace
+
+extern "C" {
+
+int th_sampler_create(int device, th_sampler** out) {
+    if (!out) TH_FAIL(TH_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(device));
+    std::unique_ptr<th_sampler> s(new th_sampler);
+    s->device = device;
+    HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    *out = s.release();
+    return TH_OK;
+}
+
+void th_sampler_free(th_sampler* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    for (Scratch* b : {&s->dp, &s->dq, &s->dc, &s->dflags, &s->drow, &s->du, &s->di, &s->dr, &s->dlet, &s->dcat, &s->dmet, &s->dtab, &s->hq})
+        b->release();
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+int th_sampler_load(th_sampler* s, const double* probs, int64_t n_rows, int n_cls, double temperature, int temper_mode,
+                    double* q_out) {
+    if (!s) TH_FAIL(TH_EINVAL, "null sampler");
+    std::lock_guard<std::mutex> lock(s->mu);
+    return sampler_load(s, probs, n_rows, n_cls, temperature, temper_mode, q_out);
+}
+
+int th_sampler_draw(th_sampler* s, int64_t n_keys, const int64_t* row_off, int64_t n_samples, int rng_mode, uint64_t seed,
+                    uint64_t rng_offset, const double* uniforms, const char* cat_letters, int32_t* idx_out, double* r_out,
+                    char* letters_out, double* metrics_out) {
+    if (!s) TH_FAIL(TH_EINVAL, "null sampler");
+    std::lock_guard<std::mutex> lock(s->mu);
+    return sampler_draw(s, n_keys, row_off, n_samples, rng_mode, seed, rng_offset, uniforms, cat_letters, idx_out, r_out,
+                        letters_out, metrics_out);
+}
+
+}  // extern "C"
 
 int sampler_run(int device, const double* h_probs, int64_t n_res, int n_cls, int64_t n_samples, double temperature,
                 int rng_mode, uint64_t seed, uint64_t rng_offset, const double* h_uniforms, int32_t* h_idx,
@@ -193,47 +516,15 @@ int sampler_run(int device, const double* h_probs, int64_t n_res, int n_cls, int
     if (rng_mode < TH_RNG_HOST || rng_mode > TH_RNG_MT19937) TH_FAIL(TH_EINVAL, "th_sample: rng_mode %d", rng_mode);
     if (rng_mode == TH_RNG_MT19937 && seed > 0xffffffffULL) TH_FAIL(TH_EINVAL, "th_sample: MT19937 seed must fit 32 bits");
     if (h_letters && !cat_letters) TH_FAIL(TH_EINVAL, "th_sample: letters_out needs cat_letters");
-    std::lock_guard<std::mutex> pool_lock(g_pool.mu);
-    g_pool.next = 0;
-    HIP_TRY(hipSetDevice(device));
-    const int64_t total = n_samples * n_res;
-    const size_t pbytes = (size_t)n_res * n_cls * sizeof(double);
-    DevBuf dp, dq, dc, du, di, dl, dlo;
-    int rc;
-    if ((rc = dp.alloc(pbytes)) || (rc = dq.alloc(pbytes)) || (rc = dc.alloc(pbytes))) return rc;
-    HIP_TRY(hipMemcpy(dp.p, h_probs, pbytes, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_temper_cumsum, dim3((unsigned)((n_res + 63) / 64)), dim3(64), 0, 0, (const double*)dp.p, n_res,
-                       n_cls, temperature, (n_samples == 0 && h_q_out) ? 1 : 0, (double*)dq.p, (double*)dc.p);
-    HIP_TRY(hipGetLastError());
-    if (h_q_out) HIP_TRY(hipMemcpy(h_q_out, dq.p, pbytes, hipMemcpyDeviceToHost));
-    if (total == 0) { HIP_TRY(hipDeviceSynchronize()); return TH_OK; }
-    const bool need_u = rng_mode != TH_RNG_PHILOX;
-    if (need_u) {
-        if ((rc = du.alloc((size_t)total * sizeof(double)))) return rc;
-        if (rng_mode == TH_RNG_HOST) {
-            HIP_TRY(hipMemcpy(du.p, h_uniforms, (size_t)total * sizeof(double), hipMemcpyHostToDevice));
-        } else {
-            hipLaunchKernelGGL(k_mt19937_uniforms, dim3(1), dim3(256), 0, 0, (uint32_t)seed, rng_offset, total,
-                               (double*)du.p);
-            HIP_TRY(hipGetLastError());
-        }
-    }
-    if ((rc = di.alloc((size_t)total * sizeof(int32_t)))) return rc;
-    DevBuf dr;
-    if (h_r_out && (rc = dr.alloc((size_t)total * sizeof(double)))) return rc;
-    if (h_letters) {
-        if ((rc = dl.alloc((size_t)n_cls)) || (rc = dlo.alloc((size_t)total))) return rc;
-        HIP_TRY(hipMemcpy(dl.p, cat_letters, (size_t)n_cls, hipMemcpyHostToDevice));
-    }
-    int64_t blocks = (total + 255) / 256;
-    if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(k_draw, dim3((unsigned)blocks), dim3(256), 0, 0, (const double*)dc.p, n_res, n_cls, n_samples,
-                       rng_mode, seed, rng_offset, (const double*)du.p, (int32_t*)di.p, (double*)dr.p, (const char*)dl.p,
-                       (char*)dlo.p);
-    HIP_TRY(hipGetLastError());
-    if (h_idx) HIP_TRY(hipMemcpy(h_idx, di.p, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (h_r_out) HIP_TRY(hipMemcpy(h_r_out, dr.p, (size_t)total * sizeof(double), hipMemcpyDeviceToHost));
-    if (h_letters) HIP_TRY(hipMemcpy(h_letters, dlo.p, (size_t)total, hipMemcpyDeviceToHost));
-    HIP_TRY(hipDeviceSynchronize());
-    return TH_OK;
+    th_sampler* S = default_sampler(device);
+    if (!S) return TH_EHIP;
+    std::lock_guard<std::mutex> lock(S->mu);
+    // sample.py:40 skips apply_temp_to_probs when t == 1 (rows stay un-normalised); apply_temp_to_probs itself
+    // (n_samples == 0 with q_out) always renormalises, also at t == 1 where x**1.0 is x.
+    const bool apply = temperature != 1.0 || (n_samples == 0 && h_q_out);
+    int rc = sampler_load(S, h_probs, n_res, n_cls, temperature, apply ? TH_TEMPER_POW : TH_TEMPER_NONE, h_q_out);
+    if (rc || n_samples == 0) return rc;
+    const int64_t row_off[2] = {0, n_res};
+    return sampler_draw(S, 1, row_off, n_samples, rng_mode, seed, rng_offset, h_uniforms, cat_letters, h_idx, h_r_out,
+                        h_letters, nullptr);
 }

@@ -32,6 +32,12 @@ PROTOTYPES = {
     "th_model_set_chunk": (_i, [_vp, _i]),
     "th_predict": (_i, [_vp, _vp, _i, _i64, _vp, _u]),
     "th_predict_device": (_i, [_vp, _vp, _i, _i64, _vp, _u]),
+    "th_predict_async": (_i, [_vp, _vp, _i, _i64, _vp, _u, _pi]),
+    "th_predict_wait": (_i, [_vp, _i]),
+    "th_host_alloc": (_i, [_sz, C.POINTER(_vp)]),
+    "th_host_free": (_i, [_vp]),
+    "th_host_register": (_i, [_vp, _sz]),
+    "th_host_unregister": (_i, [_vp]),
     "th_model_fetch": (_i, [_vp, C.c_char_p, _i64, _vp, _i64]),
     "th_model_profile": (_i, [_vp, _i]),
     "th_model_step_info": (_i, [_vp, _i, C.c_char_p, _sz, _pd, _pi64, _pd, _pd, _pd]),

@@ -83,6 +83,28 @@ class HipFrameModel:
 
     __call__ = predict
 
+    def predict_async(self, X, logits: bool = False) -> "PendingPrediction":
+        """Queue ``X`` (copy to the device, kernels, copy of the probabilities back) and return at once; the
+        returned handle's ``result()`` blocks until that batch is done and gives the float32 [B, n_classes] array.
+        Up to four batches may be in flight per model; they finish in submission order.  The caller's loop (load the
+        next batch, format the previous one) then runs under the GPU's work — reference predict.py:125-155 is strictly
+        sequential.  ``X`` is held by the handle until ``result()``; batches built in ``pinned_empty`` memory are
+        fetched by the DMA engine without blocking this call."""
+        X = np.asarray(X)
+        if X.ndim != 5 or tuple(X.shape[1:]) != self.input_shape:
+            raise ValueError(f"expected frames of shape (B, {', '.join(map(str, self.input_shape))}), got {X.shape}")
+        dt = _DTYPES.get(X.dtype)
+        if dt is None:
+            X = X.astype(np.float32)
+            dt = _lib.TH_F32
+        X = np.ascontiguousarray(X)
+        n = X.shape[0]
+        out = np.empty((n, self.logits_width if logits else self.n_classes), dtype=np.float32)
+        ticket = C.c_int(-1)
+        _lib.check(self._lib.th_predict_async(self._h, X.ctypes.data, dt, n, out.ctypes.data,
+                                              _lib.TH_PREDICT_LOGITS if logits else 0, C.byref(ticket)))
+        return PendingPrediction(self, ticket.value, X, out)
+
     @property
     def logits_width(self) -> int:
         return self.n_classes
@@ -132,6 +154,69 @@ class HipFrameModel:
             self.close()
         except Exception:
             pass
+
+
+class PendingPrediction:
+    """A batch in flight (HipFrameModel.predict_async).  Keeps the input alive until the result is taken."""
+
+    def __init__(self, model: HipFrameModel, ticket: int, frames: np.ndarray, out: np.ndarray):
+        self._model, self._ticket, self._frames, self._out = model, ticket, frames, out
+
+    def result(self) -> np.ndarray:
+        if self._ticket is not None:
+            t, self._ticket = self._ticket, None
+            try:
+                _lib.check(self._model._lib.th_predict_wait(self._model._h, t))
+            finally:
+                self._frames = None
+        return self._out
+
+    def __del__(self):          # a dropped handle must still return its ticket to the model
+        try:
+            if self._ticket is not None and self._model._h:
+                self._model._lib.th_predict_wait(self._model._h, self._ticket)
+        except Exception:
+            pass
+
+
+class PinnedBuffer:
+    """Page-locked host memory from the C ABI (th_host_alloc) exposed as NumPy arrays: frame batches built here are
+    copied to the device asynchronously (no staging pass through pageable memory)."""
+
+    def __init__(self, nbytes: int):
+        self._lib = _lib.load()
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        _lib.check(self._lib.th_host_alloc(self.nbytes, C.byref(p)))
+        self.ptr = p.value
+        self._raw = (C.c_char * self.nbytes).from_address(self.ptr)
+
+    def array(self, shape, dtype, offset: int = 0) -> np.ndarray:
+        dtype = np.dtype(dtype)
+        count = int(np.prod(shape))
+        if offset + count * dtype.itemsize > self.nbytes:
+            raise ValueError("PinnedBuffer too small for the requested array")
+        a = np.frombuffer(self._raw, dtype=dtype, count=count, offset=offset).reshape(shape)
+        return a          # holds a reference to self._raw; keep the PinnedBuffer alive while arrays are in use
+
+    def free(self):
+        if self.ptr:
+            self._raw = None
+            self._lib.th_host_free(C.c_void_p(self.ptr))
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype=np.float32):
+    """(array, owner): an uninitialised page-locked array; drop both to release it."""
+    dtype = np.dtype(dtype)
+    buf = PinnedBuffer(max(1, int(np.prod(shape)) * dtype.itemsize))
+    return buf.array(shape, dtype), buf
 
 
 class DeviceBuffer:

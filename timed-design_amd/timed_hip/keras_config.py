@@ -58,12 +58,34 @@ class Layer:
     out_shape: tuple = ()                                 # (D,H,W,C) or (F,)
 
 
-def _act_code(name) -> int:
+def _act_code(name):
+    """activation spec -> (code, alpha).  A string names the Keras function with its default parameters
+    ('elu' alpha 1.0; 'leaky_relu' negative_slope 0.2 — keras.activations.leaky_relu's default); a serialized
+    object ({"class_name": ..., "config": {...}}) carries its own alpha / negative_slope.  A leaky slope that
+    cannot be determined is an error, never a silent identity."""
+    cfg = {}
     if isinstance(name, dict):  # serialized activation object
-        name = name.get("class_name") or name.get("config", {}).get("name")
+        cfg = name.get("config") or {}
+        if not isinstance(cfg, dict):       # {"class_name": "function", "config": "relu"}
+            cfg = {"name": cfg}
+        cls = name.get("class_name")
+        name = cls if cls in _ACT_BY_NAME else cfg.get("name", cls)
     if name not in _ACT_BY_NAME:
         raise UnsupportedLayer(f"activation {name!r} is not supported")
-    return _ACT_BY_NAME[name]
+    code = _ACT_BY_NAME[name]
+    alpha = 1.0
+    if code == ACT_ELU:
+        alpha = float(cfg.get("alpha", 1.0))
+    elif code == ACT_LEAKY:
+        if "negative_slope" in cfg or "alpha" in cfg:
+            alpha = float(cfg.get("negative_slope", cfg.get("alpha")))
+        elif name == "leaky_relu":
+            alpha = 0.2
+        elif name == "LeakyReLU" and cfg:   # the layer class used as an activation: its own default
+            alpha = 0.3
+        else:
+            raise UnsupportedLayer(f"activation {name!r}: negative slope not given")
+    return code, alpha
 
 
 def _triple(v) -> tuple:
@@ -178,11 +200,12 @@ def parse_keras_model(model_config, weights: Dict[str, Sequence[np.ndarray]]) ->
                 ws["bias"] = np.asarray(w[1], dtype=np.float32).reshape(cout)
             out = (_conv_out(d, k[0], s[0], dl[0], same), _conv_out(h, k[1], s[1], dl[1], same),
                    _conv_out(wd, k[2], s[2], dl[2], same), cout)
+            act, alpha = _act_code(c.get("activation"))
             add(Layer(name=name, op=OP_CONV3D, inputs=ins,
                       ip=dict(kd=k[0], kh=k[1], kw=k[2], sd=s[0], sh=s[1], sw=s[2], dd=dl[0], dh=dl[1],
                               dw=dl[2], same=int(same), cin=cin, cout=cout, use_bias=int(use_bias),
-                              act=_act_code(c.get("activation"))),
-                      fp=dict(alpha=1.0), weights=ws, out_shape=out))
+                              act=act),
+                      fp=dict(alpha=alpha), weights=ws, out_shape=out))
         elif cname == "Dense":
             shp = shapes[ins[0]]
             if len(shp) != 1:
@@ -195,9 +218,10 @@ def parse_keras_model(model_config, weights: Dict[str, Sequence[np.ndarray]]) ->
             ws = {"kernel": kern}
             if use_bias:
                 ws["bias"] = np.asarray(w[1], dtype=np.float32).reshape(fout)
+            act, alpha = _act_code(c.get("activation"))
             add(Layer(name=name, op=OP_DENSE, inputs=ins,
-                      ip=dict(fin=fin, fout=fout, use_bias=int(use_bias), act=_act_code(c.get("activation"))),
-                      fp=dict(alpha=1.0), weights=ws, out_shape=(fout,)))
+                      ip=dict(fin=fin, fout=fout, use_bias=int(use_bias), act=act),
+                      fp=dict(alpha=alpha), weights=ws, out_shape=(fout,)))
         elif cname == "BatchNormalization":
             shp = shapes[ins[0]]
             axis = c.get("axis", -1)
@@ -220,7 +244,7 @@ def parse_keras_model(model_config, weights: Dict[str, Sequence[np.ndarray]]) ->
             shp = shapes[ins[0]]
             alpha = 1.0
             if cname == "Activation":
-                act = _act_code(c["activation"])
+                act, alpha = _act_code(c["activation"])
             elif cname == "ELU":
                 act, alpha = ACT_ELU, float(c.get("alpha", 1.0))
             elif cname == "ReLU":
