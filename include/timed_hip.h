@@ -51,6 +51,8 @@ extern "C" {
 /* th_predict* flags */
 #define TH_PREDICT_DEFAULT 0u
 #define TH_PREDICT_LOGITS 1u    /* skip the final Softmax: return its input (parity on the logits) */
+#define TH_PREDICT_OUT_DEVICE 2u /* th_predict/_async: probs_out is memory of the model's DEVICE (frames still come from the
+                                  * host); the rows stay in HBM, e.g. for th_comm_gather_rows */
 
 typedef struct th_model th_model;
 typedef struct th_comm th_comm;
@@ -121,7 +123,8 @@ int th_dev_synth_frames(int device, float* d_frames, int64_t n, int side, int ch
 
 /* ---- sampler: replaces design_utils/sampling_utils.py ------------------------------------- */
 /* apply_temp_to_probs (sampling_utils.py:139-161): q = p**(1/t), rows renormalised; fp64 */
-int th_apply_temp(const double* probs, int64_t n_res, int n_cls, double t, double* out);
+int th_apply_temp(const double* probs, int64_t n_res, int n_cls, double t, double* out);           /* device 0 */
+int th_apply_temp_on(int device, const double* probs, int64_t n_res, int n_cls, double t, double* out);
 /* random_choice_prob_index (sampling_utils.py:53-90, kernel lines 81-82), n_samples draws fused:
  *   idx[s,i] = first j with cumsum_j(q[i,:]) > r[s,i], 0 if none   (q = tempered probs, t==1: q=p)
  * rng_mode 0: r = uniforms[s*n_res+i] supplied by the caller (e.g. np.random.rand — bit-exact
@@ -133,7 +136,7 @@ int th_apply_temp(const double* probs, int64_t n_res, int n_cls, double t, doubl
 #define TH_RNG_PHILOX 1
 #define TH_RNG_MT19937 2
 int th_sample(const double* probs, int64_t n_res, int n_cls, int64_t n_samples, double temperature,
-              int rng_mode, uint64_t seed, const double* uniforms, int32_t* idx_out);
+              int rng_mode, uint64_t seed, const double* uniforms, int32_t* idx_out);               /* device 0 */
 /* optionally also return the uniforms the device drew (r_out [n_samples,n_res], may be NULL) and
  * residue letters (letters_out [n_samples, n_res] bytes, via cat_letters[n_cls], may be NULL) */
 /* rng_offset = uniforms already consumed from the device stream (Philox: added to the subsequence
@@ -142,6 +145,42 @@ int th_sample(const double* probs, int64_t n_res, int n_cls, int64_t n_samples, 
 int th_sample_ex(const double* probs, int64_t n_res, int n_cls, int64_t n_samples, double temperature,
                  int rng_mode, uint64_t seed, uint64_t rng_offset, const double* uniforms, int32_t* idx_out,
                  double* r_out, const char* cat_letters, char* letters_out, double* q_out, int device);
+
+/* A resident sampler: the probability rows of a whole run (every PDB key of sample.py's prediction matrix) stay on
+ * one device, tempered and normalised, with their running sums; any number of sequences for any contiguous range of
+ * keys is then drawn by ONE launch sequence — instead of one upload + launch + synchronise per key as the per-PDB
+ * loop of sample_with_multiprocessing (sampling_utils.py:164-197) would do.  A handle serialises its own calls. */
+typedef struct th_sampler th_sampler;
+int th_sampler_create(int device, th_sampler** out);
+void th_sampler_free(th_sampler* s);
+#define TH_TEMPER_NONE 0        /* rows used as they are (sample.py:40 skips apply_temp_to_probs at T == 1)        */
+#define TH_TEMPER_POW 1         /* q = p**(1/t), rows renormalised (sampling_utils.py:159-161)                      */
+#define TH_TEMPER_PREPOWERED 2  /* rows already hold p**(1/t) (powered by the caller's NumPy); rows renormalised    */
+/* probs [n_rows, n_cls] fp64 (host).  TH_TEMPER_POW: exponents 1, 2 and 0.5 are exact IEEE operations on the device
+ * (NumPy takes the same fast paths); any other exponent is raised on the HOST with libm pow() before the upload —
+ * device pow() is not correctly rounded and one ulp in q can move a residue index.  NumPy's own float64 `**` is libm
+ * pow() in its scalar loop but an SVML routine under AVX-512, which differs in the last bit for ~5 % of inputs: a
+ * caller that must reproduce one particular NumPy build bit for bit powers the rows itself and passes
+ * TH_TEMPER_PREPOWERED (design_utils.sampling_utils does).  The normaliser follows NumPy's pairwise summation order
+ * and the running sum is strictly sequential.  q_out (may be NULL) receives the tempered rows.
+ * cum_dtype (TH_F64, TH_F32 or TH_F16) is the type the running sum is rounded to after every addition: np.cumsum
+ * accumulates in the array's own dtype and the reference passes predict's float16 rows unconverted
+ * (sampling_utils.py:82,125); sample.py's own path is float64. */
+int th_sampler_load(th_sampler* s, const double* probs, int64_t n_rows, int n_cls, double temperature, int temper_mode,
+                    int cum_dtype, double* q_out);
+/* Key k owns rows [row_off[k], row_off[k+1]) of the loaded matrix (row_off has n_keys+1 ascending entries).  Draws are
+ * numbered in the reference's consumption order — for key: for sample: rand(n_res_key) (sampling_utils.py:118-125):
+ *   d(k, s, i) = n_samples*(row_off[k]-row_off[0]) + s*n_res_k + i
+ * which is the position of the draw's uniform in `uniforms` (TH_RNG_HOST) or in the device stream (offset by
+ * rng_offset), and of its result in idx_out / r_out / letters_out (each may be NULL).  cat_letters[n_cls] maps a
+ * category to its one-letter code.  metrics_out (may be NULL) receives, per sampled sequence in the same key-major
+ * order, [charge at pH 7.4, isoelectric point, molecular weight, molar extinction at 280 nm] — the tuple
+ * calculate_seq_metrics (design_utils/analyse_utils.py:351-371) appends to every sequence at sampling_utils.py:132;
+ * computed on the device from a 20-bin residue histogram per sequence (constants: ampal's published tables as
+ * restated in design_utils/analyse_utils.py — parity unpinned, ampal is not in the reference tree). */
+int th_sampler_draw(th_sampler* s, int64_t n_keys, const int64_t* row_off, int64_t n_samples, int rng_mode, uint64_t seed,
+                    uint64_t rng_offset, const double* uniforms, const char* cat_letters, int32_t* idx_out, double* r_out,
+                    char* letters_out, double* metrics_out);
 
 /* ---- text output: replaces np.savetxt(f, matrix, delimiter=",") — design_utils/utils.py:768-771 (float16
  * probabilities) and predict.py:145-146 (full-precision rotamer matrix).  Host code only.  Formats the row-major

@@ -75,6 +75,120 @@ def test_two_rank_gloo_gather_restores_map_order(tmp_path, n_total):
     assert f"ROOT_OK {n_total}" in r.stdout
 
 
+PREDICT_WORKER = textwrap.dedent("""
+    import os, sys, warnings
+    from pathlib import Path
+    sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "timed-design_amd")); sys.path.insert(0, os.path.join({root!r}, "tests"))
+    import torch.distributed as dist
+    from timed_hip import distributed as td
+    import predict, _oracle_model
+    warnings.simplefilter("ignore")
+    dist.init_process_group(backend="gloo")
+    out = Path({out!r})
+    res = predict.load_dataset_and_predict([Path({model!r})], {data!r}, batch_size={bs}, start_batch={start}, dataset_map_path=out / "datasetmap.txt",
+                                           path_to_output=out, frames_per_call={fpc}, model_loader=_oracle_model.load_model,
+                                           gather=td.GlooGather())
+    rank = dist.get_rank()
+    lo, hi = td.shard_bounds(26 - {start} * {bs}, 2)[rank]
+    assert sum(n for _d, n in _oracle_model.OracleModel.calls) == hi - lo, _oracle_model.OracleModel.calls
+    if rank == 0:
+        assert set(res[1]) == {{"1ubqA", "2xyz_0A", "2xyz_0B"}}
+        print("ROOT_WROTE", sorted(p.name for p in out.iterdir()))
+    else:
+        assert res[1] is None and len(res[0]) == 26
+    dist.barrier()
+    dist.destroy_process_group()
+""")
+
+
+@pytest.mark.parametrize("bs,fpc,start", [(7, 1024, 0), (3, 5, 0), (5, 10, 2)])
+def test_two_rank_predict_writes_the_same_bytes_as_one_rank(tmp_path, bs, fpc, start):
+    """The real predict.load_dataset_and_predict control flow on two gloo ranks (contiguous shards of the flat dataset
+    map, gather to rank 0, rank 0 writes) against the single-process run — every output file byte for byte.  The model
+    is the CPU oracle behind the HipFrameModel surface (tests/_oracle_model.py): no GPU here, and the product has no
+    CPU path of its own."""
+    import warnings
+    from pathlib import Path
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import predict
+    import _oracle_model
+    G = os.path.join(ROOT, "tests", "golden")
+    model, data = os.path.join(G, "keras_tiny.h5"), os.path.join(G, "frames_tiny.hdf5")
+    one, two = tmp_path / "one", tmp_path / "two"
+    one.mkdir(); two.mkdir()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        if start:      # a resumed run appends to what the first batches left behind: seed both directories alike
+            for d in (one, two):
+                predict.load_dataset_and_predict([Path(model)], data, batch_size=bs, dataset_map_path=d / "datasetmap.txt",
+                                                 path_to_output=d, model_loader=_oracle_model.load_model)
+                for fn in ("keras_tiny.csv", "encoded_labels.csv"):
+                    lines = (d / fn).read_text().splitlines(True)
+                    (d / fn).write_text("".join(lines[: start * bs]))
+        predict.load_dataset_and_predict([Path(model)], data, batch_size=bs, start_batch=start, dataset_map_path=one / "datasetmap.txt",
+                                         path_to_output=one, frames_per_call=fpc, model_loader=_oracle_model.load_model)
+    script = tmp_path / "worker.py"
+    script.write_text(PREDICT_WORKER.format(root=ROOT, out=str(two), model=model, data=data, bs=bs, fpc=fpc, start=start))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "ROOT_WROTE" in r.stdout
+    names = sorted(p.name for p in one.iterdir())
+    assert names == sorted(p.name for p in two.iterdir()) and "keras_tiny.csv" in names
+    for fn in names:
+        assert (one / fn).read_bytes() == (two / fn).read_bytes(), fn
+
+
+def test_in_process_multi_device_round_robin(tmp_path):
+    """devices=[...]: one handle per device in this process, call groups dealt round-robin, files unchanged"""
+    import warnings
+    from pathlib import Path
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import predict
+    import _oracle_model
+    G = os.path.join(ROOT, "tests", "golden")
+    model, data = os.path.join(G, "keras_tiny.h5"), os.path.join(G, "frames_tiny.hdf5")
+    a, b = tmp_path / "a", tmp_path / "b"
+    a.mkdir(); b.mkdir()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        predict.load_dataset_and_predict([Path(model)], data, batch_size=4, dataset_map_path=a / "datasetmap.txt", path_to_output=a,
+                                         frames_per_call=4, model_loader=_oracle_model.load_model)
+        _oracle_model.OracleModel.calls.clear()
+        predict.load_dataset_and_predict([Path(model)], data, batch_size=4, dataset_map_path=b / "datasetmap.txt", path_to_output=b,
+                                         frames_per_call=4, devices=[0, 1, 2], model_loader=_oracle_model.load_model)
+    assert [d for d, _n in _oracle_model.OracleModel.calls] == [0, 1, 2, 0, 1, 2, 0]
+    for fn in sorted(p.name for p in a.iterdir()):
+        assert (a / fn).read_bytes() == (b / fn).read_bytes(), fn
+
+
+@pytest.mark.gpu
+def test_sharded_predict_through_rccl_equals_plain_run(gpu, tmp_path):
+    """The shard + gather path of predict.py on the real engine with a 1-rank RCCL communicator: probabilities are
+    written by the kernels into a device shard buffer (TH_PREDICT_OUT_DEVICE), gathered with th_comm_gather_rows,
+    downloaded on rank 0 and written — same bytes as the plain run."""
+    import warnings
+    from pathlib import Path
+    import predict
+    G = os.path.join(ROOT, "tests", "golden")
+    model, data = Path(os.path.join(G, "keras_tiny.h5")), os.path.join(G, "frames_tiny.hdf5")
+    a, b = tmp_path / "a", tmp_path / "b"
+    a.mkdir(); b.mkdir()
+    comm = td.RcclGather(td.RcclGather.new_unique_id(), 1, 0, gpu)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        predict.load_dataset_and_predict([model], data, batch_size=6, dataset_map_path=a / "datasetmap.txt", path_to_output=a)
+        predict.load_dataset_and_predict([model], data, batch_size=6, dataset_map_path=b / "datasetmap.txt", path_to_output=b,
+                                         frames_per_call=8, gather=comm)
+    comm.close()
+    for fn in sorted(p.name for p in a.iterdir()):
+        assert (a / fn).read_bytes() == (b / fn).read_bytes(), fn
+
+
 @pytest.mark.gpu
 def test_rccl_transport_single_rank(gpu):
     """th_comm_* end to end with a 1-rank communicator: dlopen(librccl), init, gather (root's own

@@ -68,8 +68,11 @@ def test_unsupported_layers_fail_at_conversion_or_load(gpu):
 
 def test_sampler_argument_checks(gpu, lib):
     p = np.full((3, 20), 0.05)
-    with pytest.raises(_lib.TimedHipError):
-        sampler.sample_indices(p, 2, temperature=0.0, rng="philox")    # the reference divides by t (sampling_utils.py:159)
+    with pytest.raises(ZeroDivisionError):                             # what the reference raises: 1 / t (sampling_utils.py:159)
+        sampler.sample_indices(p, 2, temperature=0.0, rng="philox")
+    idx0 = np.zeros((2, 3), np.int32)
+    assert lib.th_sample(p.ctypes.data, 3, 20, 2, 0.0, 1, 0, None, idx0.ctypes.data) == -1   # the C ABI: TH_EINVAL
+    assert b"temperature 0" in lib.th_last_error()
     with pytest.raises(ValueError):
         sampler.sample_indices(p, 2, rng="host")                        # no uniforms
     with pytest.raises(ValueError):

@@ -32,10 +32,47 @@ def test_temperature_bit_exact_when_power_is_exact(gpu, sampler_golden, name, t)
 
 
 @pytest.mark.parametrize("name", CASES[:4])
-def test_temperature_generic_exponent(gpu, sampler_golden, name):
+@pytest.mark.parametrize("t", [0.1, 0.3, 0.7, 3.0])
+def test_temperature_generic_exponent_bit_exact(gpu, sampler_golden, name, t):
+    """Generic exponents: the Python layer raises the rows with NumPy's own `**` (what the reference executes,
+    sampling_utils.py:159) and the GPU normalises in NumPy's pairwise order -> bit-identical to the NumPy restatement
+    run on THIS host.  Against the fixture (generated on the build host, whose NumPy may pick another pow loop) the
+    bound is 2 ulp."""
     g = sampler_golden
-    got = sampler.apply_temperature(g[f"probs_{name}"], 0.1)
-    np.testing.assert_allclose(got, g[f"temp_{name}_t0.1"], rtol=1e-13, atol=1e-300)
+    p = g[f"probs_{name}"]
+    got = sampler.apply_temperature(p, t)
+    assert np.array_equal(got, so.apply_temp(p, t))
+    if f"temp_{name}_t{t}" in g.files:
+        np.testing.assert_allclose(got, g[f"temp_{name}_t{t}"], rtol=5e-16, atol=1e-300)
+
+
+def test_abi_generic_exponent_is_host_libm_pow(gpu, lib, sampler_golden):
+    """Through the bare C ABI (TH_TEMPER_POW) a generic exponent is raised with libm pow() on the host, never with the
+    device's pow: q equals math.pow element by element followed by NumPy's normaliser, bit for bit."""
+    import ctypes as C
+    import math
+    p = np.ascontiguousarray(sampler_golden["probs_dir20_f16"])
+    for t in (0.1, 0.7):
+        powered = np.array([math.pow(x, 1.0 / t) for x in p.ravel()]).reshape(p.shape)
+        want = powered / np.sum(powered, axis=1)[:, None]
+        out = np.empty_like(p)
+        assert lib.th_apply_temp_on(gpu, p.ctypes.data, p.shape[0], p.shape[1], t, out.ctypes.data) == 0
+        assert np.array_equal(out, want)
+        out2 = np.empty_like(p)
+        assert lib.th_apply_temp(p.ctypes.data, p.shape[0], p.shape[1], t, out2.ctypes.data) == 0
+        assert np.array_equal(out2, want)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_indices_bit_exact_at_low_temperature(gpu, sampler_golden, name):
+    """north star: bit-exact residue indices at every T, including T = 0.1 where the CDF is steep"""
+    g = sampler_golden
+    p, r = g[f"probs_{name}"], g[f"r_{name}_s42"]
+    for t in (0.1, 0.3):
+        with np.errstate(all="ignore"):
+            want = so.choice_indices(so.apply_temp(p, t), r)
+            got = sampler.sample_indices(p, r.shape[0], temperature=t, uniforms=r)
+        assert np.array_equal(got, want)
 
 
 def test_fused_temperature_draw_consistent(gpu, sampler_golden):
@@ -100,3 +137,127 @@ def test_config5_shape(gpu):
         idx, r = sampler.sample_indices(p, 1000, temperature=t, rng="mt19937", seed=42, return_uniforms=True)
         q = sampler.apply_temperature(p, t) if t != 1.0 else p
         assert np.array_equal(idx, so.choice_indices(q, r))
+
+
+# ---- resident sampler: every key of a run in one launch sequence ---------------------------------------------
+def _keys(rng, n_cls, sizes):
+    mats = [rng.dirichlet(np.full(n_cls, 0.3), size=n).astype(np.float16).astype(np.float64) for n in sizes]
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    return mats, off
+
+
+@pytest.mark.parametrize("n_cls", [20, 338])
+def test_batched_keys_equal_per_key_calls(gpu, n_cls):
+    rng = np.random.default_rng(11)
+    sizes = [7, 1, 64, 300, 13]
+    mats, off = _keys(rng, n_cls, sizes)
+    n_samples = 9
+    r = rng.random(n_samples * int(off[-1]))
+    sm = sampler.Sampler(gpu)
+    sm.load(np.concatenate(mats))
+    letters = "".join(chr(33 + (i % 90)) for i in range(n_cls))
+    d = sm.draw(off, n_samples, uniforms=r, letters=letters, want_uniforms=True)
+    assert np.array_equal(d["uniforms"], r)
+    for k, (m, idx, let) in enumerate(zip(mats, sm.split(d["idx"], off, n_samples), sm.split(d["letters"], off, n_samples))):
+        rk = r[n_samples * off[k]: n_samples * off[k + 1]].reshape(n_samples, -1)
+        assert np.array_equal(idx, so.choice_indices(m, rk))                      # the oracle, key by key
+        assert np.array_equal(idx, sampler.sample_indices(m, n_samples, uniforms=rk))
+        assert np.array_equal(let, np.array(list(letters), dtype="S1")[idx])
+    # a sub-range of keys draws from the same resident rows; the draw numbering restarts at its first key
+    sub = sm.draw(off[2:5], n_samples, uniforms=r[: n_samples * int(off[4] - off[2])])
+    assert np.array_equal(sm.split(sub["idx"], off[2:5], n_samples)[1],
+                          so.choice_indices(mats[3], r[n_samples * 64: n_samples * 364].reshape(n_samples, 300)))
+    # device generators number draws the same way: one stream across keys
+    for rng_name, ref in (("mt19937", so.legacy_uniforms), ("philox", so.philox_uniforms)):
+        dd = sm.draw(off, n_samples, rng=rng_name, seed=42, want_uniforms=True)
+        assert np.array_equal(dd["uniforms"], ref(42, n_samples * int(off[-1])))
+        for k, m in enumerate(mats):
+            rk = dd["uniforms"][n_samples * off[k]: n_samples * off[k + 1]].reshape(n_samples, -1)
+            assert np.array_equal(sm.split(dd["idx"], off, n_samples)[k], so.choice_indices(m, rk))
+    sm.close()
+
+
+def test_edge_rows_wide(gpu):
+    """338-wide rows take the bisection path only when their running sum is finite and non-decreasing; NaN rows, zero rows,
+    rows with a negative entry and rows summing to < r must give exactly NumPy's (cumsum > r).argmax() (0 when nothing
+    exceeds r — SURVEY Appendix C-5)."""
+    rng = np.random.default_rng(5)
+    p = rng.dirichlet(np.full(338, 0.05), size=40)
+    p[3] = 0.0
+    p[5, 17] = np.nan
+    p[7] *= 0.5                      # sums to 0.5: half of the draws fall through to index 0
+    p[9, 100] = -0.2                 # decreasing running sum
+    p[11, 337] = np.inf
+    r = rng.random((50, 40))
+    with np.errstate(all="ignore"):
+        want = so.choice_indices(p, r)
+        got = sampler.sample_indices(p, 50, uniforms=r)
+    assert np.array_equal(got, want)
+    assert (want[:, 7] == 0).sum() > 10
+
+
+@pytest.mark.parametrize("dtype", [np.float16, np.float32])
+def test_running_sum_in_input_dtype(gpu, sampler_golden, dtype):
+    """np.cumsum accumulates in the array's dtype: predict() returns float16 probabilities and the reference feeds them
+    unconverted to random_choice_prob_index (sampling_utils.py:82,125)."""
+    rng = np.random.default_rng(3)
+    p = rng.dirichlet(np.full(20, 0.3), size=500).astype(dtype)
+    r = rng.random((30, 500))
+    want = (p.cumsum(axis=1)[None] > r[:, :, None]).argmax(axis=2)           # the reference expression on the typed array
+    assert want.dtype == np.int64 and p.cumsum(axis=1).dtype == dtype
+    got = sampler.sample_indices(p, 30, uniforms=r, cum_dtype=dtype)
+    assert np.array_equal(got, want)
+    f64 = sampler.sample_indices(p, 30, uniforms=r)
+    if dtype == np.float16:
+        assert not np.array_equal(f64, want)                                   # the dtype matters: float64 sums differ
+
+
+def test_sequence_metrics_on_device_match_host_restatement(gpu):
+    """f-2: (charge, pI, MW, eps280) per sampled sequence from the 20-bin histogram kernel == the host restatement of
+    calculate_seq_metrics (design_utils/analyse_utils.py; ampal itself is absent: parity unpinned), bit for bit — both
+    accumulate in class order."""
+    from design_utils import analyse_utils as au
+    rng = np.random.default_rng(8)
+    sizes = [300, 5, 76, 1]
+    mats, off = _keys(rng, 20, sizes)
+    sm = sampler.Sampler(gpu)
+    sm.load(np.concatenate(mats))
+    d = sm.draw(off, 25, rng="philox", seed=1, letters="ACDEFGHIKLMNPQRSTVWY", want_metrics=True)
+    assert d["metrics"].shape == (4 * 25, 4)
+    for k in range(4):
+        seqs = [row.tobytes().decode() for row in sm.split(d["letters"], off, 25)[k]]
+        want = au.seq_metrics_batch(seqs)
+        got = d["metrics"][k * 25:(k + 1) * 25]
+        assert np.array_equal(got[:, 1:], want[:, 1:])                          # pI grid value, mass, extinction: exact
+        np.testing.assert_allclose(got[:, 0], want[:, 0], rtol=1e-14, atol=1e-15)
+        assert np.array_equal(got[:, 0], want[:, 0])
+    # letters outside the 20 standard residues are not counted
+    d2 = sm.draw(off[:2], 3, rng="philox", seed=1, letters="XCDEFGHIKLMNPQRSTVWY", want_metrics=True)
+    seqs = [row.tobytes().decode() for row in sm.split(d2["letters"], off[:2], 3)[0]]
+    assert np.array_equal(d2["metrics"], au.seq_metrics_batch(seqs))
+    sm.close()
+
+
+def test_sample_with_multiprocessing_is_one_stream_in_key_order(gpu):
+    """reference sampling_utils.py:164-197 / :118-125 replayed under np.random.seed: for key: for sample: rand(n_res)"""
+    from design_utils import sampling_utils as su
+    rng = np.random.default_rng(2)
+    sizes = dict(a=12, b=300, c=1)
+    p2p = {k: [list(row) for row in rng.dirichlet(np.full(20, 0.3), size=n)] for k, n in sizes.items()}
+    np.random.seed(42)
+    out = su.sample_with_multiprocessing(8, list(p2p), 5, p2p, None)
+    stream = so.legacy_uniforms(42, 5 * sum(sizes.values()))
+    letters = np.array(list("ACDEFGHIKLMNPQRSTVWY"))
+    pos = 0
+    for k, n in sizes.items():
+        r = stream[pos:pos + 5 * n].reshape(5, n)
+        pos += 5 * n
+        want = ["".join(letters[i]) for i in so.choice_indices(np.array(p2p[k]), r)]
+        assert [t[0] for t in out[k]] == want
+        assert all(len(t) == 5 and isinstance(t[4], int) for t in out[k])
+    assert list(out) == list(p2p)
+    np.random.seed(42)
+    one = su.sample_from_sequences("a", 5, p2p, None)
+    assert one["a"] == out["a"]
+    with pytest.raises(ValueError):
+        su.sample_with_multiprocessing(1, ["z"], 2, {"z": []}, None)

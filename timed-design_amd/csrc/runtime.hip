@@ -939,13 +939,14 @@ int th_predict_async(th_model* m, const void* frames, int dtype, int64_t n, floa
         m->in_ring_bytes = need_in;
     }
     const size_t floats = (size_t)n * width;
-    if (t.d_out_floats < floats) {
+    const bool out_on_device = (flags & TH_PREDICT_OUT_DEVICE) != 0;   // probs_out is device memory: no copy back
+    if (!out_on_device && t.d_out_floats < floats) {
         if (t.d_out) HIP_TRY(hipFree(t.d_out));
         t.d_out = nullptr; t.d_out_floats = 0;
         HIP_TRY(hipMalloc(&t.d_out, std::max<size_t>(floats, 1024) * sizeof(float)));
         t.d_out_floats = std::max<size_t>(floats, 1024);
     }
-    if (t.h_out_floats < floats) {
+    if (!out_on_device && t.h_out_floats < floats) {
         if (t.h_out) HIP_TRY(hipHostFree(t.h_out));
         t.h_out = nullptr; t.h_out_floats = 0;
         HIP_TRY(hipHostMalloc((void**)&t.h_out, std::max<size_t>(floats, 1024) * sizeof(float), hipHostMallocDefault));
@@ -964,7 +965,8 @@ int th_predict_async(th_model* m, const void* frames, int dtype, int64_t n, floa
                                hipMemcpyHostToDevice, m->copy_stream));
         HIP_TRY(hipEventRecord(m->ev_h2d[r], m->copy_stream));
         HIP_TRY(hipStreamWaitEvent(m->stream, m->ev_h2d[r], 0));
-        int rc = run_device(m, m->d_in_ring[r], dtype, cnt, t.d_out + (size_t)off * width, flags, /*sync=*/false);
+        int rc = run_device(m, m->d_in_ring[r], dtype, cnt, (out_on_device ? probs_out : t.d_out) + (size_t)off * width, flags,
+                            /*sync=*/false);
         if (rc) return rc;
         HIP_TRY(hipEventRecord(m->ev_free[r], m->stream));
         m->ring_used[r] = true;
@@ -972,10 +974,11 @@ int th_predict_async(th_model* m, const void* frames, int dtype, int64_t n, floa
     }
     HIP_TRY(hipEventRecord(t.computed, m->stream));
     HIP_TRY(hipStreamWaitEvent(m->d2h_stream, t.computed, 0));
-    if (floats) HIP_TRY(hipMemcpyAsync(t.h_out, t.d_out, floats * sizeof(float), hipMemcpyDeviceToHost, m->d2h_stream));
+    if (floats && !out_on_device)
+        HIP_TRY(hipMemcpyAsync(t.h_out, t.d_out, floats * sizeof(float), hipMemcpyDeviceToHost, m->d2h_stream));
     HIP_TRY(hipEventRecord(t.done, m->d2h_stream));
     t.user_out = probs_out;
-    t.floats = floats;
+    t.floats = out_on_device ? 0 : floats;
     t.busy = true;
     *ticket = ti;
     return TH_OK;
@@ -1111,6 +1114,10 @@ int th_dev_synth_frames(int device, float* d_frames, int64_t n, int side, int ch
 int th_apply_temp(const double* probs, int64_t n_res, int n_cls, double t, double* out) {
     if (!out) TH_FAIL(TH_EINVAL, "null argument");
     return sampler_run(0, probs, n_res, n_cls, 0, t, TH_RNG_PHILOX, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, out);
+}
+int th_apply_temp_on(int device, const double* probs, int64_t n_res, int n_cls, double t, double* out) {
+    if (!out) TH_FAIL(TH_EINVAL, "null argument");
+    return sampler_run(device, probs, n_res, n_cls, 0, t, TH_RNG_PHILOX, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, out);
 }
 int th_sample(const double* probs, int64_t n_res, int n_cls, int64_t n_samples, double temperature, int rng_mode,
               uint64_t seed, const double* uniforms, int32_t* idx_out) {

@@ -58,8 +58,12 @@ __device__ double np_pairwise_sum(const double* a, int n) {
 //   mode 0 (TH_TEMPER_NONE): rows used as they are;   1: q = x**e here (e in {1, 2, 0.5} — exact IEEE ops, the same
 //   fast paths NumPy takes);   2: rows already hold x**e (host pow);   modes 1, 2 renormalise.
 // flags[row] bit 0: the running sum is finite and non-decreasing (k_draw may then bisect instead of scanning).
+// cum_dtype: the running sum is rounded to this type after every addition (TH_F64 / TH_F32 / TH_F16) — np.cumsum
+// accumulates in the array's own dtype, and the reference hands float16 rows straight from predict's
+// pdb_to_probability to random_choice_prob_index (sampling_utils.py:82,125); float16 adds go through float like
+// NumPy's HALF_add loop.  The comparison with r stays fp64 (NumPy promotes).
 __global__ void __launch_bounds__(64) k_temper_cumsum(const double* __restrict__ p, int64_t n_res, int n_cls, double e, int mode,
-                                                      int rows_per_wg, double* __restrict__ q, double* __restrict__ c,
+                                                      int cum_dtype, int rows_per_wg, double* __restrict__ q, double* __restrict__ c,
                                                       unsigned char* __restrict__ flags) {
     extern __shared__ double lds[];
     const int ld = n_cls | 1;
@@ -80,7 +84,9 @@ __global__ void __launch_bounds__(64) k_temper_cumsum(const double* __restrict__
         double run = 0.;
         bool mono = true;
         for (int j = 0; j < n_cls; ++j) {
-            const double nx = (j == 0) ? qr[0] : run + qr[j];
+            double nx = (j == 0) ? qr[0] : run + qr[j];
+            if (cum_dtype == TH_F32) nx = (j == 0) ? qr[0] : (double)((float)run + (float)qr[j]);
+            else if (cum_dtype == TH_F16) nx = (j == 0) ? qr[0] : (double)(_Float16)((float)(_Float16)run + (float)(_Float16)qr[j]);
             mono = mono && (nx >= run || j == 0) && (nx - nx == 0.0);   // finite and not decreasing
             run = nx;
             cr[j] = run;
@@ -159,6 +165,7 @@ struct MetricTables {
 __global__ void __launch_bounds__(256) k_seq_metrics(const char* __restrict__ letters, const int64_t* __restrict__ row_off,
                                                      int n_keys, int64_t n_samples, const MetricTables* __restrict__ T,
                                                      double* __restrict__ out) {
+#pragma clang fp contract(off)       // separate multiply and add, like the host restatement (no FMA contraction)
     __shared__ int hist[4][20];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t seq = (int64_t)blockIdx.x * 4 + wave;          // sequence number: key-major, then sample
@@ -309,7 +316,8 @@ void build_metric_tables(MetricTables* T) {
     for (int c = 0; c < 20; ++c) { T->mass[c] = kMass[c]; T->ext[c] = kExt[c]; }
     T->water = kWater;
     for (int g = 0; g < kGrid; ++g) {
-        T->grid[g] = 1.0 + g * 0.1;            // np.arange(1, 13, 0.1)[g] = start + g*step
+        const volatile double first = 1.0, next = 1.0 + 0.1;
+        T->grid[g] = first + g * (next - first);   // np.arange(1, 13, 0.1) fills first + i*delta, delta = (start+step)-start
         fill(T->grid[g], T->tab[g], &T->term[g]);
     }
 }
@@ -331,8 +339,9 @@ struct th_sampler {
 
 namespace {
 
-int sampler_load(th_sampler* S, const double* probs, int64_t n_rows, int n_cls, double t, int mode, double* q_out) {
+int sampler_load(th_sampler* S, const double* probs, int64_t n_rows, int n_cls, double t, int mode, int cum_dtype, double* q_out) {
     if (!S || !probs || n_rows <= 0 || n_cls <= 0) TH_FAIL(TH_EINVAL, "th_sampler_load: bad shape");
+    if (cum_dtype != TH_F64 && cum_dtype != TH_F32 && cum_dtype != TH_F16) TH_FAIL(TH_EINVAL, "th_sampler_load: running-sum dtype %d", cum_dtype);
     if (mode < TH_TEMPER_NONE || mode > TH_TEMPER_PREPOWERED) TH_FAIL(TH_EINVAL, "th_sampler_load: temper mode %d", mode);
     if (mode != TH_TEMPER_NONE && t == 0.0)
         TH_FAIL(TH_EINVAL, "th_sample: temperature 0 (the reference divides by it: sampling_utils.py:159)");
@@ -368,7 +377,7 @@ int sampler_load(th_sampler* S, const double* probs, int64_t n_rows, int n_cls, 
     }
     if (lds > 160 * 1024) TH_FAIL(TH_EUNSUP, "th_sampler_load: %d categories per row exceed the LDS budget", n_cls);
     hipLaunchKernelGGL(k_temper_cumsum, dim3((unsigned)((n_rows + rows - 1) / rows)), dim3(64), lds, S->stream,
-                       (const double*)S->dp.p, n_rows, n_cls, e, kmode, rows, (double*)S->dq.p, (double*)S->dc.p,
+                       (const double*)S->dp.p, n_rows, n_cls, e, kmode, cum_dtype, rows, (double*)S->dq.p, (double*)S->dc.p,
                        (unsigned char*)S->dflags.p);
     HIP_TRY(hipGetLastError());
     if (q_out) HIP_TRY(hipMemcpyAsync(q_out, S->dq.p, bytes, hipMemcpyDeviceToHost, S->stream));
@@ -490,10 +499,10 @@ void th_sampler_free(th_sampler* s) {
 }
 
 int th_sampler_load(th_sampler* s, const double* probs, int64_t n_rows, int n_cls, double temperature, int temper_mode,
-                    double* q_out) {
+                    int cum_dtype, double* q_out) {
     if (!s) TH_FAIL(TH_EINVAL, "null sampler");
     std::lock_guard<std::mutex> lock(s->mu);
-    return sampler_load(s, probs, n_rows, n_cls, temperature, temper_mode, q_out);
+    return sampler_load(s, probs, n_rows, n_cls, temperature, temper_mode, cum_dtype, q_out);
 }
 
 int th_sampler_draw(th_sampler* s, int64_t n_keys, const int64_t* row_off, int64_t n_samples, int rng_mode, uint64_t seed,
@@ -522,7 +531,7 @@ int sampler_run(int device, const double* h_probs, int64_t n_res, int n_cls, int
     // sample.py:40 skips apply_temp_to_probs when t == 1 (rows stay un-normalised); apply_temp_to_probs itself
     // (n_samples == 0 with q_out) always renormalises, also at t == 1 where x**1.0 is x.
     const bool apply = temperature != 1.0 || (n_samples == 0 && h_q_out);
-    int rc = sampler_load(S, h_probs, n_res, n_cls, temperature, apply ? TH_TEMPER_POW : TH_TEMPER_NONE, h_q_out);
+    int rc = sampler_load(S, h_probs, n_res, n_cls, temperature, apply ? TH_TEMPER_POW : TH_TEMPER_NONE, TH_F64, h_q_out);
     if (rc || n_samples == 0) return rc;
     const int64_t row_off[2] = {0, n_res};
     return sampler_draw(S, 1, row_off, n_samples, rng_mode, seed, rng_offset, h_uniforms, cat_letters, h_idx, h_r_out,

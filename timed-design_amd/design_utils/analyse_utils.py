@@ -13,6 +13,7 @@ sampling_utils.py:132, where it dominates wall time — SURVEY.md §8 row f-2).
 """
 from __future__ import annotations
 
+import math
 import typing as t
 
 import numpy as np
@@ -38,28 +39,45 @@ except Exception:  # ImportError or a broken optional dependency
 
 
 def _partial(pka: float, sign: int, ph) -> np.ndarray:
-    diff = np.asarray(ph, dtype=float) - pka
-    if sign > 0:
-        diff = -diff
-    r = 10.0 ** diff
-    return r / (1.0 + r)
+    """ampal's partial_charge: 10**d / (1 + 10**d), d = pH - pKa (negated for basic groups).  ampal evaluates it with
+    Python floats, i.e. libm pow — so does this (NumPy's vectorised power may round differently) and so does the table
+    the device kernel uses (csrc/sampler.hip build_metric_tables)."""
+    out = []
+    for p in np.atleast_1d(np.asarray(ph, dtype=float)):
+        diff = float(p) - pka
+        if sign > 0:
+            diff = -diff
+        r = math.pow(10.0, diff)
+        out.append(r / (1.0 + r))
+    return np.array(out)
 
 
-def _charge_from_counts(counts: np.ndarray, ph) -> np.ndarray:
-    """counts [n_seq, 20] -> net charge [n_seq, len(ph)]"""
+def _charge_table(ph) -> t.Tuple[np.ndarray, np.ndarray]:
+    """signed partial charge of one residue of each class (alphabetical order) and of the two termini at each pH"""
     ph = np.atleast_1d(np.asarray(ph, dtype=float))
     per_res = np.zeros((20, ph.size))
     for aa, sign in _CHARGE.items():
         per_res[_AA.index(aa)] = _partial(_PKA[aa], sign, ph) * sign
-    term = sum(_partial(_PKA_TERM[k], s, ph) * s for k, s in _CHARGE_TERM.items())
-    return counts @ per_res + term[None, :]
+    term = _partial(_PKA_TERM["N-term"], +1, ph) * (+1) + _partial(_PKA_TERM["C-term"], -1, ph) * (-1)
+    return per_res, term
 
 
-def seq_metrics_batch(seqs: t.Sequence[str]) -> np.ndarray:
-    """[n_seq, 4] = (charge at pH 7.4, isoelectric point, molecular weight, molar extinction at 280)."""
-    if sequence_charge is not None:  # pragma: no cover
-        return np.array([[sequence_charge(s), sequence_isoelectric_point(s), sequence_molecular_weight(s),
-                          sequence_molar_extinction_280(s)] for s in seqs], dtype=float)
+def _dot_in_class_order(counts: np.ndarray, table: np.ndarray) -> np.ndarray:
+    """sum_c counts[:, c] * table[c] accumulated strictly in class order (c = 0..19) — the order the device kernel
+    (csrc/sampler.hip k_seq_metrics) uses, so that the two agree bit for bit (a BLAS dot would not)."""
+    acc = np.zeros((counts.shape[0],) + table.shape[1:])
+    for c in range(20):
+        acc = acc + counts[:, c].reshape((-1,) + (1,) * (table.ndim - 1)) * table[c]
+    return acc
+
+
+def _charge_from_counts(counts: np.ndarray, ph) -> np.ndarray:
+    """counts [n_seq, 20] -> net charge [n_seq, len(ph)]"""
+    per_res, term = _charge_table(ph)
+    return _dot_in_class_order(counts, per_res) + term[None, :]
+
+
+def residue_counts(seqs: t.Sequence[str]) -> np.ndarray:
     lut = np.full(256, -1, dtype=np.int64)
     for i, a in enumerate(_AA):
         lut[ord(a)] = i
@@ -67,15 +85,24 @@ def seq_metrics_batch(seqs: t.Sequence[str]) -> np.ndarray:
     for k, s in enumerate(seqs):
         idx = lut[np.frombuffer(s.encode("ascii"), dtype=np.uint8)]
         counts[k] = np.bincount(idx[idx >= 0], minlength=20)
-    grid = np.arange(1, 13, 0.1)
+    return counts
+
+
+def seq_metrics_batch(seqs: t.Sequence[str]) -> np.ndarray:
+    """[n_seq, 4] = (charge at pH 7.4, isoelectric point, molecular weight, molar extinction at 280)."""
+    if sequence_charge is not None:  # pragma: no cover
+        return np.array([[sequence_charge(s), sequence_isoelectric_point(s), sequence_molecular_weight(s),
+                          sequence_molar_extinction_280(s)] for s in seqs], dtype=float)
+    counts = residue_counts(seqs)
+    grid = np.arange(1, 13, 0.1)                # NumPy fills first + i*((1 + 0.1) - 1): 120 points
     charge = _charge_from_counts(counts, [7.4])[:, 0]
     pi = grid[np.abs(_charge_from_counts(counts, grid)).argmin(axis=1)]
-    mw = counts @ np.array([_MWT[a] for a in _AA]) + _WATER
-    ext = counts @ np.array([_EXT280.get(a, 0) for a in _AA])
+    mw = _dot_in_class_order(counts, np.array([_MWT[a] for a in _AA])) + _WATER
+    ext = _dot_in_class_order(counts, np.array([float(_EXT280.get(a, 0)) for a in _AA]))
     return np.stack([charge, pi, mw, ext], axis=1)
 
 
 def calculate_seq_metrics(seq: str) -> t.Tuple[float, float, float, float]:
     """reference analyse_utils.py:351-371 -> (charge, iso_ph, mw, me)."""
     c, p, m, e = seq_metrics_batch([seq])[0]
-    return float(c), float(p), float(m), float(e)
+    return float(c), float(p), float(m), int(e) if float(e).is_integer() else float(e)

@@ -10,8 +10,8 @@ Randomness: like the reference, the uniforms come from NumPy's GLOBAL legacy gen
 (``np.random.rand``, reference :81), drawn in the reference's order, so after ``np.random.seed(s)``
 every function here returns what the reference returns — bit-exact residue indices.  (The
 reference never seeds it — its ``--seed`` is inert; our sample.py does.)
-``sample_from_sequences`` draws all ``sample_n`` sequences of a PDB in ONE launch
-([sample_n, n_res] uniforms — the same stream the reference's per-sample loop consumes).
+``sample_with_multiprocessing`` draws every sequence of every PDB key in ONE launch sequence on a resident
+sampler (th_sampler_load / th_sampler_draw), including the per-sequence metrics of calculate_seq_metrics.
 """
 from __future__ import annotations
 
@@ -23,39 +23,47 @@ import numpy as np
 from timed_hip import sampler as _sampler
 
 from .amino_acids import standard_amino_acids
-from .analyse_utils import seq_metrics_batch
+from .analyse_utils import METRICS_SOURCE, seq_metrics_batch
 
 _LETTERS20 = "".join(standard_amino_acids.keys())
+_CUM_DTYPES = (np.dtype(np.float16), np.dtype(np.float32), np.dtype(np.float64))
+
+
+# ---- writers ------------------------------------------------------------------------------------------------
+# Output formats of reference sampling_utils.py:12-50, as data: (suffix, selected-by, row writer).
+def _emit_json(fh, pdb_to_sampled):
+    json.dump(pdb_to_sampled, fh)
+
+
+def _emit_fasta(fh, pdb_to_sampled):
+    fh.writelines(f">{pdb}_{n}\n{rec[0]}\n" for pdb, recs in pdb_to_sampled.items() for n, rec in enumerate(recs))
+
+
+_METRIC_COLUMNS = ("pdb", "sequence", "charge", "isoelectric_point", "molecular_weight", "molar_extinction")
+
+
+def _emit_metrics(fh, pdb_to_sampled):
+    fh.write(",".join(_METRIC_COLUMNS) + "\n")
+    fh.writelines(",".join(str(v) for v in (pdb, *rec[:5])) + "\n" for pdb, recs in pdb_to_sampled.items() for rec in recs)
+
+
+# a sequence file is written unless the mode names the OTHER sequence format ("all", or anything else, selects both)
+_SEQUENCE_OUTPUTS = ((".json", "fasta", _emit_json), (".fasta", "json", _emit_fasta))
 
 
 def save_as(pdb_to_sampled: dict, filename: str, mode: str):
-    """reference sampling_utils.py:12-50: .json (unless mode=='fasta'), .fasta (unless 'json'), and
-    always ``_metrics.csv``.  Returns the written paths in that order."""
-    output_paths = []
-    print(f"Saving sampled sequences in mode {mode}")
-    if mode != "fasta":
-        outfile_path = f"{filename}.json"
-        output_paths.append(outfile_path)
-        with open(outfile_path, "w") as outfile:
-            json.dump(pdb_to_sampled, outfile)
-    if mode != "json":
-        outfile_path = f"{filename}.fasta"
-        output_paths.append(outfile_path)
-        with open(outfile_path, "w") as outfile:
-            for pdb, seq_list in pdb_to_sampled.items():
-                for i, seq in enumerate(seq_list):
-                    outfile.write(f">{pdb}_{i}\n{seq[0]}\n")
-    print("Saving Metrics")
-    outfile_path = f"{filename}_metrics.csv"
-    output_paths.append(outfile_path)
-    with open(outfile_path, "w") as outfile:
-        outfile.write("pdb,sequence,charge,isoelectric_point,molecular_weight,molar_extinction\n")
-        for pdb, seq_list in pdb_to_sampled.items():
-            for seq in seq_list:
-                outfile.write(f"{pdb},{seq[0]},{seq[1]},{seq[2]},{seq[3]},{seq[4]}\n")
-    return output_paths
+    """reference sampling_utils.py:12-50: ``<filename>.json`` unless mode == "fasta", ``<filename>.fasta`` unless
+    mode == "json", and always ``<filename>_metrics.csv``; returns the paths in that order."""
+    jobs = [(filename + suffix, emit) for suffix, skipped_by, emit in _SEQUENCE_OUTPUTS if mode != skipped_by]
+    jobs.append((filename + "_metrics.csv", _emit_metrics))
+    print(f"Writing {len(jobs)} output file(s) for {len(pdb_to_sampled)} structure(s) (mode={mode})")
+    for path, emit in jobs:
+        with open(path, "w") as fh:
+            emit(fh, pdb_to_sampled)
+    return [path for path, _ in jobs]
 
 
+# ---- sampling -----------------------------------------------------------------------------------------------
 def _category_letters(rotamer_categories, n_cls: int) -> np.ndarray:
     if rotamer_categories is not None and len(rotamer_categories):
         res = np.array(rotamer_categories)
@@ -66,6 +74,12 @@ def _category_letters(rotamer_categories, n_cls: int) -> np.ndarray:
     return res
 
 
+def _cum_dtype(a: np.ndarray):
+    """np.cumsum accumulates in the array's dtype (reference :82): float16/float32 rows keep their running sum in
+    that type on the GPU too; everything else is float64 like NumPy's promotion of ints/bools would make it."""
+    return a.dtype if a.dtype in _CUM_DTYPES else np.dtype(np.float64)
+
+
 def random_choice_prob_index(
     probs: np.ndarray,
     axis: int = 1,
@@ -74,13 +88,56 @@ def random_choice_prob_index(
 ) -> np.ndarray:
     """reference sampling_utils.py:53-90: one uniform per residue from np.random.rand, inverse CDF
     (first index whose running sum exceeds r, 0 if none) — computed on the GPU."""
-    probs = np.asarray(probs, dtype=np.float64)
+    probs = np.asarray(probs)
     p = probs if axis == 1 else probs.T
     r = np.random.rand(p.shape[0])
-    idxs = _sampler.sample_indices(p, 1, uniforms=r[None, :])[0].astype(np.int64)
+    idxs = _sampler.sample_indices(p, 1, uniforms=r[None, :], cum_dtype=_cum_dtype(p))[0].astype(np.int64)
     if return_seq:
         return _category_letters(rotamer_categories, p.shape[1])[idxs]
     return idxs
+
+
+def _sample_keys(keys, sample_n: int, pdb_to_probability: dict, rotamer_categories, device: int = 0) -> dict:
+    """All ``keys`` in ONE resident-sampler pass: rows of every key concatenated and uploaded once, one draw launch
+    over (key, sample, residue), metrics reduced on the device, three arrays copied back.  Uniforms come from the
+    global legacy generator in the reference's order — for key: for sample: rand(n_res) — which one rand() call of the
+    total length reproduces exactly (the stream is consumed value by value)."""
+    keys = list(keys)
+    if not keys:
+        return {}
+    mats = [np.array(pdb_to_probability[k]) for k in keys]          # what the reference builds per sample (:125)
+    for k, m in zip(keys, mats):
+        if m.ndim != 2 or m.shape[0] == 0:
+            raise ValueError(f"{k}: expected a non-empty (n_residues, n_categories) probability matrix, got shape {m.shape}")
+    n_cls = mats[0].shape[1]
+    if any(m.shape[1] != n_cls for m in mats):
+        raise ValueError("all keys must have the same number of categories")
+    cum = _cum_dtype(mats[0]) if all(m.dtype == mats[0].dtype for m in mats) else np.dtype(np.float64)
+    row_off = np.concatenate([[0], np.cumsum([m.shape[0] for m in mats])]).astype(np.int64)
+    cats = _category_letters(rotamer_categories, n_cls)
+    one_letter = all(len(c) == 1 for c in cats[:n_cls])
+    r = np.random.rand(int(sample_n) * int(row_off[-1]))
+    sm = _sampler.default_sampler(device)
+    sm.load(np.concatenate(mats).astype(np.float64), cum_dtype=cum)
+    on_device = one_letter and METRICS_SOURCE != "ampal"
+    d = sm.draw(row_off, sample_n, uniforms=r, letters="".join(cats[:n_cls]) if one_letter else None,
+                want_idx=not one_letter, want_metrics=on_device)
+    out = {}
+    for k, key in enumerate(keys):
+        lo, hi = int(row_off[k]), int(row_off[k + 1])
+        if one_letter:
+            block = d["letters"][sample_n * lo: sample_n * hi].reshape(sample_n, hi - lo)
+            seqs = [row.tobytes().decode("ascii") for row in block]
+        else:   # multi-character category names (full rotamer labels): join on the host like the reference
+            block = d["idx"][sample_n * lo: sample_n * hi].reshape(sample_n, hi - lo)
+            seqs = ["".join(cats[row]) for row in block]
+        if on_device:
+            met = d["metrics"][k * sample_n: (k + 1) * sample_n]
+        else:
+            met = seq_metrics_batch(seqs) if seqs else np.empty((0, 4))
+        out[key] = [(s, float(m[0]), float(m[1]), float(m[2]), int(m[3]) if float(m[3]).is_integer() else float(m[3]))
+                    for s, m in zip(seqs, met)]
+    return out
 
 
 def sample_from_sequences(
@@ -90,31 +147,19 @@ def sample_from_sequences(
     rotamer_categories: t.Optional[np.ndarray],
 ) -> dict:
     """reference sampling_utils.py:93-136 -> {pdb: [(seq, charge, pI, MW, eps280), ...]}."""
-    probs = np.array(pdb_to_probability[pdb], dtype=np.float64)
-    n_res, n_cls = probs.shape
-    cats = _category_letters(rotamer_categories, n_cls)
-    r = np.random.rand(sample_n, n_res) if sample_n else np.empty((0, n_res))
-    if all(len(c) == 1 for c in cats[:n_cls]):
-        _, letters = _sampler.sample_indices(probs, sample_n, uniforms=r, letters="".join(cats[:n_cls]))
-        seqs = [row.tobytes().decode("ascii") for row in letters]
-    else:  # multi-character category names (full rotamer labels): join on the host like the reference
-        idx = _sampler.sample_indices(probs, sample_n, uniforms=r)
-        seqs = ["".join(cats[row]) for row in idx]
-    metrics = seq_metrics_batch(seqs) if seqs else np.empty((0, 4))
-    return {pdb: [(s, *(float(x) for x in m)) for s, m in zip(seqs, metrics)]}
+    return _sample_keys([pdb], sample_n, pdb_to_probability, rotamer_categories)
 
 
 def apply_temp_to_probs(probs: np.ndarray, t: float = 1.0):
-    """reference sampling_utils.py:139-161: probs**(1/t), rows renormalised — on the GPU, fp64."""
+    """reference sampling_utils.py:139-161: probs**(1/t), rows renormalised, fp64.  The power is NumPy's own ``**``
+    for generic exponents (bit-identical to the reference on any host), square/sqrt/copy on the GPU for t in
+    {0.5, 2, 1}; the pairwise-order normaliser runs on the GPU."""
     return _sampler.apply_temperature(np.array(probs, dtype=np.float64), t)
 
 
 def sample_with_multiprocessing(workers, pdb_codes, sample_n, pdb_to_probability, flat_categories):
-    """reference sampling_utils.py:164-197.  The reference fans PDB keys over a process Pool (every
-    forked worker inherits the SAME generator state, so different PDBs can receive identical uniform
-    streams — Appendix C-1).  Here the keys run in order in this process, one fused launch each, and
-    consume one continuous stream; ``workers`` is accepted and ignored."""
-    pdb_to_sample = {}
-    for pdb in pdb_codes:
-        pdb_to_sample.update(sample_from_sequences(pdb, sample_n, pdb_to_probability, flat_categories))
-    return pdb_to_sample
+    """reference sampling_utils.py:164-197.  The reference fans PDB keys over a process Pool (every forked worker
+    inherits the SAME generator state, so different PDBs can receive identical uniform streams — Appendix C-1).  Here
+    all keys are drawn together on the GPU from one continuous stream in key order; ``workers`` is accepted and
+    ignored."""
+    return _sample_keys(pdb_codes, sample_n, pdb_to_probability, flat_categories)

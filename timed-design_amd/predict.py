@@ -1,40 +1,119 @@
-"""predict.py — same command line, function signature and output files as the reference's
-predict.py, with the Keras model object replaced by the HIP engine:
+"""predict.py — the reference's command line, ``load_dataset_and_predict`` signature and output files, with the Keras
+model object replaced by the HIP engine and the strictly sequential batch loop replaced by a pipeline:
 
     reference predict.py:121   frame_model = tf.keras.models.load_model(Path(m))
     reference predict.py:142   y_pred_batch = frame_model.predict(X_batch)
-    here                       frame_model = timed_hip.engine.load_model(m); frame_model.predict(X_batch)
+    here                       engine.load_model(m) ; frame_model.predict_async(X) ... .result()
 
     python3 predict.py --path_to_dataset data.hdf5 --path_to_model TIMED.h5 --path_to_output .
 
-``--path_to_model`` takes a Keras legacy ``.h5`` (converted on the fly) or a ``.pack``.  Outputs
-(reference README.md:119-131): <model>.csv, <model>.fasta, <model>.txt, dataset.fasta, datasetmap.txt,
-encoded_labels.csv, plus <model>_rot.csv in rotamer mode.
+``--path_to_model`` takes a Keras legacy ``.h5`` (converted on the fly) or a ``.pack``; ``--path_to_dataset`` an
+aposteriori ``.hdf5`` or a frame pack.  Outputs (reference README.md:119-131): <model>.csv, <model>.fasta, <model>.txt,
+dataset.fasta, datasetmap.txt, encoded_labels.csv, plus <model>_rot.csv in rotamer mode.
+
+How a run is organised (all of it invisible in the files, which are byte-identical to a batch-by-batch run):
+  * consecutive reference batches are grouped into GPU calls of about ``frames_per_call`` frames;
+  * a loader thread builds group g+1 (reference load_batch, utils.py:487-530) while the GPU computes group g and the
+    main thread formats and appends the outputs of group g-1 (th_predict_async / th_predict_wait);
+  * ``devices=[0, 1, ...]`` (``--devices 0,1``): one model handle per GPU in this process, groups dealt round-robin;
+  * under ``torch.distributed.run`` (WORLD_SIZE > 1, one process per GPU): the flat dataset map is cut into contiguous
+    per-rank shards, every rank predicts its shard into device memory, ONE gather (RCCL over xGMI, th_comm_gather_rows)
+    assembles the [N, n_classes] matrix on rank 0, which writes every file; other ranks return only the dataset map.
 
 Deliberate differences from the reference: the raw rotamer probabilities go to
-``<model_name>_rot.csv`` (the reference's missing f-string writes a file literally called
-"{model_name}_rot.csv", predict.py:123 — the UI and scripts expect the real name); the consensus
-fasta honours --path_to_output.  Extra, opt-in flags: --device.
+``<model_name>_rot.csv`` (the reference's missing f-string writes a file literally called "{model_name}_rot.csv",
+predict.py:123 — the UI and scripts expect the real name); the consensus files honour --path_to_output.
 """
 import argparse
+import os
+import sys
+from collections import deque
+from concurrent.futures import ThreadPoolExecutor
 from math import ceil
 from pathlib import Path
 
 import numpy as np
-from numpy import genfromtxt
 
-from design_utils.utils import (
-    convert_dataset_map_for_srb,
-    create_flat_dataset_map,
-    extract_sequence_from_pred_matrix,
-    get_pdb_keys_to_filter,
-    get_rotamer_codec,
-    load_batch,
-    save_consensus_probs,
-    save_dict_to_fasta,
-    save_outputs_to_file,
-)
+from design_utils import utils as du
 from timed_hip import engine, textio
+
+N_RESIDUE_CLASSES, N_ROTAMER_CLASSES = 20, 338
+
+
+# ---- one model over one dataset --------------------------------------------------------------------------------
+class _OutputFiles:
+    """The per-model files of reference predict.py:123,145-155 / utils.save_outputs_to_file, appended group by group in
+    row order, and the float16 matrix the reference re-reads from the CSV afterwards (predict.py:163)."""
+
+    def __init__(self, model_index, model_name, flat_dataset_map, path_to_output, predict_rotamers, codec, resume):
+        self.model_index, self.model_name = model_index, model_name
+        self.flat_dataset_map, self.path_to_output = flat_dataset_map, path_to_output
+        self.codec = codec
+        self.matrix_path = path_to_output / (f"{model_name}_rot.csv" if predict_rotamers else f"{model_name}.csv")
+        # rows already in the file (an earlier, interrupted or repeated run) are part of what the reference reads back
+        self.must_reread = resume or (self.matrix_path.exists() and self.matrix_path.stat().st_size > 0)
+        self._f16_rows = []
+
+    def append(self, probs: np.ndarray, labels: np.ndarray):
+        if self.codec is not None:
+            with open(self.matrix_path, "ab") as f:
+                textio.savetxt_csv(f, probs)            # = np.savetxt(f, y_pred_batch, delimiter=","), full precision
+            self._f16_rows.append(probs.astype(np.float16))
+            probs = np.array([self.codec[c] for c in np.argmax(probs, axis=1)])
+        else:
+            self._f16_rows.append(probs.astype(np.float16))
+        du.save_outputs_to_file(list(labels), {self.model_index: list(probs)}, self.flat_dataset_map, self.model_index,
+                                self.model_name, self.path_to_output)
+
+    def prediction_matrix(self) -> np.ndarray:
+        """what np.genfromtxt(matrix_path, delimiter=",", dtype=np.float16) would return: '%.18e' text round-trips every
+        float16/float32 exactly, so for a fresh file it is the float16 cast of what was written; a file that already
+        held rows is read back."""
+        if self.must_reread or not self._f16_rows:
+            return textio.loadtxt_f16(self.matrix_path)
+        return np.concatenate(self._f16_rows, axis=0)
+
+
+def _row_groups(n_rows, batch_size, start_batch, frames_per_call):
+    """[lo, hi) row ranges, each a whole number of reference batches (so resuming at ``start_batch`` lines up)"""
+    per_call = max(1, int(frames_per_call) // max(1, batch_size)) * batch_size
+    return [(lo, min(lo + per_call, n_rows)) for lo in range(start_batch * batch_size, n_rows, per_call)]
+
+
+def _run_groups(models, dataset_path, flat_dataset_map, groups, consume):
+    """Pipeline: loader thread (group g+1) | GPUs (group g, round-robin over ``models``) | ``consume`` (group g-1)."""
+    if not groups:
+        return
+    depth = 2 * len(models)
+
+    def load(k):
+        lo, hi = groups[k]
+        return du.load_batch(dataset_path, flat_dataset_map[lo:hi])
+
+    pending = deque()
+    with ThreadPoolExecutor(max_workers=1, thread_name_prefix="load_batch") as pool:
+        nxt = pool.submit(load, 0)
+        for k in range(len(groups)):
+            X, y = nxt.result()
+            if k + 1 < len(groups):
+                nxt = pool.submit(load, k + 1)
+            pending.append((models[k % len(models)].predict_async(X), y))
+            del X
+            if len(pending) >= depth:
+                ticket, labels = pending.popleft()
+                consume(ticket.result(), labels)
+        while pending:
+            ticket, labels = pending.popleft()
+            consume(ticket.result(), labels)
+
+
+def _distributed_context(gather):
+    """(rank, world, local_rank, gather): world > 1 when launched one process per GPU (torch.distributed.run)."""
+    from timed_hip import distributed as td
+    if gather is not None:
+        return gather.rank, gather.world, int(os.environ.get("LOCAL_RANK", gather.rank)), gather
+    rank, world, local = td.env_rank_world()
+    return rank, world, local, None
 
 
 def load_dataset_and_predict(
@@ -50,115 +129,188 @@ def load_dataset_and_predict(
     path_to_output: Path = Path.cwd(),
     device: int = 0,
     frames_per_call: int = 1024,
+    devices=None,
+    model_loader=None,
+    gather=None,
 ) -> (np.ndarray, np.ndarray, np.ndarray, np.ndarray, np.ndarray, np.ndarray):
-    """reference predict.py:28-194 — same parameters and return tuple
-    (flat_dataset_map, pdb_to_sequence, pdb_to_probability, pdb_to_real_sequence, pdb_to_consensus,
-    pdb_to_consensus_prob).  ``start_batch`` keeps the reference's resume semantics: batches before it
-    are skipped and outputs are appended.  ``batch_size`` keeps its meaning for resuming, but consecutive
-    batches are handed to the GPU together (about ``frames_per_call`` frames per launch): the per-batch appends
-    of the reference concatenate to exactly the same files, and the CLI default of 12 frames per batch no longer
-    costs one 1.7 ms launch sequence per 12 frames."""
+    """reference predict.py:28-194 — same leading parameters and return tuple (flat_dataset_map, pdb_to_sequence,
+    pdb_to_probability, pdb_to_real_sequence, pdb_to_consensus, pdb_to_consensus_prob).  ``start_batch`` keeps the
+    reference's resume semantics (batches before it are skipped, outputs are appended).
+
+    Opt-in extras: ``device`` / ``devices`` (HIP device indices for this process), ``frames_per_call`` (frames handed to
+    a GPU per call), ``model_loader(path, device=...)`` (default ``timed_hip.engine.load_model``) and ``gather`` (a
+    row-gather transport from ``timed_hip.distributed``; default: RCCL when WORLD_SIZE > 1)."""
     path_to_output = Path(path_to_output)
-    n_classes = 338 if predict_rotamers else 20
-    print(f"Running model on {n_classes} classes. Rotamer Mode is {predict_rotamers}")
-    filter_pdb_list = get_pdb_keys_to_filter(blacklist) if blacklist else []
+    n_classes = N_ROTAMER_CLASSES if predict_rotamers else N_RESIDUE_CLASSES
+    rank, world, local_rank, gather = _distributed_context(gather)
+    sharded = world > 1 or gather is not None      # an explicit transport selects the shard + gather path even for 1 rank
+    if rank == 0:
+        print(f"Predicting {n_classes} classes per residue ({'rotamer' if predict_rotamers else 'residue'} mode)")
     if Path(dataset_map_path).exists():
-        flat_dataset_map = genfromtxt(dataset_map_path, delimiter=",", dtype="str")
-        flat_dataset_map = np.atleast_2d(flat_dataset_map)
+        flat_dataset_map = np.atleast_2d(np.genfromtxt(dataset_map_path, delimiter=",", dtype="str"))
     else:
-        flat_dataset_map, _training_set_pdbs = create_flat_dataset_map(dataset_path, filter_pdb_list)
-    old_datasetmap = True if len(flat_dataset_map[0]) == 4 else False
-    codec, flat_categories = get_rotamer_codec() if predict_rotamers else (None, None)
-    n_batches = ceil(len(flat_dataset_map) / batch_size)
-    pdb_to_sequence = pdb_to_probability = pdb_to_real_sequence = pdb_to_consensus = pdb_to_consensus_prob = None
-    for i, m in enumerate(models):
-        model_name = (m.stem if isinstance(m, Path) else str(m)) + model_name_suffix
-        frame_model = engine.load_model(Path(m), device=device)
-        if frame_model.n_classes != n_classes:
-            raise ValueError(f"{m}: model has {frame_model.n_classes} outputs but predict_rotamers={predict_rotamers} "
-                             f"expects {n_classes}")
-        model_out = path_to_output / (f"{model_name}_rot.csv" if predict_rotamers else f"{model_name}.csv")
-        group = max(1, int(frames_per_call) // max(1, batch_size))    # reference batches per GPU call
-        for index in range(start_batch, n_batches, group):
-            current_batch_map = flat_dataset_map[index * batch_size: (index + group) * batch_size]
-            X_batch, y_true_batch = load_batch(dataset_path, current_batch_map)
-            y_pred_batch = frame_model.predict(X_batch)
-            if predict_rotamers:
-                with open(model_out, "ab") as f:
-                    textio.savetxt_csv(f, y_pred_batch)    # = np.savetxt(f, y_pred_batch, delimiter=","), full precision
-                current_batch = np.argmax(y_pred_batch, axis=1)
-                y_pred_batch = np.array([codec[c] for c in current_batch])
-            save_outputs_to_file(list(y_true_batch), {i: list(y_pred_batch)}, flat_dataset_map, i, model_name, path_to_output)
-        frame_model.close()
+        excluded = du.get_pdb_keys_to_filter(blacklist) if blacklist else []
+        flat_dataset_map, _ = du.create_flat_dataset_map(dataset_path, excluded)
+    old_datasetmap = len(flat_dataset_map[0]) == 4
+    codec, flat_categories = du.get_rotamer_codec() if predict_rotamers else (None, None)
+    loader = model_loader or engine.load_model
+    if world > 1:
+        device_ids = [local_rank if devices is None else list(devices)[local_rank % len(devices)]]
+    elif sharded:
+        device_ids = [device]
+    else:
+        device_ids = [device] if not devices else list(devices)
+    outputs = (None,) * 5
+    for index, model_path in enumerate(models):
+        model_name = (model_path.stem if isinstance(model_path, Path) else str(model_path)) + model_name_suffix
+        handles = [loader(Path(model_path), device=d) for d in device_ids]
+        try:
+            for h in handles:
+                if h.n_classes != n_classes:
+                    raise ValueError(f"{model_path}: the model has {h.n_classes} outputs, predict_rotamers="
+                                     f"{predict_rotamers} needs {n_classes}")
+            if sharded:
+                done = _predict_sharded(handles[0], gather, rank, world, dataset_path, flat_dataset_map, batch_size,
+                                        start_batch, frames_per_call)
+                if rank != 0:
+                    continue
+                files = _OutputFiles(index, model_name, flat_dataset_map, path_to_output, predict_rotamers, codec,
+                                     resume=start_batch > 0)
+                probs, labels, row0 = done
+                for lo, hi in _row_groups(len(flat_dataset_map), batch_size, start_batch, frames_per_call):
+                    files.append(probs[lo - row0:hi - row0], labels[lo - row0:hi - row0])
+            else:
+                files = _OutputFiles(index, model_name, flat_dataset_map, path_to_output, predict_rotamers, codec,
+                                     resume=start_batch > 0)
+                _run_groups(handles, dataset_path, flat_dataset_map,
+                            _row_groups(len(flat_dataset_map), batch_size, start_batch, frames_per_call), files.append)
+        finally:
+            for h in handles:
+                h.close()
         flat_dataset_map = np.array(flat_dataset_map)
-        convert_dataset_map_for_srb(flat_dataset_map, model_name, path_to_output)
-        prediction_matrix = textio.loadtxt_f16(model_out)   # = np.atleast_2d(genfromtxt(..., dtype=np.float16)), C parser
-        (pdb_to_sequence, pdb_to_probability, pdb_to_real_sequence, pdb_to_consensus,
-         pdb_to_consensus_prob) = extract_sequence_from_pred_matrix(
-            flat_dataset_map, prediction_matrix,
-            rotamers_categories=flat_categories if predict_rotamers else None,
+        du.convert_dataset_map_for_srb(flat_dataset_map, model_name, path_to_output)
+        outputs = du.extract_sequence_from_pred_matrix(
+            flat_dataset_map, files.prediction_matrix(), rotamers_categories=flat_categories if predict_rotamers else None,
             old_datasetmap=old_datasetmap, is_consensus=is_consensus)
-        save_dict_to_fasta(pdb_to_sequence, model_name, path_to_output)
-        save_dict_to_fasta(pdb_to_real_sequence, "dataset", path_to_output)
+        pdb_to_sequence, _prob, pdb_to_real_sequence, pdb_to_consensus, pdb_to_consensus_prob = outputs
+        du.save_dict_to_fasta(pdb_to_sequence, model_name, path_to_output)
+        du.save_dict_to_fasta(pdb_to_real_sequence, "dataset", path_to_output)
         if pdb_to_consensus:
-            save_dict_to_fasta(pdb_to_consensus, model_name + "_consensus", path_to_output)
-            save_consensus_probs(pdb_to_consensus_prob, model_name, path_to_output)
-    return (flat_dataset_map, pdb_to_sequence, pdb_to_probability, pdb_to_real_sequence, pdb_to_consensus,
-            pdb_to_consensus_prob)
+            du.save_dict_to_fasta(pdb_to_consensus, model_name + "_consensus", path_to_output)
+            du.save_consensus_probs(pdb_to_consensus_prob, model_name, path_to_output)
+    return (flat_dataset_map, *outputs)
 
 
-def main(args):
-    args.path_to_dataset = Path(args.path_to_dataset)
-    args.path_to_model = Path(args.path_to_model)
-    args.path_to_datasetmap = Path(args.path_to_datasetmap)
-    args.path_to_output = Path(args.path_to_output)
-    if not args.path_to_output.exists():
-        print(f"Output directory at {args.path_to_output} does not exist. Do you want to create it? (y/n)")
-        if input() == "y":
-            args.path_to_output.mkdir(parents=True, exist_ok=True)
-        else:
-            print("Exiting...")
-            exit()
-    if args.path_to_blacklist:
-        args.path_to_blacklist = Path(args.path_to_blacklist)
-        assert args.path_to_blacklist.exists(), f"Path to blacklist at {args.path_to_blacklist} does not exists."
-    assert args.path_to_model.exists(), f"Path to model at {args.path_to_model} does not exists."
-    assert args.path_to_dataset.exists(), f"Path to dataset at {args.path_to_dataset} does not exists."
-    assert args.batch_size > 0, f"Batch size must be higher than 0 but got {args.batch_size}"
-    return load_dataset_and_predict(
-        [args.path_to_model],
-        args.path_to_dataset,
-        batch_size=args.batch_size,
-        start_batch=0,
-        blacklist=args.path_to_blacklist,
-        dataset_map_path=args.path_to_datasetmap,
-        predict_rotamers=args.predict_rotamers,
-        is_consensus=args.is_structure_nmr,
-        path_to_output=args.path_to_output,
-        device=args.device,
-    )
+def _predict_sharded(model, gather, rank, world, dataset_path, flat_dataset_map, batch_size, start_batch, frames_per_call):
+    """One process per GPU: rows [row0, N) are cut into ``world`` contiguous shards (timed_hip.distributed.shard_bounds),
+    this rank predicts its shard and the shards are gathered to rank 0 in rank order = map order.
+    With the default transport the probabilities never leave the GPUs before the gather: predict_async writes them
+    into a device buffer and th_comm_gather_rows moves them over xGMI.  Returns (probs, labels, row0) on rank 0."""
+    from timed_hip import distributed as td
+    row0 = min(start_batch * batch_size, len(flat_dataset_map))
+    n = len(flat_dataset_map) - row0
+    counts = td.shard_counts(n, world)
+    lo, hi = td.shard_bounds(n, world)[rank]
+    shard = flat_dataset_map[row0 + lo: row0 + hi]
+    groups = [(a, min(a + max(1, int(frames_per_call)), len(shard))) for a in range(0, len(shard), max(1, int(frames_per_call)))]
+    labels = np.zeros((len(shard), N_RESIDUE_CLASSES), dtype=np.float32)
+    own_transport = gather is None
+    if own_transport:
+        gather = td.RcclGather.from_environment(rank, world, model.device)     # raises when RCCL cannot be brought up
+    try:
+        if isinstance(gather, td.RcclGather):
+            d_local = engine.DeviceBuffer(max(1, len(shard) * model.n_classes * 4), model.device)
+            cursor = [0]
+
+            def keep(_none, y):
+                labels[cursor[0]:cursor[0] + len(y)] = y
+                cursor[0] += len(y)
+
+            class _ToDevice:      # the model facade _run_groups drives: outputs land in d_local at the shard row
+                def __init__(self):
+                    self.row = 0
+
+                def predict_async(self, X):
+                    t = model.predict_async_device(X, d_local.ptr + self.row * model.n_classes * 4)
+                    self.row += len(X)
+                    return t
+            _run_groups([_ToDevice()], dataset_path, shard, groups, keep)
+            d_all = engine.DeviceBuffer(max(1, n * model.n_classes * 4), model.device) if rank == 0 else None
+            gather.gather_rows_device(d_local.ptr, counts, model.n_classes, 0, d_all.ptr if d_all else 0)
+            probs = d_all.download((n, model.n_classes), np.float32) if rank == 0 else None
+            d_lab = engine.DeviceBuffer(max(1, labels.nbytes), model.device)
+            d_lab.upload(labels)
+            d_lab_all = engine.DeviceBuffer(max(1, n * N_RESIDUE_CLASSES * 4), model.device) if rank == 0 else None
+            gather.gather_rows_device(d_lab.ptr, counts, N_RESIDUE_CLASSES, 0, d_lab_all.ptr if d_lab_all else 0)
+            all_labels = d_lab_all.download((n, N_RESIDUE_CLASSES), np.float32) if rank == 0 else None
+        else:                     # host transport (GlooGather): the probabilities are wanted on the host anyway
+            local = np.zeros((len(shard), model.n_classes), dtype=np.float32)
+            cursor = [0]
+
+            def keep(p, y):
+                local[cursor[0]:cursor[0] + len(y)] = p
+                labels[cursor[0]:cursor[0] + len(y)] = y
+                cursor[0] += len(y)
+            _run_groups([model], dataset_path, shard, groups, keep)
+            probs = gather.gather_rows(local, counts, 0)
+            all_labels = gather.gather_rows(labels, counts, 0)
+    finally:
+        if own_transport:
+            gather.close()
+    return (probs, all_labels.astype(float), row0) if rank == 0 else None
+
+
+# ---- command line ----------------------------------------------------------------------------------------------
+# (flag, argparse keywords): names, types and defaults are the reference's (predict.py:251-296); --device/--devices and
+# --frames_per_call are additions of this build.
+CLI_FLAGS = (
+    ("--batch_size", dict(type=int, default=12, help="frames per reference batch; also the unit --start_batch-style resumes count in")),
+    ("--path_to_dataset", dict(type=str, help="aposteriori frame dataset (.hdf5) or frame pack")),
+    ("--path_to_datasetmap", dict(type=str, default="datasetmap.txt", help="flat dataset map (.txt); created when missing")),
+    ("--path_to_model", dict(type=str, help="Keras legacy .h5 model or converted .pack")),
+    ("--path_to_blacklist", dict(type=str, default=None, help="directory of PDB lists to refuse (training-set structures)")),
+    ("--path_to_output", dict(type=str, default=".", help="output directory (asked before it is created)")),
+    ("--output_analysis", dict(action="store_true", help="accepted for compatibility; unused, as in the reference")),
+    ("--predict_rotamers", dict(action="store_true", help="the model predicts 338 rotamer classes instead of 20 residues")),
+    ("--is_structure_nmr", dict(action="store_true", help="merge the states of an NMR ensemble into a consensus")),
+    ("--device", dict(type=int, default=0, help="HIP device index")),
+    ("--devices", dict(type=str, default=None, help="comma-separated HIP device indices to spread the frames over")),
+    ("--frames_per_call", dict(type=int, default=1024, help="frames handed to a GPU per call")),
+)
 
 
 def build_parser():
-    parser = argparse.ArgumentParser(description="Predict with TIMED")
-    parser.add_argument("--batch_size", type=int, default=12,
-                        help="Number of batches of frames to predict at once (default: 12)")
-    parser.add_argument("--path_to_dataset", type=str, help="Path to dataset file ending with .hdf5")
-    parser.add_argument("--path_to_datasetmap", default="datasetmap.txt", type=str,
-                        help="Path to dataset map ending with .txt")
-    parser.add_argument("--path_to_model", type=str, help="Path to model file ending with .h5 (or .pack)")
-    parser.add_argument("--path_to_blacklist", type=str, default=None,
-                        help="Path to csv file containing PDBs in the training set.")
-    parser.add_argument("--path_to_output", type=str, default=".",
-                        help="Directory to save output files. Defaults to current working directory. If the directory "
-                             "does not exist, the user will be prompted to create it.")
-    parser.add_argument("--output_analysis", action="store_true", help="Whether to output analysis graphs.")
-    parser.add_argument("--predict_rotamers", action="store_true",
-                        help="Whether model outputs predictions for 338 rotamers (True) or 20 residues (False).")
-    parser.add_argument("--is_structure_nmr", action="store_true",
-                        help="Whether the structure is NMR. NMR will have different states so TIMED will try to build a consensus")
-    parser.add_argument("--device", type=int, default=0, help="HIP device index (default: 0)")
+    parser = argparse.ArgumentParser(description="Residue / rotamer probabilities for every frame of a dataset (MI355X)")
+    for flag, keywords in CLI_FLAGS:
+        parser.add_argument(flag, **keywords)
     return parser
+
+
+def _confirm_output_directory(directory: Path):
+    if directory.exists():
+        return
+    print(f"{directory} does not exist yet - create it? (y/n)")
+    if input() != "y":
+        print("Nothing written.")
+        sys.exit()
+    directory.mkdir(parents=True, exist_ok=True)
+
+
+def main(args):
+    required = {"model": Path(args.path_to_model), "dataset": Path(args.path_to_dataset)}
+    if args.path_to_blacklist:
+        required["blacklist"] = Path(args.path_to_blacklist)
+    _confirm_output_directory(Path(args.path_to_output))
+    for what, path in required.items():
+        assert path.exists(), f"No {what} at {path}"
+    assert args.batch_size > 0, f"--batch_size must be positive, got {args.batch_size}"
+    devices = [int(d) for d in args.devices.split(",")] if getattr(args, "devices", None) else None
+    return load_dataset_and_predict(
+        [required["model"]], required["dataset"], batch_size=args.batch_size, start_batch=0,
+        dataset_map_path=Path(args.path_to_datasetmap), blacklist=required.get("blacklist"),
+        predict_rotamers=args.predict_rotamers, is_consensus=args.is_structure_nmr,
+        path_to_output=Path(args.path_to_output), device=getattr(args, "device", 0), devices=devices,
+        frames_per_call=getattr(args, "frames_per_call", 1024))
 
 
 if __name__ == "__main__":

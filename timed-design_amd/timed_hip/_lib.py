@@ -11,8 +11,9 @@ LIB_PATH = os.environ.get("TIMED_HIP_LIB", os.path.join(_HERE, "libtimedhip.so")
 TH_OK = 0
 TH_F32, TH_F64, TH_U8, TH_BOOL, TH_F16 = 0, 1, 2, 3, 4
 TH_LOAD_DEFAULT, TH_LOAD_NO_FUSE, TH_LOAD_NO_MFMA, TH_LOAD_KEEP_ALL = 0, 1, 2, 4
-TH_PREDICT_DEFAULT, TH_PREDICT_LOGITS = 0, 1
+TH_PREDICT_DEFAULT, TH_PREDICT_LOGITS, TH_PREDICT_OUT_DEVICE = 0, 1, 2
 TH_RNG_HOST, TH_RNG_PHILOX, TH_RNG_MT19937 = 0, 1, 2
+TH_TEMPER_NONE, TH_TEMPER_POW, TH_TEMPER_PREPOWERED = 0, 1, 2
 TH_COMM_ID_BYTES = 128
 
 _vp, _i, _u, _i64, _u64, _d, _sz = C.c_void_p, C.c_int, C.c_uint, C.c_int64, C.c_uint64, C.c_double, C.c_size_t
@@ -48,6 +49,11 @@ PROTOTYPES = {
     "th_dev_sync": (_i, [_i]),
     "th_dev_synth_frames": (_i, [_i, _vp, _i64, _i, _i, _i, _u64]),
     "th_apply_temp": (_i, [_vp, _i64, _i, _d, _vp]),
+    "th_apply_temp_on": (_i, [_i, _vp, _i64, _i, _d, _vp]),
+    "th_sampler_create": (_i, [_i, C.POINTER(_vp)]),
+    "th_sampler_free": (None, [_vp]),
+    "th_sampler_load": (_i, [_vp, _vp, _i64, _i, _d, _i, _i, _vp]),
+    "th_sampler_draw": (_i, [_vp, _i64, _pi64, _i64, _i, _u64, _u64, _vp, C.c_char_p, _vp, _vp, _vp, _vp]),
     "th_sample": (_i, [_vp, _i64, _i, _i64, _d, _i, _u64, _vp, _vp]),
     "th_sample_ex": (_i, [_vp, _i64, _i, _i64, _d, _i, _u64, _u64, _vp, _vp, _vp, C.c_char_p, _vp, _vp, _i]),
     "th_comm_unique_id": (_i, [C.c_char_p]),

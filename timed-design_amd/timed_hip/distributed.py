@@ -87,6 +87,40 @@ class RcclGather:
         self._h = C.c_void_p()
         _lib.check(self._lib.th_comm_init(unique_id, world, rank, device, C.byref(self._h)))
 
+    @classmethod
+    def from_environment(cls, rank: int, world: int, device: int) -> "RcclGather":
+        """Bring the communicator up inside a ``torch.distributed.run`` job: rank 0 creates the RCCL unique id and it
+        travels to the other ranks through a gloo broadcast (CPU tensors; torch is rendezvous plumbing only).  Raises
+        on every rank when any rank fails — a GPU job never degrades silently to a host exchange."""
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        ident = bytearray(_lib.TH_COMM_ID_BYTES)
+        err = ""
+        if rank == 0:
+            try:
+                ident = bytearray(cls.new_unique_id())
+            except _lib.TimedHipError as e:
+                err = str(e)
+        t = torch.frombuffer(ident, dtype=torch.uint8).clone()
+        dist.broadcast(t, src=0)
+        ident = bytes(t.numpy().tobytes())
+        comm = None
+        if any(ident):
+            try:
+                comm = cls(ident, world, rank, device)
+            except _lib.TimedHipError as e:
+                err = str(e)
+        ok = torch.tensor([1 if comm is not None else 0])
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) != 1:
+            if comm is not None:
+                comm.close()
+            raise RuntimeError(f"RCCL communicator could not be created on every rank (rank {rank}: {err or 'ok'})")
+        return comm
+
     @staticmethod
     def new_unique_id() -> bytes:
         buf = C.create_string_buffer(_lib.TH_COMM_ID_BYTES)

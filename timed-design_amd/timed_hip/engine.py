@@ -105,6 +105,23 @@ class HipFrameModel:
                                               _lib.TH_PREDICT_LOGITS if logits else 0, C.byref(ticket)))
         return PendingPrediction(self, ticket.value, X, out)
 
+    def predict_async_device(self, X, d_out: int) -> "PendingPrediction":
+        """As predict_async, but the probability rows are left in device memory at address ``d_out`` (this model's
+        device, room for len(X) * n_classes floats) — e.g. a shard buffer that th_comm_gather_rows sends over xGMI.
+        ``result()`` returns None once the rows are there."""
+        X = np.asarray(X)
+        if X.ndim != 5 or tuple(X.shape[1:]) != self.input_shape:
+            raise ValueError(f"expected frames of shape (B, {', '.join(map(str, self.input_shape))}), got {X.shape}")
+        dt = _DTYPES.get(X.dtype)
+        if dt is None:
+            X = X.astype(np.float32)
+            dt = _lib.TH_F32
+        X = np.ascontiguousarray(X)
+        ticket = C.c_int(-1)
+        _lib.check(self._lib.th_predict_async(self._h, X.ctypes.data, dt, X.shape[0], C.c_void_p(d_out),
+                                              _lib.TH_PREDICT_OUT_DEVICE, C.byref(ticket)))
+        return PendingPrediction(self, ticket.value, X, None)
+
     @property
     def logits_width(self) -> int:
         return self.n_classes
