@@ -97,6 +97,10 @@ def main():
     ap.add_argument("--chunk", type=int, default=4096, help="frames per launch (activation arenas are sized for this many frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP events (roofline omitted)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the e2e / sampler / other-topology legs (N=1 only)")
+    ap.add_argument("--e2e-frames", type=int, default=20000, help="frames in the synthetic frame packs of the predict.py leg")
+    ap.add_argument("--e2e-hdf5-frames", type=int, default=2000, help="frames in the synthetic gzip .hdf5 of the predict.py leg")
+    ap.add_argument("--other-frames", type=int, default=40960, help="frames for the densecpd / timed_rotamer legs")
     args = ap.parse_args()
 
     # stdout carries exactly one JSON line: gloo / RCCL banners written to fd 1 by native code go to stderr
@@ -165,12 +169,17 @@ def main():
             if rank == 0:
                 d_gather = engine.DeviceBuffer(world * n * model.n_classes * 4, device)
         else:
-            # RCCL could not be brought up on some rank: keep measuring, with the exchange done on the host
-            # (device->host copy + gloo gather), and say so in the JSON line
             if rc == 0:
                 lib.th_comm_free(h)
-            exchange = "HOST FALLBACK (gloo gather of downloaded rows): RCCL init failed: " + \
-                lib.th_last_error().decode(errors="replace")
+            why = lib.th_last_error().decode(errors="replace")
+            if ndev >= world:
+                # every rank has its own GPU: RCCL must work here, and a silent host exchange would be measured as if
+                # it were the xGMI gather — refuse
+                sys.exit(f"[bench] rank {rank}: RCCL communicator could not be created although {ndev} devices are "
+                         f"visible for {world} ranks: {why}")
+            # ranks share a GPU (fewer devices than ranks): RCCL cannot span them; measure with the exchange done on the
+            # host (device->host copy + gloo gather) and say so in the JSON line
+            exchange = f"HOST FALLBACK (gloo gather of downloaded rows): {world} ranks on {ndev} device(s): " + why
             if rank == 0:
                 print("[bench] " + exchange, file=sys.stderr)
             from timed_hip import distributed as td
@@ -212,6 +221,29 @@ def main():
     probe = d_probs.download((min(n, 256), model.n_classes), np.float32)
     assert np.all(np.isfinite(probe)) and np.allclose(probe.sum(1), 1.0, atol=1e-4), "bench output is not a probability matrix"
 
+    # N > 1: the gathered matrix on rank 0 must hold rank r's rows in block r, bit for bit.  Every rank ships the head
+    # and tail rows of its own shard over gloo (host) and rank 0 compares them with the same rows of the RCCL result.
+    gather_verified = None
+    if world > 1 and comm is not None:
+        import torch
+        k = min(n, 64)
+        mine = np.concatenate([d_probs.download((k, model.n_classes), np.float32),
+                               d_probs.download((k, model.n_classes), np.float32, offset=(n - k) * model.n_classes * 4)])
+        parts = [torch.empty(mine.shape, dtype=torch.float32) for _ in range(world)] if rank == 0 else None
+        dist.gather(torch.from_numpy(mine), parts, dst=0)
+        if rank == 0:
+            gather_verified = True
+            for r in range(world):
+                base = r * n * model.n_classes * 4
+                got = np.concatenate([d_gather.download((k, model.n_classes), np.float32, offset=base),
+                                      d_gather.download((k, model.n_classes), np.float32, offset=base + (n - k) * model.n_classes * 4)])
+                if not np.array_equal(got, parts[r].numpy()):
+                    gather_verified = False
+            if not gather_verified:
+                sys.exit("[bench] RCCL gather delivered rows that differ from the ranks' own shards")
+            # distinct seeds per rank: two blocks holding the same rows would mean a misrouted transfer
+            assert not np.array_equal(parts[0].numpy(), parts[1].numpy()), "ranks produced identical shards"
+
     if rank == 0:
         cost = model.cost()
         total_frames = n * world * args.steps
@@ -224,7 +256,7 @@ def main():
             "config": {"workload": f"{model.name}-synth forward, {D}x{H}x{W}x{Cc} fp32 frames resident in HBM, "
                                    f"{n} frames per GPU per step, {model.n_classes} classes, random-init weights",
                        "frames_per_gpu": n, "chunk": args.chunk, "parallelism": f"frame-shard x{world}",
-                       "exchange": exchange,
+                       "exchange": exchange, "rccl_ranks": world if comm is not None else 0, "gather_verified": gather_verified,
                        "algo_mflop_per_frame": cost["algo_flops"] / 1e6, "exec_mflop_per_frame": cost["exec_flops"] / 1e6,
                        "device": f"{model.device_arch} {model.device_cus} CUs"},
             "model_tflops": fps / world * cost["algo_flops"] / 1e12,
@@ -239,6 +271,8 @@ def main():
             achieved = dom["flops"] * frames_per_launch / (avg_ms * 1e-3) / 1e12
             line["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                 "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(dom["label"], avg_ms),
+                                "traffic_source": "profiles/pmc_latest.json: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                                  "this command (looked up by kernel name and launch duration, not measured in this run)",
                                 "kernel": dom["label"], "avg_launch_ms": avg_ms, "launches": dom["launches"],
                                 "measured": "HIP events around every launch of this kernel inside the timed region",
                                 "exec_tflops": dom["exec_flops"] * frames_per_launch / (avg_ms * 1e-3) / 1e12}
@@ -253,6 +287,20 @@ def main():
                                    for s in warm_steps]
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(cfg, weights, f"{model.name}-synth")
+        if world == 1 and not args.no_extras:
+            # secondary legs, outside the timed region (tools/bench_legs.py): each is reported, none feeds `value`
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_legs
+            model.profile(0)
+            t_legs = time.perf_counter()
+            e2e = bench_legs.host_resident(model, d_frames.ptr, n, fps)
+            e2e.update(bench_legs.predict_py_e2e(cfg, weights, n_pack=args.e2e_frames, n_hdf5=args.e2e_hdf5_frames))
+            line["e2e"] = e2e
+            line["sampler"] = bench_legs.sampler_config5(device)
+            others = [t for t in ("densecpd", "timed_rotamer") if t != args.topology]
+            line["other_configs"] = [bench_legs.topology_rate(t, device, d_frames.ptr, min(n, args.other_frames), args.chunk)
+                                     for t in others]
+            line["extras_wall_s"] = time.perf_counter() - t_legs
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if comm is not None:

@@ -194,7 +194,7 @@ int64_t th_format_csv(const void* data, int dtype, int64_t n, int64_t k, char* o
  * datasets that share one geometry (shape[rank], chunk[rank], element size, filter pipeline ids in write order:
  * 1 deflate, 2 shuffle, 3 fletcher32) and whose chunk B-trees (version 1) start at btree_addrs[i], inflate every
  * chunk and scatter it into dests[i] (C order, shape[] elements of esz bytes) on nthreads host threads (0 = all
- * cores, at most 32).  Unallocated chunks read as zeros.  TH_EUNSUP when the file uses something else (the
+ * cores, at most 128).  Unallocated chunks read as zeros.  TH_EUNSUP when the file uses something else (the
  * caller then reads through its generic path). */
 int th_h5_read_chunked(const void* file, int64_t file_len, int64_t base, int64_t n_datasets, const int64_t* btree_addrs,
                        void* const* dests, int rank, const int64_t* shape, const int64_t* chunk, int esz, int n_filters,

@@ -159,7 +159,7 @@ extern "C" int th_h5_read_chunked(const void* file, int64_t file_len, int64_t ba
     }
     if (n_datasets == 0) return TH_OK;
     unsigned hw = std::thread::hardware_concurrency();
-    int nt = nthreads > 0 ? nthreads : (int)std::min<unsigned>(hw ? hw : 4, 32);
+    int nt = nthreads > 0 ? nthreads : (int)std::min<unsigned>(hw ? hw : 4, 128);
     nt = (int)std::max<int64_t>(1, std::min<int64_t>(nt, n_datasets));
     std::atomic<int64_t> next{0};
     std::atomic<int> failed{0};

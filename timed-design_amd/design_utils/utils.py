@@ -294,10 +294,20 @@ def save_outputs_to_file(
     path_to_datasetmap = path_to_output / "datasetmap.txt"
     if not path_to_datasetmap.exists():
         with open(path_to_datasetmap, "a") as f:
-            np.savetxt(f, np.asarray(flat_dataset_map), delimiter=",", fmt="%s")
+            _savetxt_strings(f, flat_dataset_map)
     predictions = np.array(y_pred[model], dtype=np.float16)
     with open(path_to_output / f"{model_name}.csv", "ab") as f:
         textio.savetxt_csv(f, predictions)     # same bytes as np.savetxt(f, predictions, delimiter=","), formatted natively
+
+
+def _savetxt_strings(f, rows) -> None:
+    """np.savetxt(f, np.asarray(rows), delimiter=",", fmt="%s") for a table of strings (the flat dataset map): '%s' of a
+    NumPy string is the string itself, so every row is its fields joined by commas."""
+    rows = np.asarray(rows)
+    if rows.ndim == 2 and rows.dtype.kind in "US":
+        f.write("".join([",".join(r) + "\n" for r in rows.tolist()]))
+    else:
+        np.savetxt(f, rows, delimiter=",", fmt="%s")
 
 
 def _savetxt_small_ints(f, a: np.ndarray) -> None:

@@ -81,7 +81,12 @@ def _row_groups(n_rows, batch_size, start_batch, frames_per_call):
 
 
 def _run_groups(models, dataset_path, flat_dataset_map, groups, consume):
-    """Pipeline: loader thread (group g+1) | GPUs (group g, round-robin over ``models``) | ``consume`` (group g-1)."""
+    """Pipeline over the call groups, three stages on three threads:
+         loader thread   load_batch of group g+1 (reference utils.py:487-530)
+         this thread     th_predict_async of group g, round-robin over ``models`` (the host->device copy of pageable
+                         frames blocks here while the kernels of group g-1 run)
+         writer thread   ``consume(probs, labels)`` for group g-1, strictly in group order (formats and appends)
+    An exception in any stage surfaces here."""
     if not groups:
         return
     depth = 2 * len(models)
@@ -90,21 +95,32 @@ def _run_groups(models, dataset_path, flat_dataset_map, groups, consume):
         lo, hi = groups[k]
         return du.load_batch(dataset_path, flat_dataset_map[lo:hi])
 
-    pending = deque()
-    with ThreadPoolExecutor(max_workers=1, thread_name_prefix="load_batch") as pool:
-        nxt = pool.submit(load, 0)
+    def finish(ticket, labels):
+        consume(ticket.result(), labels)
+
+    pending = deque()          # tickets submitted to a GPU, oldest first
+    writing = deque()          # futures of the writer thread, oldest first
+    with ThreadPoolExecutor(max_workers=1, thread_name_prefix="load_batch") as loader, \
+            ThreadPoolExecutor(max_workers=1, thread_name_prefix="write_outputs") as writer:
+        nxt = loader.submit(load, 0)
         for k in range(len(groups)):
             X, y = nxt.result()
             if k + 1 < len(groups):
-                nxt = pool.submit(load, k + 1)
+                nxt = loader.submit(load, k + 1)
+            # a model has 4 tickets (th_predict_async): at most 3 consecutive groups per model are outstanding here,
+            # 2 on the GPU queue and 1 with the writer
+            while len(pending) + len(writing) >= 3 * len(models):
+                if not writing:
+                    writing.append(writer.submit(finish, *pending.popleft()))
+                writing.popleft().result()
             pending.append((models[k % len(models)].predict_async(X), y))
             del X
             if len(pending) >= depth:
-                ticket, labels = pending.popleft()
-                consume(ticket.result(), labels)
+                writing.append(writer.submit(finish, *pending.popleft()))
         while pending:
-            ticket, labels = pending.popleft()
-            consume(ticket.result(), labels)
+            writing.append(writer.submit(finish, *pending.popleft()))
+        while writing:
+            writing.popleft().result()
 
 
 def _distributed_context(gather):

@@ -40,6 +40,7 @@ class HipFrameModel:
         self.input_shape = tuple(dims)
         self.n_classes = ncls.value
         self.device_name, self.device_arch, self.device_cus = _lib.device_info(device)
+        self.chunk = 1024           # frames per internal pass (th_model_set_chunk); the library's default
 
     # ---- constructors -----------------------------------------------------------------------
     @classmethod
@@ -134,6 +135,7 @@ class HipFrameModel:
     # ---- introspection / tuning ----------------------------------------------------------------
     def set_chunk(self, frames: int):
         _lib.check(self._lib.th_model_set_chunk(self._h, int(frames)))
+        self.chunk = int(frames)
 
     def cost(self):
         a, e, n = C.c_double(), C.c_double(), C.c_int()

@@ -78,6 +78,16 @@ def pack_dataset(hdf5_path, out_stem, filter_list: Sequence[str] = (), remove_bl
     return FramePack(out_stem)
 
 
+def _read_map(path) -> np.ndarray:
+    """the pack's own map file (written by pack_dataset with '%s' fields, no quoting, no comments): plain split; anything
+    irregular goes through NumPy's general reader"""
+    with open(path) as f:
+        rows = [line.split(",") for line in f.read().splitlines() if line]
+    if rows and all(len(r) == 4 for r in rows):
+        return np.array(rows, dtype=str)
+    return np.atleast_2d(np.genfromtxt(path, delimiter=",", dtype=str))
+
+
 class FramePack:
     def __init__(self, path):
         stem = pack_stem(path)
@@ -87,7 +97,7 @@ class FramePack:
         self.meta = json.load(open(stem + ".meta.json"))
         self.frames = np.load(stem + ".frames.npy", mmap_mode="r")
         self.labels = np.load(stem + ".labels.npy")
-        self.flat_map = np.atleast_2d(np.genfromtxt(stem + ".map.txt", delimiter=",", dtype=str))
+        self.flat_map = _read_map(stem + ".map.txt")
         if len(self.flat_map) != self.frames.shape[0] or self.labels.shape[0] != self.frames.shape[0]:
             raise ValueError(f"{stem}: inconsistent pack (map {len(self.flat_map)}, frames {self.frames.shape[0]})")
         self._index: Optional[Dict[Tuple[str, str, str], int]] = None

@@ -2,7 +2,7 @@
 """Write a synthetic aposteriori-style frame dataset with REAL h5py (only /opt/conda python has it in this image):
     /opt/conda/bin/python3.9 tools/make_synthetic_hdf5.py out.hdf5 <n_pdb> <n_residues_per_chain>
 gzip-chunked float64 (21,21,21,6) frames under pdb/chain/residue, attrs as aposteriori 2.x writes them (reference
-design_utils/utils.py:238-251).  Used to time the HDF5 ingest path (tools/bench_predict_hdf5.py)."""
+design_utils/utils.py:238-251).  Used to time the HDF5 ingest path (tools/bench_e2e.py)."""
 import h5py, numpy as np, sys
 rng = np.random.default_rng(0)
 THREE = ["ALA","CYS","ASP","GLU","PHE","GLY","HIS","ILE","LYS","LEU","MET","ASN","PRO","GLN","ARG","SER","THR","VAL","TRP","TYR"]

@@ -6,11 +6,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "timed-design_amd")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 from timed_hip import pack, synth
 import predict
-import bench_predict_e2e as b
+import bench_legs as b
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 bs = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
 with tempfile.TemporaryDirectory() as td:
-    stem = os.path.join(td, "synth"); b.make_pack(stem, n, True)
+    stem = os.path.join(td, "synth"); b.make_frame_pack(stem, n, gaussian=(os.environ.get("E2E_BOOL") is None))
     cfg, w = synth.timed_synth(20); mp = Path(td) / "TIMED.pack"; mp.write_bytes(pack.keras_to_pack(cfg, w))
     out = Path(td) / "out"; out.mkdir()
     pr = cProfile.Profile(); pr.enable()

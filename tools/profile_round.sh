@@ -9,7 +9,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --steps 1 --warmup 1 --frames 20480 --no-cpu-baseline --no-profile"
+CMD="python $ROOT/bench.py --steps 1 --warmup 1 --frames 20480 --no-cpu-baseline --no-profile --no-extras"
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/kt" -o kt -- $CMD > "$OUT/kt.log" 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/fetch" -o fetch -- $CMD > "$OUT/fetch.log" 2>&1
@@ -22,6 +22,12 @@ WR=$(grep '/write/' "$OUT/dbs.txt" | head -1); SQ=$(grep '/sq/' "$OUT/dbs.txt" |
 python tools/rocpd_summary.py --kernel-trace "$KT" --pmc FETCH_SIZE="$FE" --pmc WRITE_SIZE="$WR" \
     --json "$OUT/pmc_latest.json" > "$OUT/summary.txt" 2> "$OUT/summary.err"
 [ -n "$SQ" ] && python tools/pmc_table.py "$SQ" > "$OUT/sq_table.txt" 2>> "$OUT/summary.err"
+# BASELINE config 5 (the sampler) under the kernel trace
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/sampler" -o sampler -- python $ROOT/tools/bench_sampler.py > "$OUT/sampler_bench.json" 2> "$OUT/sampler.log"
+cd "$ROOT"
+SM=$(find "$OUT/sampler" -name '*.db' | head -1)
+[ -n "$SM" ] && python tools/rocpd_summary.py --kernel-trace "$SM" > "$OUT/sampler_rocprof.txt" 2>> "$OUT/summary.err"
 # the bench line itself, default settings, outside the profiler
 timeout 600 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
 tail -1 "$OUT/bench_default.json"
