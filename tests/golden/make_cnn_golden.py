@@ -5,9 +5,15 @@ TensorFlow/Keras cannot be imported anywhere in this project, s
 (oracle/cnn_oracle.py) is pinned against an INDEPENDENT implementation instead: the same Keras
 ``model_config`` graphs are evaluated here with torch.nn.functional CPU ops (conv3d, max_pool3d,
 avg_pool3d, batch_norm, elu, ...) written from the Keras layer documentation, not from the oracle.
-The fixture stores, per case: the topology name/kwargs, frame seed, and the torch fp32 and fp64
-outputs.  Inputs/weights are regenerated from their seeds at test time (numpy PCG64 is
-deterministic), so the fixture stays a few KB.
+The fixture stores, per case: the topology name/kwargs, frame seed, the torch fp32 and fp64 probabilities, the
+fp64 LOGITS (input of the final softmax) and three intermediate tensors (first frame, stored as float32 of the
+fp64 result).  Inputs/weights are regenerated from their seeds at test time (numpy PCG64 is deterministic).
+
+The case ``padding_zoo`` is evaluated by a SECOND torch evaluator that shares no padding arithmetic with the oracle or
+with the first evaluator: stride-1 'same' goes through torch's own ``padding='same'``, stride-2 / even-kernel 'same' pads
+come from a table of literals worked out by hand from the TensorFlow documentation's rule (pad_along = max((ceil(n/s) -
+1)*s + k - n, 0), pad_before = pad_along // 2), 'same' average pooling uses ``count_include_pad=False`` (+ ``ceil_mode``
+for a trailing partial window), 'leaky_relu' is ``F.leaky_relu(x, 0.2)`` — Keras' default slope written out.
 
 Usage:  python tests/golden/make_cnn_golden.py
 """
@@ -27,16 +33,26 @@ from timed_hip import synth  # noqa: E402
 
 CASES = [
     # name, builder, kwargs, n_frames, frame kwargs
-    ("timed20", "timed_synth", dict(n_classes=20), 2, dict(seed=1234)),
-    ("timed338", "timed_synth", dict(n_classes=338), 2, dict(seed=1235)),
+    ("timed20", "timed_synth", dict(n_classes=20), 8, dict(seed=1234)),
+    ("timed338", "timed_synth", dict(n_classes=338), 8, dict(seed=1235)),
     ("timed20_c5_bias", "timed_synth", dict(n_classes=20, in_channels=5, bias_std=0.1, seed=7), 2,
      dict(seed=11, channels=5)),
     ("timed20_bool", "timed_synth", dict(n_classes=20, seed=99), 2, dict(seed=12, gaussian=False)),
-    ("densecpd20", "densecpd_synth", dict(n_classes=20), 2, dict(seed=1236)),
-    ("prodconn20", "prodconn_synth", dict(n_classes=20, bias_std=0.05), 2, dict(seed=1237)),
+    ("densecpd20", "densecpd_synth", dict(n_classes=20), 8, dict(seed=1236)),
+    ("prodconn20", "prodconn_synth", dict(n_classes=20, bias_std=0.05), 8, dict(seed=1237)),
     ("timed_small", "timed_synth", dict(n_classes=20, widths=(8, 16, 16), side=9, in_channels=4, bias_std=0.2), 3,
      dict(seed=5, side=9, channels=4, atoms=30)),
+    ("padding_zoo", "padding_zoo_synth", dict(n_classes=20), 6, dict(seed=21, side=11, channels=4, atoms=60)),
 ]
+ZOO = {"padding_zoo"}
+
+# 'same' pads (before, after) per spatial axis, keyed by (input extent, kernel extent, stride) — literals, worked out
+# by hand from the TensorFlow rule quoted in the module docstring; the zoo evaluator refuses anything not listed.
+SAME_PAD_LITERALS = {
+    (11, 4, 1): (1, 2),     # out 11: pad_along = 10 + 4 - 11 = 3
+    (6, 3, 2): (0, 1),      # out 3:  pad_along = 4 + 3 - 6 = 1
+    (2, 2, 1): (0, 1),      # out 2:  pad_along = 1 + 2 - 2 = 1
+}
 
 
 def same_pad(n, k, s, d=1):
@@ -113,7 +129,79 @@ def torch_forward(cfg, weights, frames, dt):
         else:
             raise ValueError(cn)
         vals[name] = y
-    return vals[cfg["config"]["output_layers"][0][0]].numpy()
+    return vals
+
+
+def torch_forward_zoo(cfg, weights, frames, dt):
+    """Independent evaluator for the padding_zoo case (see the module docstring): no same_pad() here."""
+    vals = {}
+    W = {k: [torch.from_numpy(np.asarray(a)).to(dt) for a in v] for k, v in weights.items()}
+    acts = {None: lambda t: t, "linear": lambda t: t, "relu": F.relu, "elu": lambda t: F.elu(t, 1.0),
+            "leaky_relu": lambda t: F.leaky_relu(t, 0.2)}
+    for lc in cfg["config"]["layers"]:
+        cn, c, name = lc["class_name"], lc["config"], lc["name"]
+        xs = [vals[t[0]] for t in lc["inbound_nodes"][0]] if lc["inbound_nodes"] else []
+        w = W.get(name, [])
+        if cn == "InputLayer":
+            y = torch.from_numpy(np.asarray(frames)).to(dt).permute(0, 4, 1, 2, 3).contiguous()
+        elif cn == "Conv3D":
+            x = xs[0]
+            k, s = tuple(c["kernel_size"]), tuple(c["strides"])
+            kern = w[0].permute(4, 3, 0, 1, 2).contiguous()
+            assert c["padding"] == "same"
+            if s == (1, 1, 1) and all(kk % 2 == 1 for kk in k):
+                y = F.conv3d(x, kern, w[1], stride=1, padding="same")           # torch's own 'same'
+            else:
+                pads = [SAME_PAD_LITERALS[(x.shape[2 + i], k[i], s[i])] for i in range(3)]
+                x = F.pad(x, (pads[2][0], pads[2][1], pads[1][0], pads[1][1], pads[0][0], pads[0][1]))
+                y = F.conv3d(x, kern, w[1], stride=s)
+            y = acts[c["activation"]](y)
+        elif cn == "LeakyReLU":
+            y = F.leaky_relu(xs[0], c["alpha"])
+        elif cn == "AveragePooling3D":
+            n, k, s = xs[0].shape[2], c["pool_size"][0], c["strides"][0]
+            assert c["padding"] == "same"
+            if (n, k, s) == (11, 2, 2):      # out 6, one trailing partial window: pad_along 1 = (0, 1)
+                y = F.avg_pool3d(xs[0], 2, 2, ceil_mode=True, count_include_pad=False)
+            elif (n, k, s) == (3, 3, 1):     # out 3, pad_along 2 = (1, 1)
+                y = F.avg_pool3d(xs[0], 3, 1, padding=1, count_include_pad=False)
+            else:
+                raise ValueError((n, k, s))
+        elif cn == "MaxPooling3D":
+            n, k, s = xs[0].shape[2], c["pool_size"][0], c["strides"][0]
+            assert c["padding"] == "same" and (n, k, s) == (3, 3, 2)     # out 2, pad_along 2 = (1, 1); torch pads with -inf
+            y = F.max_pool3d(xs[0], 3, 2, padding=1)
+        elif cn == "Flatten":
+            y = xs[0].permute(0, 2, 3, 4, 1).reshape(xs[0].shape[0], -1)
+        elif cn == "Dense":
+            y = xs[0] @ w[0] + w[1]
+        elif cn == "Softmax":
+            y = F.softmax(xs[0], dim=1)
+        else:
+            raise ValueError(cn)
+        vals[name] = y
+    return vals
+
+
+def logits_layer(cfg):
+    """name of the tensor the final softmax reads (None when the model does not end in a Softmax layer)"""
+    layers = {l["name"]: l for l in cfg["config"]["layers"]}
+    last = layers[cfg["config"]["output_layers"][0][0]]
+    if last["class_name"] == "Softmax":
+        return last["inbound_nodes"][0][0][0]
+    return None
+
+
+def probe_layers(cfg):
+    """three spatial tensors spread over the depth of the net"""
+    names = [l["name"] for l in cfg["config"]["layers"]
+             if l["class_name"] in ("Conv3D", "BatchNormalization", "MaxPooling3D", "AveragePooling3D", "ELU", "ReLU", "LeakyReLU")]
+    return [names[len(names) * q // 4] for q in (1, 2, 3)]
+
+
+def to_channels_last(t):
+    a = t.numpy()
+    return np.ascontiguousarray(np.moveaxis(a, 1, -1)) if a.ndim == 5 else a
 
 
 def main():
@@ -124,8 +212,10 @@ def main():
     for name, builder, kw, n, fkw in CASES:
         cfg, weights = getattr(synth, builder)(**kw)
         frames = synth.synthetic_frames(n, **fkw)
-        y32 = torch_forward(cfg, weights, frames, torch.float32)
-        y64 = torch_forward(cfg, weights, frames, torch.float64)
+        fwd = torch_forward_zoo if name in ZOO else torch_forward
+        out_name = cfg["config"]["output_layers"][0][0]
+        v32, v64 = fwd(cfg, weights, frames, torch.float32), fwd(cfg, weights, frames, torch.float64)
+        y32, y64 = v32[out_name].numpy(), v64[out_name].numpy()
         o32 = cnn_oracle.forward(cfg, weights, frames, np.float32)
         o64 = cnn_oracle.forward(cfg, weights, frames, np.float64)
         print(f"{name:18s} torch32-vs-64 {np.abs(y32 - y64).max():.2e}  oracle32-vs-torch64 "
@@ -133,7 +223,13 @@ def main():
               f"argmax equal {np.array_equal(o32.argmax(1), y64.argmax(1))}  pmax {y64.max():.3f}")
         out[f"{name}__torch32"] = y32.astype(np.float32)
         out[f"{name}__torch64"] = y64.astype(np.float64)
-        meta.append(dict(name=name, builder=builder, kwargs=kw, n=n, frame_kwargs=fkw))
+        ll = logits_layer(cfg)
+        if ll is not None:
+            out[f"{name}__logits64"] = v64[ll].numpy().astype(np.float64)
+        probes = probe_layers(cfg)
+        for pn in probes:
+            out[f"{name}__layer__{pn}"] = to_channels_last(v64[pn][:1]).astype(np.float32)
+        meta.append(dict(name=name, builder=builder, kwargs=kw, n=n, frame_kwargs=fkw, logits_layer=ll, probes=probes))
     out["meta"] = np.array(json.dumps(meta))
     path = os.path.join(ROOT, "tests", "golden", "cnn_golden.npz")
     np.savez_compressed(path, **out)

@@ -1,7 +1,9 @@
 """Parity proper: the HIP engine, called through the C ABI, against the CPU oracle and the golden
-vectors.  Tolerance (BASELINE.json north_star): 1e-4 absolute on the logits and on the
-probabilities, identical argmax.  fp32 MFMA is an exact fmaf chain, so the observed error is
-accumulation-order noise (~1e-6)."""
+vectors.  The north-star tolerance (BASELINE.json) is 1e-4 absolute on the logits and on the
+probabilities with identical argmax; fp32 MFMA is an exact fmaf chain, the observed error is
+accumulation-order noise (3e-7), and the ASSERTED bound is within an order of magnitude of that:
+TIGHT = 5e-6 absolute on probabilities, logits and (scaled) intermediate tensors, against the
+fp64 torch fixtures (tests/golden/make_cnn_golden.py) and against the oracle."""
 import json
 import os
 
@@ -12,8 +14,9 @@ from oracle import cnn_oracle
 from timed_hip import _lib, engine, synth
 
 pytestmark = pytest.mark.gpu
-TOL = 1e-4
-CASES = ["timed20", "timed338", "timed20_c5_bias", "timed20_bool", "densecpd20", "prodconn20", "timed_small"]
+TOL = 1e-4          # the north-star bound (kept for the property tests that compare two GPU paths)
+TIGHT = 5e-6        # what is asserted against the fixtures and the oracle
+CASES = ["timed20", "timed338", "timed20_c5_bias", "timed20_bool", "densecpd20", "prodconn20", "timed_small", "padding_zoo"]
 
 
 def _build(meta, name):
@@ -39,17 +42,71 @@ def _logits_oracle(cfg, weights, frames):
 def test_forward_matches_oracle_and_golden(gpu, cnn_golden, name, flags):
     z, meta = cnn_golden
     cfg, weights, frames = _build(meta, name)
+    m = next(x for x in meta if x["name"] == name)
     model = engine.HipFrameModel.from_keras(cfg, weights, device=gpu, flags=flags)
     probs = model.predict(frames)
     assert probs.dtype == np.float32 and probs.shape == z[f"{name}__torch32"].shape
-    logits_ref, probs_ref = _logits_oracle(cfg, weights, frames)
-    np.testing.assert_allclose(probs, probs_ref, atol=TOL, rtol=0)
-    np.testing.assert_allclose(probs, z[f"{name}__torch64"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(probs, z[f"{name}__torch64"], atol=TIGHT, rtol=0)       # 8 frames per full-size case
     np.testing.assert_allclose(probs.sum(1), 1.0, atol=1e-5)
-    assert np.array_equal(probs.argmax(1), probs_ref.argmax(1))
-    if logits_ref is not None:
+    assert np.array_equal(probs.argmax(1), z[f"{name}__torch64"].argmax(1))
+    n_or = min(len(frames), 3)                                                          # the oracle on a few of them
+    logits_ref, probs_ref = _logits_oracle(cfg, weights, frames[:n_or])
+    np.testing.assert_allclose(probs[:n_or], probs_ref, atol=TIGHT, rtol=0)
+    if m["logits_layer"]:
         logits = model.predict(frames, logits=True)
-        np.testing.assert_allclose(logits, logits_ref, atol=TOL, rtol=0)
+        np.testing.assert_allclose(logits, z[f"{name}__logits64"], atol=TIGHT, rtol=0)   # torch fp64 logits
+        np.testing.assert_allclose(logits[:n_or], logits_ref, atol=TIGHT, rtol=0)
+    model.close()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_intermediate_tensors_match_torch_fixture(gpu, cnn_golden, name):
+    """three tensors spread over the depth of each net (fp64 torch results stored in the fixture) against the engine's
+    kept layer outputs"""
+    z, meta = cnn_golden
+    cfg, weights, frames = _build(meta, name)
+    m = next(x for x in meta if x["name"] == name)
+    model = engine.HipFrameModel.from_keras(cfg, weights, device=gpu, flags=_lib.TH_LOAD_KEEP_ALL)
+    model.predict(frames[:1])
+    checked = 0
+    for pn in m["probes"]:
+        want = z[f"{name}__layer__{pn}"]
+        try:
+            got = model.fetch(pn, 1, want.shape[1:])
+        except _lib.TimedHipError as e:
+            # the converter's exact graph rewrite (BatchNorm / pooling pushed through a Concatenate of conv branches,
+            # timed_hip/keras_config.py) replaces some layers of branchy nets by per-branch ones: no such tensor exists
+            assert "no layer named" in str(e) and name == "prodconn20", (pn, str(e))
+            continue
+        np.testing.assert_allclose(got, want, atol=TIGHT * max(1.0, float(np.abs(want).max())), rtol=0, err_msg=pn)
+        checked += 1
+    assert checked >= 2
+    model.close()
+
+
+def _keras_real_fixtures():
+    import glob
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    return sorted(p for p in glob.glob(os.path.join(g, "keras_real_*.npz")) if os.path.exists(p[:-4] + ".h5"))
+
+
+@pytest.mark.parametrize("path", _keras_real_fixtures() or [None])
+def test_engine_matches_real_keras_fixture(gpu, path):
+    """Picks up tests/golden/keras_real_<model>.npz/.h5 written by tools/validate_against_keras.py --emit-fixture (needs
+    TensorFlow 2.13 + a released model: absent from the build image, so CNN parity is 'unpinned' until one exists).  The
+    .h5 goes through the engine's own loader (reference predict.py:121) and the probabilities must agree with Keras'
+    predict (reference predict.py:142) within the north-star bound."""
+    if path is None:
+        pytest.skip("no tests/golden/keras_real_*.npz fixture")
+    z = np.load(path)
+    model = engine.load_model(path[:-4] + ".h5", device=gpu)
+    probs = model.predict(z["frames"])
+    np.testing.assert_allclose(probs, z["keras_probs"], atol=TOL, rtol=0)
+    top2 = np.sort(z["keras_probs"], axis=1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > TOL
+    assert np.array_equal(probs.argmax(1)[clear], z["keras_probs"].argmax(1)[clear])
+    if "keras_logits" in z.files:
+        np.testing.assert_allclose(model.predict(z["frames"], logits=True), z["keras_logits"], atol=TOL, rtol=0)
     model.close()
 
 
@@ -62,7 +119,7 @@ def test_input_dtypes_agree(gpu):
     for dt in (np.float64, np.uint8, np.bool_, np.float16):
         assert np.array_equal(model.predict(fb.astype(dt)), base), dt
     ref = cnn_oracle.forward(cfg, weights, fb)
-    np.testing.assert_allclose(base, ref, atol=TOL, rtol=0)
+    np.testing.assert_allclose(base, ref, atol=TIGHT, rtol=0)
 
 
 @pytest.mark.parametrize("n,chunk", [(1, 4), (7, 4), (8, 4), (33, 16), (0, 4)])
@@ -76,7 +133,7 @@ def test_ragged_batches_and_chunking(gpu, n, chunk):
     assert probs.shape == (n, 20)
     if n:
         ref = cnn_oracle.forward(cfg, weights, frames)
-        np.testing.assert_allclose(probs, ref, atol=TOL, rtol=0)
+        np.testing.assert_allclose(probs, ref, atol=TIGHT, rtol=0)
         # frame independence: the same frame gives the same bits wherever it sits in the batch
         again = model.predict(frames[::-1].copy())[::-1]
         assert np.array_equal(again, probs)

@@ -237,6 +237,27 @@ def prodconn_synth(n_classes: int = 20, in_channels: int = 6, side: int = 21, se
     return b.finish(x)
 
 
+def padding_zoo_synth(n_classes: int = 20, in_channels: int = 4, side: int = 11, seed: int = 4321, bias_std: float = 0.1):
+    """Every padding rule of SURVEY Appendix A in one small net (a parity-test case, not a benchmark): 'same' with odd,
+    anisotropic and EVEN kernels, stride-2 'same' (asymmetric: the extra row goes after), 'same' average / max
+    pooling (padding excluded from the average's divisor), a Conv3D with activation='leaky_relu' (slope 0.2) and a
+    LeakyReLU layer with its own alpha."""
+    b = KerasGraphBuilder((side, side, side, in_channels), seed=seed, bias_std=bias_std, name="padding_zoo")
+    x = b.conv3d(b.input_name, 8, 3, padding="same", activation="leaky_relu")
+    x = b.conv3d(x, 8, (1, 3, 5), padding="same")
+    x = b.leaky_relu(x, 0.1)
+    x = b.conv3d(x, 12, 4, padding="same", activation="relu")
+    x = b.avgpool(x, 2, 2, padding="same")
+    x = b.conv3d(x, 12, 3, strides=2, padding="same", activation="elu")
+    x = b.avgpool(x, 3, 1, padding="same")
+    x = b.maxpool(x, 3, 2, padding="same")
+    x = b.conv3d(x, 16, 2, padding="same")
+    x = b.flatten(x)
+    x = b.dense(x, n_classes)
+    x = b.softmax(x)
+    return b.finish(x)
+
+
 TOPOLOGIES = {
     "timed": lambda **kw: timed_synth(20, **kw),
     "timed_rotamer": lambda **kw: timed_synth(338, **kw),

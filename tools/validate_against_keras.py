@@ -7,11 +7,14 @@ NOT runnable in the build image (no TensorFlow, no released .h5 — SURVEY.md §
 "parity unpinned" against TF for that reason).  Anyone who has both can close that gap:
 
     pip install tensorflow==2.13.0 h5py
-    python tools/validate_against_keras.py --model TIMED.h5 [--frames data.hdf5 | --synthetic 64] [--save-golden out.npz]
+    python tools/validate_against_keras.py --model TIMED.h5 [--frames data.hdf5 | --synthetic 64] [--emit-fixture]
 
 Exit status 0 when max |p_keras - p_oracle| <= 1e-4 and the argmax agrees on every frame whose top-2 margin
 exceeds 1e-4 (the north-star tolerance), for the oracle and, if available, for the HIP engine.
-`--save-golden` writes inputs + Keras outputs as a fixture that tests can pin to afterwards."""
+`--emit-fixture` writes tests/golden/keras_real_<model>.npz (the frames, Keras' probabilities and — when the model ends in
+a Softmax layer — Keras' logits) and a copy of the .h5 beside it as keras_real_<model>.h5: tests/test_oracle_cnn.py and
+tests/test_gpu_cnn.py pick every such pair up automatically and from then on the oracle and the HIP engine are pinned to
+TensorFlow's own output."""
 import argparse
 import os
 import sys
@@ -29,6 +32,7 @@ def main():
     ap.add_argument("--frames", help="aposteriori .hdf5 frame dataset; default: synthetic frames")
     ap.add_argument("--synthetic", type=int, default=64, help="number of synthetic frames when --frames is not given")
     ap.add_argument("--save-golden", help="write inputs and Keras probabilities to this .npz")
+    ap.add_argument("--emit-fixture", action="store_true", help="write tests/golden/keras_real_<model>.npz + .h5 (see above)")
     ap.add_argument("--tol", type=float, default=1e-4)
     args = ap.parse_args()
 
@@ -73,6 +77,19 @@ def main():
         agree = bool(np.array_equal(got.argmax(1)[clear], want.argmax(1)[clear]))
         print(f"[validate] {name:6s}: max |dp| = {err:.3e} (tolerance {args.tol:g}); argmax agrees on {int(clear.sum())} clear frames: {agree}")
         ok &= err <= args.tol and agree
+    if args.emit_fixture:
+        import shutil
+        stem = os.path.splitext(os.path.basename(args.model))[0]
+        gold = os.path.join(ROOT, "tests", "golden")
+        extra = {}
+        last = keras_model.layers[-1]
+        if last.__class__.__name__ == "Softmax":     # logits = the tensor the final Softmax layer reads
+            logits_model = tf.keras.Model(keras_model.input, last.input)
+            extra["keras_logits"] = np.asarray(logits_model.predict(X), dtype=np.float32)
+        np.savez_compressed(os.path.join(gold, f"keras_real_{stem}.npz"), frames=X, keras_probs=want,
+                            tf_version=tf.__version__, **extra)
+        shutil.copyfile(args.model, os.path.join(gold, f"keras_real_{stem}.h5"))
+        print(f"[validate] wrote tests/golden/keras_real_{stem}.npz and .h5")
     if args.save_golden:
         np.savez_compressed(args.save_golden, frames=X, keras_probs=want, model=os.path.basename(args.model))
         print(f"[validate] wrote {args.save_golden}: drop it under tests/golden/ to pin the oracle to Keras")
