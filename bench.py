@@ -43,7 +43,16 @@ PEAK_HBM_GBS = 8000.0           # HBM3E spec
 def cpu_baseline(cfg, weights, topology: str, budget_s: float = 15.0):
     """Time the oracle (NumPy + multithreaded BLAS) on a bounded sample of the same workload."""
     from oracle import cnn_oracle
-    from timed_hip import synth
+    from timed_hip import _lib, synth
+    # the container may expose every host core but enforce a CPU quota (cgroup cpu.max): a BLAS pool wider than the
+    # quota is throttled in 100 ms periods, so the pool is limited to the CPUs this process can really use
+    usable = _lib.load().th_host_cpus()
+    limiter = None
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=usable, user_api="blas")
+    except Exception:
+        pass
     cnn_oracle.forward(cfg, weights, synth.synthetic_frames(1, seed=999))  # warm up BLAS threads
     # grow the sample until it holds >= 10 s of CPU work (small batches run far below the large-batch rate,
     # so a single calibration point would under-size it); the last, largest run is the one reported
@@ -63,9 +72,12 @@ def cpu_baseline(cfg, weights, topology: str, budget_s: float = 15.0):
         threads = max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] or [1])
     except Exception:
         pass
+    if limiter is not None:
+        limiter.restore_original_limits()
     return dict(value=n / dt, unit="frames/s", cores=threads, kind="port",
                 sample=f"{n} synthetic frames of {topology} through oracle/cnn_oracle.py (NumPy im2col + BLAS sgemm on "
-                       f"{threads} threads of {os.cpu_count()} host cores, fp32), {dt:.1f} s wall")
+                       f"{threads} threads; {os.cpu_count()} host cores visible, {usable} usable under the container's CPU "
+                       f"quota; fp32), {dt:.1f} s wall")
 
 
 def pmc_traffic(label: str, avg_ms: float):

@@ -61,6 +61,8 @@ typedef struct th_comm th_comm;
 int th_version(void);                 /* ABI version, currently 1 */
 const char* th_last_error(void);
 int th_device_count(int* n_out);
+/* CPUs the host-side thread pools of this library will use: min(hardware threads, affinity, cgroup CPU quota) */
+int th_host_cpus(void);
 /* name/arch of a device, e.g. "AMD Instinct MI355X" / "gfx950" */
 int th_device_info(int device, char* name, size_t name_len, char* arch, size_t arch_len, int* cus);
 
@@ -194,11 +196,32 @@ int64_t th_format_csv(const void* data, int dtype, int64_t n, int64_t k, char* o
  * datasets that share one geometry (shape[rank], chunk[rank], element size, filter pipeline ids in write order:
  * 1 deflate, 2 shuffle, 3 fletcher32) and whose chunk B-trees (version 1) start at btree_addrs[i], inflate every
  * chunk and scatter it into dests[i] (C order, shape[] elements of esz bytes) on nthreads host threads (0 = all
- * cores, at most 128).  Unallocated chunks read as zeros.  TH_EUNSUP when the file uses something else (the
+ * usable CPUs — th_host_cpus() —, at most 128).  Unallocated chunks read as zeros.  TH_EUNSUP when the file uses something else (the
  * caller then reads through its generic path). */
 int th_h5_read_chunked(const void* file, int64_t file_len, int64_t base, int64_t n_datasets, const int64_t* btree_addrs,
                        void* const* dests, int rank, const int64_t* shape, const int64_t* chunk, int esz, int n_filters,
                        const int* filter_ids, int nthreads);
+
+/* the same with a conversion while the chunks are placed: conv 0 = bytes as stored, 1 = float64 -> float32 (round to
+ * nearest even: exactly the cast Keras applies to load_batch's float64 frames; halves the host->device bytes) */
+int th_h5_read_chunked_as(const void* file, int64_t file_len, int64_t base, int64_t n_datasets, const int64_t* btree_addrs,
+                          void* const* dests, int rank, const int64_t* shape, const int64_t* chunk, int esz, int n_filters,
+                          const int* filter_ids, int nthreads, int conv);
+/* contiguous (unchunked, unfiltered) datasets: data_addrs[i] = file address of `count` elements of `esz` bytes, -1 = never
+ * written (zeros) */
+int th_h5_read_contiguous_as(const void* file, int64_t file_len, int64_t base, int64_t n_datasets, const int64_t* data_addrs,
+                             void* const* dests, int64_t count, int esz, int conv);
+/* Resolve MANY datasets' object headers in one call — the per-residue `dataset[pdb][chain][res]` header parse and the
+ * two attribute reads of load_batch (`encoded_residue`, utils.py:529) and create_flat_dataset_map (`label`,
+ * utils.py:375).  ohdr_addrs[n] are object-header addresses (from the chain groups' symbol tables).  Outputs:
+ * btree_out[i] (chunk B-tree address or -1), geom_out[40] (rank, shape[7], chunk[7], element size, datatype class,
+ * signed, n_filters, filter ids[8], layout class (1 contiguous: btree_out is then the data address; 2 chunked) of the
+ * FIRST dataset), status_out[i] bits: 1 = storage with exactly geom_out's geometry, 2 = numeric attribute `num_attr` copied to num_out[i*num_len ..] as doubles, 4 = string
+ * attribute `str_attr` copied NUL-terminated to str_out[i*str_len ..].  Either attribute name may be NULL.  A clear
+ * bit means "use the general reader for this one"; nothing is guessed. */
+int th_h5_resolve(const void* file, int64_t file_len, int64_t base, int64_t n, const int64_t* ohdr_addrs, const char* num_attr,
+                  double* num_out, int num_len, const char* str_attr, char* str_out, int str_len, int64_t* btree_out,
+                  int64_t* geom_out, int* status_out, int nthreads);
 
 /* ---- multi-GPU reassembly (no reference counterpart: the reference is single-process) ----- */
 /* one process per GPU; rank 0 creates the id and ships it to the others out of band */

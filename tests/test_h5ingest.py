@@ -65,3 +65,104 @@ def test_native_reader_reports_corrupt_btree_address():
                                 (C.c_void_p * 1)(dest.ctypes.data), 2, (C.c_int64 * 2)(4, 4), (C.c_int64 * 2)(2, 2), 8, 1,
                                 (C.c_int * 1)(32000), 1)
     assert rc != 0     # unknown filter id
+
+
+@pytest.mark.parametrize("name", ["frames_tiny.hdf5", "frames_tiny_bool.hdf5"])
+def test_native_header_resolution_equals_python_reader(name):
+    """th_h5_resolve (object headers, `encoded_residue`, `label` for a whole batch in one call) against h5lite's own
+    per-dataset parse, which is pinned to real-h5py fixtures in test_host_utils.py"""
+    path = os.path.join(G, name)
+    with h5lite.File(path) as f:
+        addrs, want_label, want_enc, want_geo = [], [], [], []
+        for pdb in f:
+            for chain in f[pdb].keys():
+                grp = f[pdb][chain]
+                links = grp._load()
+                for res in grp.keys():
+                    ds = grp[res]
+                    addrs.append(links[res])
+                    want_label.append(utils._as_str(ds.attrs["label"]))
+                    want_enc.append(np.asarray(ds.attrs["encoded_residue"], dtype=float))
+                    want_geo.append(ds.chunked_geometry())
+        r = h5lite.resolve_many(f, addrs, num_attr="encoded_residue", num_len=20, str_attr="label", str_len=16)
+        assert r is not None and np.all((r["status"] & 6) == 6)
+        # bit 1 = "stored exactly like the first dataset" (the fixtures mix contiguous and gzip-chunked residues on purpose;
+        # a real aposteriori file is homogeneous): the others are left to the general reader
+        same_as_first = np.array([(geo is None) == (want_geo[0] is None) and (geo is None or geo[1:] == want_geo[0][1:])
+                                  for geo in want_geo])
+        assert np.array_equal((r["status"] & 1).astype(bool), same_as_first)
+        assert r["strs"] == want_label
+        assert np.array_equal(r["num"], np.stack(want_enc))
+        g = r["geom"]
+        rank = int(g[0])
+        for i, geo in enumerate(want_geo):
+            if not same_as_first[i]:
+                assert int(r["btree"][i]) == -1
+                continue
+            if geo is None:                      # contiguous storage: the address slot carries the data address
+                assert int(g[27]) == 1
+                continue
+            btree, shape, chunk, esz, filters = geo
+            assert int(g[27]) == 2 and int(r["btree"][i]) == btree
+            assert tuple(g[1:1 + rank]) == shape and tuple(g[8:8 + rank]) == chunk and int(g[15]) == esz
+            assert tuple(int(x) for x in g[19:19 + int(g[18])]) == filters
+        # an attribute that is not there / a wrong length leaves the bit clear instead of guessing
+        r2 = h5lite.resolve_many(f, addrs[:3], num_attr="encoded_residue", num_len=19, str_attr="nope", str_len=8)
+        assert np.all((r2["status"] & 6) == 0) and np.array_equal((r2["status"] & 1).astype(bool), same_as_first[:3])
+        # a group's header is not a dataset: no geometry bit, nothing crashes
+        root_links = f._root._load()
+        r3 = h5lite.resolve_many(f, [next(iter(root_links.values()))], num_attr="encoded_residue", num_len=20)
+        assert int(r3["status"][0]) == 0 and int(r3["btree"][0]) == -1
+        # garbage addresses are refused, not dereferenced
+        r4 = h5lite.resolve_many(f, [addrs[0], 10 ** 12, 3], num_attr="encoded_residue", num_len=20)
+        assert int(r4["status"][0]) == 3 and int(r4["status"][1]) == 0 and (int(r4["status"][2]) & 1) == 0
+        # a batch whose first dataset is of the OTHER storage kind resolves that kind natively instead
+        other = int(np.nonzero(~same_as_first)[0][0]) if not same_as_first.all() else None
+        if other is not None:
+            r5 = h5lite.resolve_many(f, [addrs[other]] + addrs, num_attr="encoded_residue", num_len=20)
+            got = (r5["status"][1:] & 1).astype(bool)
+            assert (r5["status"][0] & 1) and got[other] and not np.any(got & same_as_first)
+
+
+def test_load_batch_float32_option_is_the_keras_cast():
+    """dtype=np.float32: the float64 -> float32 rounding happens while the chunks are placed and equals NumPy's cast of the
+    reference-dtype batch bit for bit; labels unchanged; boolean datasets ignore the option"""
+    path = os.path.join(G, "frames_tiny.hdf5")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        flat, _ = utils.create_flat_dataset_map(path)
+    X64, y64 = utils.load_batch(path, flat)
+    X32, y32 = utils.load_batch(path, flat, dtype=np.float32)
+    assert X64.dtype == np.float64 and X32.dtype == np.float32
+    assert np.array_equal(X32, X64.astype(np.float32)) and np.array_equal(y32, y64)
+    # arbitrary row order and repeated rows
+    pick = [flat[i] for i in (5, 0, 5, 25, 12)]
+    Xp, yp = utils.load_batch(path, pick, dtype=np.float32)
+    assert np.array_equal(Xp, X32[[5, 0, 5, 25, 12]]) and np.array_equal(yp, y64[[5, 0, 5, 25, 12]])
+    pb = os.path.join(G, "frames_tiny_bool.hdf5")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fb, _ = utils.create_flat_dataset_map(pb)
+    Xb, _ = utils.load_batch(pb, fb, dtype=np.float32)
+    assert Xb.dtype == bool
+
+
+def test_load_batch_falls_back_per_dataset(monkeypatch):
+    """rows the native pass declines go through the general reader, the others stay native"""
+    path = os.path.join(G, "frames_tiny.hdf5")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        flat, _ = utils.create_flat_dataset_map(path)
+    want_X, want_y = utils.load_batch(path, flat)
+    real = h5lite.resolve_many
+
+    def flaky(f, addrs, **kw):
+        r = real(f, addrs, **kw)
+        r["status"][::3] = 0            # pretend every third header was unusual
+        return r
+    monkeypatch.setattr(h5lite, "resolve_many", flaky)
+    X, y = utils.load_batch(path, flat)
+    assert np.array_equal(X, want_X) and np.array_equal(y, want_y)
+    monkeypatch.setattr(h5lite, "resolve_many", lambda *a, **k: None)      # no native library at all
+    X, y = utils.load_batch(path, flat)
+    assert np.array_equal(X, want_X) and np.array_equal(y, want_y)

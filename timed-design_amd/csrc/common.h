@@ -30,6 +30,12 @@ void th_set_error(const char* fmt, ...);
         }                                                                                        \
     } while (0)
 
+// CPUs this process may actually use: min(hardware threads, scheduler affinity, cgroup CPU quota).  Containers often
+// expose every host core but enforce a quota (cpu.max); more runnable threads than the quota are throttled in 100 ms
+// periods — measured on the GPU box (256 cores visible, quota 16): 20 k frames/s inflated with 16 threads, a bimodal
+// 11 k / 100 k with 128.  Host-side thread pools size themselves with this.
+int th_usable_cpus();
+
 // ---- device-side views --------------------------------------------------------------------
 // A channels-last activation tensor, possibly a channel slice of a wider (concat) buffer.
 // element (f, v, c) lives at p[f*fs + v*cs + coff + c], v = (z*H + y)*W + x.

@@ -83,7 +83,7 @@ extern "C" int64_t th_format_csv(const void* data, int dtype, int64_t n, int64_t
     if (n == 0) return 0;
     const bool as_half = dtype == TH_F16;
     const HalfTable* tab = as_half ? &half_table() : nullptr;
-    unsigned hw = std::thread::hardware_concurrency();
+    unsigned hw = (unsigned)th_usable_cpus();
     const int64_t work = n * k;
     int nthreads = (int)std::min<int64_t>(hw ? std::min(hw, 32u) : 4, std::max<int64_t>(1, work / (as_half ? 200000 : 20000)));
     nthreads = std::max(1, std::min<int>(nthreads, (int)n));

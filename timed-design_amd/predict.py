@@ -91,9 +91,26 @@ def _run_groups(models, dataset_path, flat_dataset_map, groups, consume):
         return
     depth = 2 * len(models)
 
+    # Batches of an .hdf5 dataset are built in a ring of page-locked buffers (th_host_alloc), sized after the first batch:
+    # no 0.5 GB of first-touch page faults per batch, and the host->device copy runs on the DMA engine without blocking
+    # this thread.  A buffer is reused only after the ticket that read it has completed: at most 3 groups per model are
+    # outstanding (below) + the one being loaded + one spare.  Frame packs hand out memory-mapped rows instead.
+    ring, ring_owners = [], []
+    ring_size = 3 * len(models) + 2
+    max_rows = max(hi - lo for lo, hi in groups)
+    from timed_hip import framepack
+    use_ring = getattr(models[0], "accepts_pinned", False) and not framepack.is_pack(dataset_path)
+
     def load(k):
         lo, hi = groups[k]
-        return du.load_batch(dataset_path, flat_dataset_map[lo:hi])
+        # float32 frames: the rounding Keras applies to load_batch's float64 anyway, done while the chunks are placed
+        X, y = du.load_batch(dataset_path, flat_dataset_map[lo:hi], dtype=np.float32, out=ring[k % ring_size] if ring else None)
+        if k == 0 and not ring and use_ring and isinstance(X, np.ndarray) and X.base is None:
+            for _ in range(ring_size):
+                buf, owner = engine.pinned_empty((max_rows, *X.shape[1:]), X.dtype)
+                ring.append(buf)
+                ring_owners.append(owner)
+        return X, y
 
     def finish(ticket, labels):
         consume(ticket.result(), labels)
@@ -121,6 +138,9 @@ def _run_groups(models, dataset_path, flat_dataset_map, groups, consume):
             writing.append(writer.submit(finish, *pending.popleft()))
         while writing:
             writing.popleft().result()
+    del ring[:]
+    for owner in ring_owners:
+        owner.free()
 
 
 def _distributed_context(gather):
@@ -243,6 +263,8 @@ def _predict_sharded(model, gather, rank, world, dataset_path, flat_dataset_map,
                 cursor[0] += len(y)
 
             class _ToDevice:      # the model facade _run_groups drives: outputs land in d_local at the shard row
+                accepts_pinned = True
+
                 def __init__(self):
                     self.row = 0
 

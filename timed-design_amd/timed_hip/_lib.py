@@ -24,6 +24,7 @@ PROTOTYPES = {
     "th_version": (_i, []),
     "th_last_error": (C.c_char_p, []),
     "th_device_count": (_i, [_pi]),
+    "th_host_cpus": (_i, []),
     "th_device_info": (_i, [_i, C.c_char_p, _sz, C.c_char_p, _sz, _pi]),
     "th_model_load": (_i, [C.c_char_p, _i, _u, C.POINTER(_vp)]),
     "th_model_load_mem": (_i, [_vp, _sz, _i, _u, C.POINTER(_vp)]),
@@ -63,6 +64,9 @@ PROTOTYPES = {
     "th_comm_barrier": (_i, [_vp]),
     "th_format_csv": (_i64, [_vp, _i, _i64, _i64, _vp, _i64]),
     "th_h5_read_chunked": (_i, [_vp, _i64, _i64, _i64, _pi64, C.POINTER(_vp), _i, _pi64, _pi64, _i, _i, _pi, _i]),
+    "th_h5_read_chunked_as": (_i, [_vp, _i64, _i64, _i64, _pi64, C.POINTER(_vp), _i, _pi64, _pi64, _i, _i, _pi, _i, _i]),
+    "th_h5_read_contiguous_as": (_i, [_vp, _i64, _i64, _i64, _pi64, C.POINTER(_vp), _i64, _i, _i]),
+    "th_h5_resolve": (_i, [_vp, _i64, _i64, _i64, _pi64, C.c_char_p, _vp, _i, C.c_char_p, _vp, _i, _pi64, _pi64, _pi, _i]),
 }
 
 _lib = None
