@@ -584,16 +584,22 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// XC > 0: output channels 16..16+XC-1 (Cout = 17..20, e.g. the 20 amino-acid classes of a TIMED head) are
-// accumulated on the VALU pipe from the SAME A registers, interleaved under the MFMAs (two v_pk_fma_f32
-// per MFMA): the matrix pipe only runs the 16-wide tile instead of a 32-wide one padded with 12 zero columns.
+// XC > 0: output channels 16..16+XC-1 (Cout = 17..20, e.g. the 20 amino-acid classes of a TIMED head) ride on
+// v_mfma_f32_4x4x1_16B_f32 from the SAME A registers: the instruction is 16 independent 4x4 outer products (lane
+// 4b+i supplies A_b[i] and B_b[i]; VGPR r of lane 4b+j receives D_b[r][j] — checked on hardware,
+// tools/microbench/mfma_4x4x1_layout.hip).  With lane (i16, q) holding channels 4q..4q+3 of tile row i16, block
+// b = 4q + (i16>>2) multiplies rows 4(i16>>2)..+3 at channel 4q+t by W[4q+t][16 + (i16&3)]: exactly 4 rows x 4 extra
+// channels per block, nothing padded, 25 % more matrix-pipe time for 25 % more channels (a 32-wide tile would spend
+// 12 of 32 columns on zeros; the round-1 version ran these channels as 64 scalar FMAs per tap per wave on the VALU
+// pipe and could not afford the next-chunk prefetch).  The four blocks of a row group hold partial sums over the
+// channel quarters q; they are added with two cross-lane exchanges in the epilogue.
 template <int WAVES, int TM, int POOL, int XC = 0>
 __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(const ConvMfmaArgs a) {
-    static_assert(XC == 0 || (XC == 4 && TM <= 4 && POOL == 0), "VALU side channels: 4 channels, ping-pong variant, no pooling");
+    static_assert(XC == 0 || (XC == 4 && TM <= 4 && POOL == 0), "side channels: 4 channels (one 4x4x1 block column), ping-pong variant, no pooling");
     constexpr int NTHREADS = WAVES * 64;
     constexpr int CI = 16, CI4 = 4, NTAPS = 27;
     constexpr int BR = 9;                       // weight-ring depth (taps in flight)
-    constexpr int PF = XC ? 1 : ((TM <= 4) ? 11 : 14);   // float4 per thread of next-chunk prefetch (XC: registers go to the side channels)
+    constexpr int PF = (TM <= 4) ? 11 : 14;   // float4 per thread of next-chunk prefetch
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -658,7 +664,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
     // next-chunk prefetch: when the whole staged image is <= PF float4 per thread, the global loads of the
     // NEXT chunk (or of chunk 0 of this workgroup's next frame group) are issued before the MFMA phase of the
     // current chunk and land in registers underneath it
-    const bool can_pf = !XC && rounds == 1 && nvec <= PF * NTHREADS && a.vec_ok && (a.Cin & 3) == 0 && !(a.dbg & 64);
+    const bool can_pf = rounds == 1 && nvec <= PF * NTHREADS && a.vec_ok && (a.Cin & 3) == 0 && !(a.dbg & 64);
 
     // nvalid: frames of the group that exist (the last group of a batch may be ragged)
     auto load_vec = [&](const float* inb, int nvalid, int ch, int i, bool* okp) -> float4 {
@@ -704,18 +710,17 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
     // use; the packed image is [chunk][tap][lane], the index runs on into the next chunk and wraps to chunk 0
     // for the next frame group
     float4 breg[BR];
-    // XC: this lane's (k-slot q) weights of the extra channels, xw[t % 3][c] = W_t[4q..4q+3][16 + c]; a slot is
-    // refilled with tap t + 3 right after use (27 taps = 9 turns of the ring, so slots line up across chunks)
-    const f32x4* wx4 = reinterpret_cast<const f32x4*>(a.wx) + q * (XC ? XC : 1);
-    f32x4 xw[3][XC ? XC : 1];
+    // XC: this lane's B operand of the 4x4x1 blocks, xw[t % 3] = W_t[4q..4q+3][16 + (i16 & 3)] (packed image
+    // [chunk][tap][q][c][4]); a slot is refilled with tap t + 3 right after use (27 taps = 9 turns of the ring, so
+    // slots line up across chunks)
+    const f32x4* wx4 = reinterpret_cast<const f32x4*>(a.wx) + q * (XC ? XC : 1) + (XC ? (i16 & 3) : 0);
+    f32x4 xw[3];
     if (wave < total_blocks) {
 #pragma unroll
         for (int t = 0; t < BR; ++t) breg[t] = wpk4[(size_t)(t % wcount) * 64];
         if (XC) {
 #pragma unroll
-            for (int c = 0; c < XC; ++c)
-#pragma unroll
-                for (int r = 0; r < 3; ++r) xw[r][c] = wx4[(size_t)(r % wcount) * 4 * XC + c];
+            for (int r = 0; r < 3; ++r) xw[r] = wx4[(size_t)(r % wcount) * 4 * XC];
         }
     }
 
@@ -736,11 +741,9 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
             f32x4 acc[TM];
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) acc[tm] = f32x4{0.f, 0.f, 0.f, 0.f};
-            f32x2 xacc[XC ? TM : 1][XC ? XC : 1];   // (even, odd) k partial sums of row i16 over this lane's 4 channels
+            f32x4 xacc[XC ? TM : 1];   // 4x4x1 accumulators: VGPR r = row 4*(i16>>2)+r, this lane = extra channel i16&3, channel quarter q
 #pragma unroll
-            for (int tm = 0; tm < (XC ? TM : 1); ++tm)
-#pragma unroll
-                for (int c = 0; c < (XC ? XC : 1); ++c) xacc[tm][c] = f32x2{0.f, 0.f};
+            for (int tm = 0; tm < (XC ? TM : 1); ++tm) xacc[tm] = f32x4{0.f, 0.f, 0.f, 0.f};
             int aidx[TM];
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
@@ -828,32 +831,25 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
                                 acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.w, breg[t % BR].w, acc[tm], 0, 0, 0);
                             }
                         } else {
-                            // k-major MFMA order (4 independent tiles between dependent accumulations); MFMA (k, tm) is
-                            // followed by the two packed FMAs of (tile tm, side channel k), pinned by sched_group_barrier
+                            // k-major MFMA order (TM independent tiles between dependent accumulations); the 16-wide MFMA
+                            // of (k, tm) is followed by the 4x4x1 MFMA of the same A register for the side channels
                             const float bk[4] = {breg[t % BR].x, breg[t % BR].y, breg[t % BR].z, breg[t % BR].w};
+                            const f32x4 wv = xw[t % 3];
 #pragma unroll
                             for (int k = 0; k < 4; ++k) {
 #pragma unroll
                                 for (int tm = 0; tm < TM; ++tm) {
                                     const f32x4 aq = av[t & 1][tm];
                                     acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[k], bk[k], acc[tm], 0, 0, 0);
-                                    const f32x4 wv = xw[t % 3][k < XC ? k : 0];
-                                    xacc[tm][k < XC ? k : 0] = __builtin_elementwise_fma(aq.xy, wv.xy, xacc[tm][k < XC ? k : 0]);
-                                    xacc[tm][k < XC ? k : 0] = __builtin_elementwise_fma(aq.zw, wv.zw, xacc[tm][k < XC ? k : 0]);
+                                    xacc[tm] = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[k], wv[k], xacc[tm], 0, 0, 0);
                                 }
-                            }
-#pragma unroll
-                            for (int k = 0; k < 4 * TM; ++k) {
-                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
                             }
                         }
                         __builtin_amdgcn_sched_barrier(0);
                         if (XC) {
                             int widx = ch * NTAPS + t + 3;
                             widx = widx >= wcount ? widx - wcount : widx;
-#pragma unroll
-                            for (int c = 0; c < XC; ++c) xw[t % 3][c] = wx4[(size_t)min(widx, wcount - 1) * 4 * XC + c];
+                            xw[t % 3] = wx4[(size_t)min(widx, wcount - 1) * 4 * XC];
                         }
                         if (!PING) {
                             if (nt < NTAPS) {
@@ -940,23 +936,23 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
                     }
                 }
                 if (XC) {
-                    // VALU side channels: lane (i16, q) holds row i16's partial sums over channels 4q..4q+3 of every
-                    // chunk; add the four k-slot lanes, then lane q finishes output channel 16 + q
-                    const int cx = 16 + q;
+                    // side channels: lane (q, g = i16>>2, j = i16&3) holds, in VGPR r, the partial sum of row 4g+r, channel
+                    // 16+j over channel quarter q; add the four quarters (lanes 16 apart), then lane q finishes row 4g+q
+                    const int cx = 16 + (i16 & 3);
                     const bool xvalid = cx < a.Cout;
                     const float bx = (a.bias && xvalid) ? a.bias[cx] : 0.f;
 #pragma unroll
                     for (int tm = 0; tm < (XC ? TM : 1); ++tm) {
                         float mine = 0.f;
 #pragma unroll
-                        for (int c = 0; c < (XC ? XC : 1); ++c) {
-                            float v = xacc[tm][c][0] + xacc[tm][c][1];
+                        for (int r = 0; r < 4; ++r) {
+                            float v = xacc[tm][r];
                             v += __shfl_xor(v, 16);
                             v += __shfl_xor(v, 32);
-                            mine = (q == c) ? v : mine;
+                            mine = (q == r) ? v : mine;
                         }
                         const int mt = blk * TM + tm;
-                        const int row = mt * 16 + i16;
+                        const int row = mt * 16 + 4 * (i16 >> 2) + q;
                         const bool ok = xvalid && mt < n_mt && (nvalid == a.FB || row / a.rows_pf < nvalid);
                         const int oo = ok ? rowout[row] : -1;
                         if (oo >= 0) outb[oo + cx] = th_post(mine + bx, cx, a.post);
@@ -1133,7 +1129,7 @@ bool plan_n16(int variant, size_t lds_limit, const TView& in, const TView& oc, c
     char buf[224];
     snprintf(buf, sizeof buf, "conv_n16<w%d,tm%d,pool%d%s> FB%d rows%d lds%zuK (16x16x4 MFMA, weight ring%s) [k_conv_n16<%d,%d,%d%s>]",
              c.WAVES, c.TM, pool, xc ? ",xc4" : "", FB, p->rows_pf, p->lds_bytes / 1024,
-             xc ? ", channels 16.. on the VALU pipe" : "", c.WAVES, c.TM, pool, xc ? ",4" : "");
+             xc ? ", channels 16.. on 4x4x1 MFMA blocks" : "", c.WAVES, c.TM, pool, xc ? ",4" : "");
     p->label = buf;
     return true;
 }
