@@ -100,5 +100,23 @@ def main():
     np.savez_compressed(os.path.join(HERE, "h5_expected.npz"), **out)
 
 
+def write_fill_values(path, expect_path):
+    """datasets whose never-written elements must read as a user-defined NON-ZERO fill value: a chunked
+    dataset with only one chunk written, a never-written chunked one, a never-written contiguous one, and a zero-fill
+    control.  Expectations are what h5py itself reads back."""
+    with h5py.File(path, "w") as f:
+        d = f.create_dataset("partial", shape=(6, 8), dtype="f8", chunks=(3, 4), fillvalue=2.5, compression="gzip")
+        d[0:3, 0:4] = np.arange(12.0).reshape(3, 4)
+        f.create_dataset("never_chunked", shape=(4, 4), dtype="f4", chunks=(2, 2), fillvalue=-1.25)
+        f.create_dataset("never_contiguous", shape=(5,), dtype="i4", fillvalue=7)
+        z = f.create_dataset("zero_fill", shape=(6, 8), dtype="f8", chunks=(3, 4), compression="gzip")
+        z[3:6, 4:8] = 1.0
+    with h5py.File(path, "r") as f:
+        np.savez(expect_path, **{k: f[k][()] for k in f})
+
+
 if __name__ == "__main__":
-    main()
+    if "--fill-only" not in sys.argv:       # the other fixtures are only rewritten on request: their bytes are pinned in tests
+        main()
+    write_fill_values(os.path.join(HERE, "fillvalue_tiny.hdf5"), os.path.join(HERE, "fillvalue_expected.npz"))
+    print("wrote fillvalue_tiny.hdf5")

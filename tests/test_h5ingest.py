@@ -166,3 +166,42 @@ def test_load_batch_falls_back_per_dataset(monkeypatch):
     monkeypatch.setattr(h5lite, "resolve_many", lambda *a, **k: None)      # no native library at all
     X, y = utils.load_batch(path, flat)
     assert np.array_equal(X, want_X) and np.array_equal(y, want_y)
+
+
+def test_user_defined_fill_values_are_honoured_not_zeroed():
+    """ADVICE r1: never-written elements read as the dataset's fill value (fixture written and read back by real h5py);
+    the native bulk paths, which zero-fill, decline such datasets instead of guessing"""
+    path = os.path.join(G, "fillvalue_tiny.hdf5")
+    want = np.load(os.path.join(G, "fillvalue_expected.npz"))
+    with h5lite.File(path) as f:
+        for name in ("partial", "never_chunked", "never_contiguous", "zero_fill"):
+            got = np.asarray(f[name][()])
+            assert got.dtype == want[name].dtype and np.array_equal(got, want[name]), name
+        assert want["partial"][5, 7] == 2.5 and want["never_contiguous"][0] == 7
+        assert f["partial"].chunked_geometry() is None and f["never_chunked"].chunked_geometry() is None
+        assert f["zero_fill"].chunked_geometry() is not None
+        dest = np.empty((6, 8))
+        assert f["partial"].read_direct(dest) is False
+        assert h5lite.read_many_direct([f["partial"], f["zero_fill"]], [np.empty((6, 8)), dest]) == [False, True]
+        assert np.array_equal(dest, want["zero_fill"])
+        links = f._root._load()
+        r = h5lite.resolve_many(f, [links["zero_fill"], links["partial"]])
+        assert (int(r["status"][0]) & 1) == 1 and (int(r["status"][1]) & 1) == 0
+        r = h5lite.resolve_many(f, [links["partial"]])
+        assert (int(r["status"][0]) & 1) == 0
+
+
+def test_bulk_reader_requires_matching_dtype_kind():
+    """a 1-byte integer dataset is not silently byte-copied into a bool array (or uint8 into int8 ...)"""
+    path = os.path.join(G, "frames_tiny_bool.hdf5")
+    with h5lite.File(path) as f:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            flat, _ = utils.create_flat_dataset_map(path)
+        dss = [f[p][c][r] for p, c, r, _ in flat]
+        ds = next(d for d in dss if d.chunked_geometry() is not None)
+        w = np.asarray(ds[()])
+        assert w.dtype == bool
+        assert h5lite.read_many_direct([ds], [np.empty(w.shape, np.int8)]) == [False]
+        ok = np.empty(w.shape, bool)
+        assert h5lite.read_many_direct([ds], [ok]) == [True] and np.array_equal(ok, w)

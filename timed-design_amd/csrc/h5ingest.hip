@@ -408,7 +408,21 @@ extern "C" int th_h5_resolve(const void* file, int64_t file_len, int64_t base, i
             else if (m.type == 0x0B) filt = &m;
             if ((m.type == 0x01 || m.type == 0x03 || m.type == 0x08 || m.type == 0x0B) && (m.flags & 2)) shared = true;
         }
-        if (space && type && layout && !shared) {
+        // a user-defined NON-ZERO fill value (message 0x05, or the old 0x04) changes what never-written elements read as;
+        // this reader zero-fills, so such a dataset is left to the general reader
+        bool nonzero_fill = false;
+        for (const Msg& m : msgs) {
+            const uint8_t* d = m.data;
+            const uint8_t* v = nullptr;
+            uint32_t sz = 0;
+            if (m.type == 0x04 && m.size >= 4) { sz = rd<uint32_t>(d); v = d + 4; if (4 + (int64_t)sz > m.size) sz = 0; }
+            else if (m.type == 0x05 && m.size >= 2) {
+                if ((d[0] == 1 || (d[0] == 2 && m.size >= 4 && d[3])) && m.size >= 8) { sz = rd<uint32_t>(d + 4); v = d + 8; if (8 + (int64_t)sz > m.size) sz = 0; }
+                else if (d[0] == 3 && (d[1] & 0x20) && m.size >= 6) { sz = rd<uint32_t>(d + 2); v = d + 6; if (6 + (int64_t)sz > m.size) sz = 0; }
+            }
+            for (uint32_t k = 0; v && k < sz; ++k) if (v[k]) nonzero_fill = true;
+        }
+        if (space && type && layout && !shared && !nonzero_fill) {
             int rank = 0;
             int64_t dims[8];
             const int64_t cnt = dataspace_count(space->data, space->size, dims, &rank);

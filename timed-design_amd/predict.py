@@ -182,13 +182,6 @@ def load_dataset_and_predict(
     sharded = world > 1 or gather is not None      # an explicit transport selects the shard + gather path even for 1 rank
     if rank == 0:
         print(f"Predicting {n_classes} classes per residue ({'rotamer' if predict_rotamers else 'residue'} mode)")
-    if Path(dataset_map_path).exists():
-        flat_dataset_map = np.atleast_2d(np.genfromtxt(dataset_map_path, delimiter=",", dtype="str"))
-    else:
-        excluded = du.get_pdb_keys_to_filter(blacklist) if blacklist else []
-        flat_dataset_map, _ = du.create_flat_dataset_map(dataset_path, excluded)
-    old_datasetmap = len(flat_dataset_map[0]) == 4
-    codec, flat_categories = du.get_rotamer_codec() if predict_rotamers else (None, None)
     loader = model_loader or engine.load_model
     if world > 1:
         device_ids = [local_rank if devices is None else list(devices)[local_rank % len(devices)]]
@@ -196,44 +189,71 @@ def load_dataset_and_predict(
         device_ids = [device]
     else:
         device_ids = [device] if not devices else list(devices)
+    # the first model is loaded (device allocations, weight upload: native code) while this thread builds the dataset map
+    side = ThreadPoolExecutor(max_workers=1, thread_name_prefix="predict_side")
+    pending_handles = side.submit(lambda m=models[0]: [loader(Path(m), device=d) for d in device_ids]) if models else None
+    if Path(dataset_map_path).exists():
+        flat_dataset_map = np.atleast_2d(np.genfromtxt(dataset_map_path, delimiter=",", dtype="str"))
+    else:
+        excluded = du.get_pdb_keys_to_filter(blacklist) if blacklist else []
+        flat_dataset_map, _ = du.create_flat_dataset_map(dataset_path, excluded)
+    old_datasetmap = len(flat_dataset_map[0]) == 4
+    codec, flat_categories = du.get_rotamer_codec() if predict_rotamers else (None, None)
     outputs = (None,) * 5
-    for index, model_path in enumerate(models):
-        model_name = (model_path.stem if isinstance(model_path, Path) else str(model_path)) + model_name_suffix
-        handles = [loader(Path(model_path), device=d) for d in device_ids]
-        try:
-            for h in handles:
-                if h.n_classes != n_classes:
-                    raise ValueError(f"{model_path}: the model has {h.n_classes} outputs, predict_rotamers="
-                                     f"{predict_rotamers} needs {n_classes}")
-            if sharded:
-                done = _predict_sharded(handles[0], gather, rank, world, dataset_path, flat_dataset_map, batch_size,
-                                        start_batch, frames_per_call)
-                if rank != 0:
-                    continue
-                files = _OutputFiles(index, model_name, flat_dataset_map, path_to_output, predict_rotamers, codec,
-                                     resume=start_batch > 0)
-                probs, labels, row0 = done
-                for lo, hi in _row_groups(len(flat_dataset_map), batch_size, start_batch, frames_per_call):
-                    files.append(probs[lo - row0:hi - row0], labels[lo - row0:hi - row0])
-            else:
-                files = _OutputFiles(index, model_name, flat_dataset_map, path_to_output, predict_rotamers, codec,
-                                     resume=start_batch > 0)
-                _run_groups(handles, dataset_path, flat_dataset_map,
-                            _row_groups(len(flat_dataset_map), batch_size, start_batch, frames_per_call), files.append)
-        finally:
-            for h in handles:
-                h.close()
-        flat_dataset_map = np.array(flat_dataset_map)
-        du.convert_dataset_map_for_srb(flat_dataset_map, model_name, path_to_output)
-        outputs = du.extract_sequence_from_pred_matrix(
-            flat_dataset_map, files.prediction_matrix(), rotamers_categories=flat_categories if predict_rotamers else None,
-            old_datasetmap=old_datasetmap, is_consensus=is_consensus)
-        pdb_to_sequence, _prob, pdb_to_real_sequence, pdb_to_consensus, pdb_to_consensus_prob = outputs
-        du.save_dict_to_fasta(pdb_to_sequence, model_name, path_to_output)
-        du.save_dict_to_fasta(pdb_to_real_sequence, "dataset", path_to_output)
-        if pdb_to_consensus:
-            du.save_dict_to_fasta(pdb_to_consensus, model_name + "_consensus", path_to_output)
-            du.save_consensus_probs(pdb_to_consensus_prob, model_name, path_to_output)
+    try:
+        for index, model_path in enumerate(models):
+            model_name = (model_path.stem if isinstance(model_path, Path) else str(model_path)) + model_name_suffix
+            handles = pending_handles.result()
+            pending_handles = None
+            if index + 1 < len(models):      # the next model loads while this one runs
+                pending_handles = side.submit(lambda m=models[index + 1]: [loader(Path(m), device=d) for d in device_ids])
+            srb = None
+            try:
+                for h in handles:
+                    if h.n_classes != n_classes:
+                        raise ValueError(f"{model_path}: the model has {h.n_classes} outputs, predict_rotamers="
+                                         f"{predict_rotamers} needs {n_classes}")
+                if rank == 0:
+                    # <model>.txt depends on the map only: written on the side thread while the GPU works
+                    srb = side.submit(du.convert_dataset_map_for_srb, np.array(flat_dataset_map), model_name, path_to_output)
+                if sharded:
+                    done = _predict_sharded(handles[0], gather, rank, world, dataset_path, flat_dataset_map, batch_size,
+                                            start_batch, frames_per_call)
+                    if rank != 0:
+                        continue
+                    files = _OutputFiles(index, model_name, flat_dataset_map, path_to_output, predict_rotamers, codec,
+                                         resume=start_batch > 0)
+                    probs, labels, row0 = done
+                    for lo, hi in _row_groups(len(flat_dataset_map), batch_size, start_batch, frames_per_call):
+                        files.append(probs[lo - row0:hi - row0], labels[lo - row0:hi - row0])
+                else:
+                    files = _OutputFiles(index, model_name, flat_dataset_map, path_to_output, predict_rotamers, codec,
+                                         resume=start_batch > 0)
+                    _run_groups(handles, dataset_path, flat_dataset_map,
+                                _row_groups(len(flat_dataset_map), batch_size, start_batch, frames_per_call), files.append)
+            finally:
+                for h in handles:
+                    h.close()
+                if srb is not None:
+                    srb.result()
+            flat_dataset_map = np.array(flat_dataset_map)
+            outputs = du.extract_sequence_from_pred_matrix(
+                flat_dataset_map, files.prediction_matrix(), rotamers_categories=flat_categories if predict_rotamers else None,
+                old_datasetmap=old_datasetmap, is_consensus=is_consensus)
+            pdb_to_sequence, _prob, pdb_to_real_sequence, pdb_to_consensus, pdb_to_consensus_prob = outputs
+            du.save_dict_to_fasta(pdb_to_sequence, model_name, path_to_output)
+            du.save_dict_to_fasta(pdb_to_real_sequence, "dataset", path_to_output)
+            if pdb_to_consensus:
+                du.save_dict_to_fasta(pdb_to_consensus, model_name + "_consensus", path_to_output)
+                du.save_consensus_probs(pdb_to_consensus_prob, model_name, path_to_output)
+    finally:
+        if pending_handles is not None:          # a model that was prefetched but never used (an error above)
+            try:
+                for h in pending_handles.result():
+                    h.close()
+            except Exception:
+                pass
+        side.shutdown(wait=True)
     return (flat_dataset_map, *outputs)
 
 

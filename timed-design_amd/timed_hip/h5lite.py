@@ -455,6 +455,7 @@ class Dataset(_Object):
     def __init__(self, f, addr, name):
         super().__init__(f, addr, name)
         self._dt = None; self._shape = None; self._layout = None; self._filters = []
+        self._fill = None          # bytes of a user-defined fill value (what never-written elements read as), else None = zeros
         for mtype, _fl, d in self._messages():
             if mtype == 0x03:
                 self._dt, _ = _parse_dtype(d, 0)
@@ -464,8 +465,47 @@ class Dataset(_Object):
                 self._layout = d
             elif mtype == 0x0B:
                 self._filters = self._parse_filters(d)
+            elif mtype in (0x04, 0x05):
+                fv = self._parse_fill(mtype, d)
+                if fv is not None:
+                    self._fill = fv
         if self._dt is None or self._layout is None:
             raise H5FormatError(f"{name}: incomplete dataset header")
+
+    @staticmethod
+    def _parse_fill(mtype: int, d: bytes):
+        """fill value bytes of a fill-value message (0x05, versions 1-3) or an old fill-value message (0x04); None when
+        no value is defined (the library default: zeros)"""
+        try:
+            if mtype == 0x04:
+                size = struct.unpack_from("<I", d, 0)[0]
+                return bytes(d[4:4 + size]) if size else None
+            ver = d[0]
+            if ver in (1, 2):
+                defined = d[3]
+                if ver == 2 and not defined:
+                    return None
+                size = struct.unpack_from("<I", d, 4)[0]
+                return bytes(d[8:8 + size]) if size else None
+            if ver == 3:
+                if not (d[1] & 0x20):
+                    return None
+                size = struct.unpack_from("<I", d, 2)[0]
+                return bytes(d[6:6 + size]) if size else None
+        except (struct.error, IndexError):
+            pass
+        return None
+
+    @property
+    def _nonzero_fill(self) -> bool:
+        return self._fill is not None and any(self._fill)
+
+    def _filled(self, shape, esz) -> np.ndarray:
+        """an array of `shape` void elements holding the dataset's fill value"""
+        out = np.zeros(shape, dtype=np.dtype(f"V{esz}"))
+        if self._nonzero_fill and len(self._fill) == esz:
+            out[...] = np.frombuffer(self._fill, dtype=out.dtype)[0]
+        return out
 
     @staticmethod
     def _parse_filters(d: bytes):
@@ -527,7 +567,7 @@ class Dataset(_Object):
         if cls == 1:
             addr, size = struct.unpack_from("<QQ", d, 2)
             if addr == UNDEF:
-                return bytes(n * esz)
+                return self._filled(shape, esz).tobytes() if shape else (self._fill if self._nonzero_fill else bytes(esz))
             return bytes(m[f._base + addr:f._base + addr + size])
         if cls == 2:
             rank = d[2]
@@ -536,7 +576,7 @@ class Dataset(_Object):
             chunk = cdims[:-1]
             if cdims[-1] != esz:
                 raise H5FormatError(f"{self.name}: chunk element size")
-            out = np.zeros(shape, dtype=np.dtype(f"V{esz}"))
+            out = self._filled(shape, esz)          # never-allocated chunks read as the fill value
             if btree != UNDEF:
                 self._walk_chunks(btree, rank, chunk, esz, out)
             return out.tobytes()
@@ -581,6 +621,8 @@ class Dataset(_Object):
         d = self._layout
         if self._shape is None or not self._shape or self._dt.vlen_str or d is None or d[0] != 3 or d[1] != 2:
             return None
+        if self._nonzero_fill:          # the native reader zero-fills what was never written: only valid for a zero fill value
+            return None
         npdt = np.dtype(bool) if self._dt.enum_bool else self._dt.np
         if npdt is None or npdt.byteorder == ">" or npdt.kind not in "fiub":
             return None
@@ -599,6 +641,8 @@ class Dataset(_Object):
         many residues' frames in parallel."""
         shape = self._shape
         if shape is None or self._dt.vlen_str or tuple(dest.shape) != tuple(shape) or not dest.flags.c_contiguous:
+            return False
+        if self._nonzero_fill:
             return False
         esz = self._dt.size
         npdt = np.dtype(bool) if self._dt.enum_bool else self._dt.np
@@ -663,7 +707,8 @@ def read_many_direct(datasets, dests) -> List[bool]:
     groups: Dict[tuple, List[int]] = {}
     for i, (ds, dest) in enumerate(zip(datasets, dests)):
         geo = ds.chunked_geometry() if isinstance(ds, Dataset) else None
-        if (geo is not None and tuple(dest.shape) == geo[1] and dest.flags.c_contiguous and dest.dtype.itemsize == geo[3]
+        kind_ok = geo is not None and (dest.dtype.kind == ds.dtype.kind or (ds.dtype.kind == "b" and dest.dtype == np.bool_))
+        if (geo is not None and kind_ok and tuple(dest.shape) == geo[1] and dest.flags.c_contiguous and dest.dtype.itemsize == geo[3]
                 and dest.flags.writeable):
             groups.setdefault((id(ds._f),) + geo[1:], []).append(i)
     if groups:
