@@ -91,25 +91,25 @@ def _run_groups(models, dataset_path, flat_dataset_map, groups, consume):
         return
     depth = 2 * len(models)
 
-    # Batches of an .hdf5 dataset are built in a ring of page-locked buffers (th_host_alloc), sized after the first batch:
-    # no 0.5 GB of first-touch page faults per batch, and the host->device copy runs on the DMA engine without blocking
-    # this thread.  A buffer is reused only after the ticket that read it has completed: at most 3 groups per model are
-    # outstanding (below) + the one being loaded + one spare.  Frame packs hand out memory-mapped rows instead.
-    ring, ring_owners = [], []
+    # Batches of an .hdf5 dataset are built in a small ring of reused buffers: a fresh 0.2-0.5 GB NumPy batch costs more
+    # in first-touch page faults than its inflation does.  The first ``ring_size`` full-size batches simply become the
+    # ring (no extra allocation); a buffer is reused only after the ticket that read it has completed: at most 3 groups
+    # per model are outstanding (below) + the one being loaded + one spare.  Pageable memory on purpose: host->device
+    # copies from it already run at the PCIe rate here, and page-locking 1 GB costs more than a short run takes
+    # (th_host_alloc exists for callers that keep their buffers).  Frame packs hand out memory-mapped rows instead.
+    ring = []
     ring_size = 3 * len(models) + 2
     max_rows = max(hi - lo for lo, hi in groups)
     from timed_hip import framepack
-    use_ring = getattr(models[0], "accepts_pinned", False) and not framepack.is_pack(dataset_path)
+    use_ring = len(groups) > ring_size and not framepack.is_pack(dataset_path)
 
     def load(k):
         lo, hi = groups[k]
+        slot = k % ring_size
         # float32 frames: the rounding Keras applies to load_batch's float64 anyway, done while the chunks are placed
-        X, y = du.load_batch(dataset_path, flat_dataset_map[lo:hi], dtype=np.float32, out=ring[k % ring_size] if ring else None)
-        if k == 0 and not ring and use_ring and isinstance(X, np.ndarray) and X.base is None:
-            for _ in range(ring_size):
-                buf, owner = engine.pinned_empty((max_rows, *X.shape[1:]), X.dtype)
-                ring.append(buf)
-                ring_owners.append(owner)
+        X, y = du.load_batch(dataset_path, flat_dataset_map[lo:hi], dtype=np.float32, out=ring[slot] if slot < len(ring) else None)
+        if use_ring and len(ring) == slot and isinstance(X, np.ndarray) and X.base is None and len(X) == max_rows:
+            ring.append(X)
         return X, y
 
     def finish(ticket, labels):
@@ -139,8 +139,6 @@ def _run_groups(models, dataset_path, flat_dataset_map, groups, consume):
         while writing:
             writing.popleft().result()
     del ring[:]
-    for owner in ring_owners:
-        owner.free()
 
 
 def _distributed_context(gather):
@@ -283,8 +281,6 @@ def _predict_sharded(model, gather, rank, world, dataset_path, flat_dataset_map,
                 cursor[0] += len(y)
 
             class _ToDevice:      # the model facade _run_groups drives: outputs land in d_local at the shard row
-                accepts_pinned = True
-
                 def __init__(self):
                     self.row = 0
 

@@ -27,8 +27,6 @@ _DTYPES = {
 
 
 class HipFrameModel:
-    accepts_pinned = True       # batches built in pinned_empty() memory are fetched by the DMA engine asynchronously
-
     def __init__(self, pack_bytes: bytes, device: int = 0, flags: int = _lib.TH_LOAD_DEFAULT, name: str = "model"):
         self._lib = _lib.load()
         self._h = C.c_void_p()
