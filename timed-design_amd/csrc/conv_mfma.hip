@@ -584,6 +584,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// Compile-time knock-outs for timing experiments on k_conv_n16's inner loop (results are WRONG when set; build a
+// second library with -DN16_KNOCK=n and load it through TIMED_HIP_LIB): 1 no weight-ring refills, 2 A fragments read
+// from conflict-free dummy addresses, 4 no A-fragment reads after tap 0.
+#ifndef N16_KNOCK
+#define N16_KNOCK 0
+#endif
+
 // XC > 0: output channels 16..16+XC-1 (Cout = 17..20, e.g. the 20 amino-acid classes of a TIMED head) ride on
 // v_mfma_f32_4x4x1_16B_f32 from the SAME A registers: the instruction is 16 independent 4x4 outer products (lane
 // 4b+i supplies A_b[i] and B_b[i]; VGPR r of lane 4b+j receives D_b[r][j] — checked on hardware,
@@ -725,6 +732,9 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
     }
 
     bool staged = false;   // chunk 0 of the current group was already written to LDS from the prefetch registers
+#if N16_KNOCK & 8
+    long long prof_t0 = clock64(), prof_mfma = 0, prof_bar = 0, prof_epi = 0, prof_pf = 0;
+#endif
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         const int64_t f0 = grp * a.FB;
         const int nvalid = (int)min((int64_t)a.FB, a.nframes - f0);
@@ -735,6 +745,9 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
         const float* inb_next = a.in + (has_next ? gnext : grp) * a.FB * a.in_fs + a.in_coff;
         const int nvalid_next = has_next ? (int)min((int64_t)a.FB, a.nframes - gnext * a.FB) : nvalid;
 
+#if N16_KNOCK & 8
+        long long prof_d = 0;
+#endif
         for (int rd = 0; rd < rounds; ++rd) {
             const int blk = rd * WAVES + wave;
             const bool active = blk < total_blocks;
@@ -752,6 +765,9 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
             }
             for (int ch = 0; ch < a.nchunks; ++ch) {
                 const bool need_a = !(a.nchunks == 1 && rd > 0) && !((a.dbg & 1) && (ch > 0 || grp != blockIdx.x));
+#if N16_KNOCK & 8
+                long long prof_a = clock64();
+#endif
                 if (!(can_pf && (ch > 0 || staged))) {   // otherwise this chunk was written from registers already
                     __syncthreads();
                     if (need_a) {
@@ -767,6 +783,9 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
                     }
                 }
                 __syncthreads();
+#if N16_KNOCK & 8
+                prof_bar += clock64() - prof_a;
+#endif
                 const bool last_ch = ch + 1 == a.nchunks;
                 const bool do_pf = can_pf && (!last_ch || has_next) && !(a.dbg & 1);
                 const int pch = last_ch ? 0 : ch + 1;
@@ -798,6 +817,9 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
                 const bool pbn = a.pre.scale && can_pf;   // can_pf: Cin % 4 == 0, so pc0 is aligned and in bounds
                 const float4 psc = *reinterpret_cast<const float4*>(pbn ? a.pre.scale + pc0 : a.wpk);
                 const float4 psh = *reinterpret_cast<const float4*>(pbn ? a.pre.shift + pc0 : a.wpk);
+#if N16_KNOCK & 8
+                long long prof_b = clock64();
+#endif
                 if (active) {
                     // A fragments: TM <= 4 keeps two register sets (ping-pong by tap).  TM = 8 has ONE set and pipelines at
                     // half-tap granularity instead: as soon as the MFMAs of tiles 0..3 of tap t have issued, their
@@ -816,9 +838,9 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
                         // opaque to LICM: otherwise hipcc hoists all 27*TM read addresses out of the chunk loop
                         // and spills them to scratch
                         asm volatile("" : "+s"(noff));
-                        if (PING && nt < NTAPS) {
+                        if (PING && nt < NTAPS && !(N16_KNOCK & 4)) {
 #pragma unroll
-                            for (int tm = 0; tm < TM; ++tm) av[nt & 1][tm] = A4v[aidx[tm] + noff];
+                            for (int tm = 0; tm < TM; ++tm) av[nt & 1][tm] = (N16_KNOCK & 2) ? A4v[tid + tm * NTHREADS + (nt & 1) * 64] : A4v[aidx[tm] + noff];
                         }
                         __builtin_amdgcn_sched_barrier(0);
                         if (!XC) {
@@ -852,9 +874,9 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
                             xw[t % 3] = wx4[(size_t)min(widx, wcount - 1) * 4 * XC];
                         }
                         if (!PING) {
-                            if (nt < NTAPS) {
+                            if (nt < NTAPS && !(N16_KNOCK & 4)) {
 #pragma unroll
-                                for (int tm = 0; tm < HT; ++tm) av[0][tm] = A4v[aidx[tm] + noff];
+                                for (int tm = 0; tm < HT; ++tm) av[0][tm] = (N16_KNOCK & 2) ? A4v[tid + tm * NTHREADS + (nt & 1) * 64] : A4v[aidx[tm] + noff];
                             }
                             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -867,17 +889,21 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
                             }
                             __builtin_amdgcn_sched_barrier(0);
                         }
-                        {
+                        if (!(N16_KNOCK & 1)) {
                             int widx = ch * NTAPS + t + BR;
                             widx = widx >= wcount ? widx - wcount : widx;
                             breg[t % BR] = wpk4[(size_t)min(widx, wcount - 1) * 64];
                         }
-                        if (!PING && nt < NTAPS) {
+                        if (!PING && nt < NTAPS && !(N16_KNOCK & 4)) {
 #pragma unroll
-                            for (int tm = HT; tm < TM; ++tm) av[0][tm] = A4v[aidx[tm] + noff];
+                            for (int tm = HT; tm < TM; ++tm) av[0][tm] = (N16_KNOCK & 2) ? A4v[tid + tm * NTHREADS + (nt & 1) * 64] : A4v[aidx[tm] + noff];
                         }
                     }
                 }
+#if N16_KNOCK & 8
+                prof_mfma += clock64() - prof_b;
+                long long prof_c = clock64();
+#endif
                 if (do_pf) {
                     // BN -> activation prologue in registers BEFORE the barrier (overlaps the other waves' last MFMAs)
 #pragma unroll
@@ -900,7 +926,13 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
                         if (i < nvec) A4[(size_t)(i / CI4) * CS4 + (i % CI4)] = pfv[u];
                     }
                 }
+#if N16_KNOCK & 8
+                prof_pf += clock64() - prof_c;
+#endif
             }
+#if N16_KNOCK & 8
+            prof_d = clock64();
+#endif
             // ---- epilogue in registers: C layout col = lane&15, row = 4*(lane>>4) + reg --------------------
             if (active) {
 #pragma unroll
@@ -960,8 +992,16 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
                 }
             }
         }
+#if N16_KNOCK & 8
+        prof_epi += clock64() - prof_d;
+#endif
         staged = can_pf && has_next && !(a.dbg & 1);
     }
+#if N16_KNOCK & 8
+    if (blockIdx.x == 0 && lane == 0)
+        printf("n16 prof wave %d: total %lld  mfma-phase %lld  barrier+stage %lld  pf-write %lld  epilogue %lld cycles (s_memtime, 100 MHz)\n", wave,
+               clock64() - prof_t0, prof_mfma, prof_bar, prof_pf, prof_epi);
+#endif
 }
 
 // ---- tile configurations ------------------------------------------------------------------------
