@@ -731,6 +731,12 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
         }
     }
 
+    int pf_off[PF];        // this thread's prefetch sources (staged voxel -> input offset, -1 = halo / nothing)
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int i = tid + u * NTHREADS;
+        pf_off[u] = (can_pf && i < nvec) ? voxsrc[i / CI4] : -1;
+    }
     bool staged = false;   // chunk 0 of the current group was already written to LDS from the prefetch registers
 #if N16_KNOCK & 8
     long long prof_t0 = clock64(), prof_mfma = 0, prof_bar = 0, prof_epi = 0, prof_pf = 0;
@@ -797,13 +803,15 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
                 {
                     const float* pin = (last_ch ? inb_next : inb0) + pch * CI;
                     const int pnv = last_ch ? nvalid_next : nvalid;
+                    const int g = tid % CI4;                 // NTHREADS % CI4 == 0: the same channel group for every u
+                    const bool gok = pch * CI + g * 4 + 4 <= a.Cin;
 #pragma unroll
                     for (int u = 0; u < PF; ++u) {
-                        const int i = tid + u * NTHREADS;
-                        int off = (do_pf && i < nvec) ? voxsrc[i / CI4] : -1;
-                        if (pnv < a.FB && off >= 0 && (i / CI4) / vox_pf >= pnv) off = -1;
-                        const int g = i % CI4;
-                        const bool ld = off >= 0 && pch * CI + g * 4 + 4 <= a.Cin;
+                        // the source offsets do not depend on the chunk or the frame group: looked up once per workgroup
+                        // (pf_off, below the tables) instead of 14 LDS reads + divisions in front of every MFMA phase
+                        int off = do_pf ? pf_off[u] : -1;
+                        if (pnv < a.FB && off >= 0 && ((tid + u * NTHREADS) / CI4) / vox_pf >= pnv) off = -1;
+                        const bool ld = off >= 0 && gok;
                         const float4* src = ld ? reinterpret_cast<const float4*>(pin + off + g * 4)
                                                : reinterpret_cast<const float4*>(a.wpk);
                         pfv[u] = *src;
