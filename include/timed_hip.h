@@ -223,6 +223,19 @@ int th_h5_resolve(const void* file, int64_t file_len, int64_t base, int64_t n, c
                   double* num_out, int num_len, const char* str_attr, char* str_out, int str_len, int64_t* btree_out,
                   int64_t* geom_out, int* status_out, int nthreads);
 
+/* ---- voxeliser: the producer of the frames — replaces aposteriori.make_frame_dataset as the reference invokes it
+ * (ui.py:73-86: frame_edge_length 21.0, voxels_per_side 21, Codec.CNOCACB, voxels_as_gaussian=True; README.md:83-97).
+ * PARITY UNPINNED: aposteriori's source is not in the reference tree; the specification implemented here is written out
+ * in timed_hip/voxeliser.py and restated by oracle/voxel_oracle.py.  Host arrays in: atoms_xyz [n_atoms,3] (Angstrom),
+ * atom_channel [n_atoms] (index into the atom encoder, < 0 = not encoded), atom_sigma [n_atoms] (Gaussian width in
+ * Angstrom; may be NULL for boolean frames), frames_rt [n_res,12] = per residue a row-major 3x3 rotation (rows = local
+ * x, y, z axes) followed by the origin (the residue's CA).  Out: [n_res, V, V, V, n_channels], float32 when gaussian
+ * else uint8 (0/1); `out` is host memory, or device memory of `device` when out_on_device (frames then go straight to
+ * th_predict_device without leaving HBM).  One frame holds at most 2048 encodable atoms (TH_EUNSUP beyond). */
+int th_voxelise(int device, const float* atoms_xyz, const int32_t* atom_channel, const float* atom_sigma, int64_t n_atoms,
+                const float* frames_rt, int64_t n_res, int voxels_per_side, float frame_edge_length, int n_channels, int gaussian,
+                void* out, int out_on_device);
+
 /* ---- multi-GPU reassembly (no reference counterpart: the reference is single-process) ----- */
 /* one process per GPU; rank 0 creates the id and ships it to the others out of band */
 #define TH_COMM_ID_BYTES 128

@@ -62,6 +62,7 @@ PROTOTYPES = {
     "th_comm_free": (None, [_vp]),
     "th_comm_gather_rows": (_i, [_vp, _vp, _pi64, _i, _i, _vp]),
     "th_comm_barrier": (_i, [_vp]),
+    "th_voxelise": (_i, [_i, _vp, _vp, _vp, _i64, _vp, _i64, _i, C.c_float, _i, _i, _vp, _i]),
     "th_format_csv": (_i64, [_vp, _i, _i64, _i64, _vp, _i64]),
     "th_h5_read_chunked": (_i, [_vp, _i64, _i64, _i64, _pi64, C.POINTER(_vp), _i, _pi64, _pi64, _i, _i, _pi, _i]),
     "th_h5_read_chunked_as": (_i, [_vp, _i64, _i64, _i64, _pi64, C.POINTER(_vp), _i, _pi64, _pi64, _i, _i, _pi, _i, _i]),
