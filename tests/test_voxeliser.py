@@ -158,3 +158,26 @@ def test_voxeliser_argument_checks(gpu, lib):
     # empty structure: all-zero frames
     z = voxeliser.voxelise(np.zeros((0, 3)), np.zeros(0), np.zeros(0), frt, device=gpu)
     assert z.shape == (1, 21, 21, 21, 5) and not z.any()
+
+
+@pytest.mark.gpu
+def test_predict_py_takes_a_pdb_file_directly(gpu, tmp_path):
+    """--path_to_dataset structure.pdb1.gz: no aposteriori, no HDF5; same files as through a frame pack of the same frames"""
+    import warnings
+    import predict
+    from timed_hip import pack, synth
+    cfg, weights = synth.timed_synth(20, widths=(8, 16), side=21, in_channels=5, seed=3)
+    mp = tmp_path / "M.pack"
+    mp.write_bytes(pack.keras_to_pack(cfg, weights))
+    X, labels, flat = voxeliser.voxelise_pdb(UBQ, device=gpu)
+    voxeliser.write_frame_pack(tmp_path / "ubq", X, labels, flat, gaussian=True)
+    a, b = tmp_path / "a", tmp_path / "b"
+    a.mkdir(); b.mkdir()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        predict.load_dataset_and_predict([mp], UBQ, batch_size=16, dataset_map_path=a / "datasetmap.txt", path_to_output=a)
+        predict.load_dataset_and_predict([mp], str(tmp_path / "ubq.framepack"), batch_size=16, dataset_map_path=b / "datasetmap.txt",
+                                         path_to_output=b)
+    for fn in sorted(p.name for p in a.iterdir()):
+        assert (a / fn).read_bytes() == (b / fn).read_bytes(), fn
+    assert (a / "M.txt").read_text().endswith("1ubqA 76\n")

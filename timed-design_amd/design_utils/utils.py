@@ -11,6 +11,7 @@ alphanumeric map codes, rm_tree.
 """
 from __future__ import annotations
 
+import os
 import typing as t
 import warnings
 from itertools import product
@@ -85,6 +86,9 @@ def create_flat_dataset_map(
     from timed_hip import framepack
     if framepack.is_pack(frame_dataset):  # packed dataset: the map was fixed when the pack was written
         fmap = [tuple(r) for r in framepack.FramePack(frame_dataset).flat_map]
+        return fmap, {r[0] for r in fmap}
+    if framepack.is_structure(frame_dataset):   # a PDB file: voxelised on the GPU (row f-4), one frame per residue
+        fmap = [tuple(str(x) for x in r) for r in _structure_pack(frame_dataset).flat_map if r[0][:4] not in filter_list]
         return fmap, {r[0] for r in fmap}
     standard_residues = list(standard_amino_acids.values())
     uncommon = UNCOMMON_RESIDUE_DICT if uncommon_residue_dict is None else uncommon_residue_dict
@@ -195,6 +199,8 @@ def load_batch(dataset_path: Path, data_point_batch: t.List[t.Tuple], dtype=None
     from timed_hip import framepack
     if framepack.is_pack(dataset_path):  # HDF5-free fast path (SURVEY f-1): memory-mapped rows, no per-residue reads
         return _frame_pack(dataset_path).load_batch(data_point_batch)
+    if framepack.is_structure(dataset_path):
+        return _structure_pack(dataset_path).load_batch(data_point_batch)
     batch_size = len(data_point_batch)
     with open_frame_dataset(dataset_path) as dataset:
         dims = tuple(int(d) for d in np.asarray(dataset.attrs["frame_dims"]).ravel())
@@ -251,6 +257,17 @@ def _is_h5lite_file(obj) -> bool:
 
 
 _PACKS: dict = {}
+_STRUCTURES: dict = {}
+
+
+def _structure_pack(path):
+    from timed_hip import framepack
+    key = (os.path.abspath(os.fspath(path)), os.path.getmtime(path))
+    if key not in _STRUCTURES:
+        _STRUCTURES.clear()            # one structure's frames at a time
+        _STRUCTURES[key] = framepack.StructurePack(path)
+    return _STRUCTURES[key]
+
 
 
 def _frame_pack(path):

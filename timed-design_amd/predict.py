@@ -8,7 +8,8 @@ model object replaced by the HIP engine and the strictly sequential batch loop r
     python3 predict.py --path_to_dataset data.hdf5 --path_to_model TIMED.h5 --path_to_output .
 
 ``--path_to_model`` takes a Keras legacy ``.h5`` (converted on the fly) or a ``.pack``; ``--path_to_dataset`` an
-aposteriori ``.hdf5`` or a frame pack.  Outputs (reference README.md:119-131): <model>.csv, <model>.fasta, <model>.txt,
+aposteriori ``.hdf5``, a frame pack, or a PDB file (``.pdb[.gz]`` / ``.pdb1[.gz]`` / ``.ent``: voxelised on the GPU by
+timed_hip.voxeliser — parity unpinned against aposteriori).  Outputs (reference README.md:119-131): <model>.csv, <model>.fasta, <model>.txt,
 dataset.fasta, datasetmap.txt, encoded_labels.csv, plus <model>_rot.csv in rotamer mode.
 
 How a run is organised (all of it invisible in the files, which are byte-identical to a batch-by-batch run):
@@ -101,7 +102,7 @@ def _run_groups(models, dataset_path, flat_dataset_map, groups, consume):
     ring_size = 3 * len(models) + 2
     max_rows = max(hi - lo for lo, hi in groups)
     from timed_hip import framepack
-    use_ring = len(groups) > ring_size and not framepack.is_pack(dataset_path)
+    use_ring = len(groups) > ring_size and not framepack.is_pack(dataset_path) and not framepack.is_structure(dataset_path)
 
     def load(k):
         lo, hi = groups[k]

@@ -124,3 +124,34 @@ class FramePack:
         if len(rows) and np.array_equal(rows, np.arange(rows[0], rows[0] + len(rows))):
             return self.batch(int(rows[0]), int(rows[0]) + len(rows))
         return np.asarray(self.frames[rows]), self.labels[rows].astype(float)
+
+
+# ---- structures as datasets --------------------------------------------------------------------------------------
+STRUCTURE_SUFFIXES = (".pdb", ".pdb.gz", ".pdb1", ".pdb1.gz", ".ent", ".ent.gz")
+
+
+def is_structure(path) -> bool:
+    p = os.fspath(path).lower()
+    return p.endswith(STRUCTURE_SUFFIXES) and os.path.isfile(os.fspath(path))
+
+
+class StructurePack:
+    """A PDB file used directly as a dataset: voxelised once on the GPU (timed_hip.voxeliser — row f-4, parity unpinned
+    against aposteriori) and kept in memory with the same ``flat_map`` / ``load_batch`` surface as a FramePack, so
+    ``predict.py --path_to_dataset structure.pdb.gz`` needs neither aposteriori nor an HDF5 file."""
+
+    def __init__(self, path, device: int = 0, gaussian: bool = True):
+        from . import voxeliser
+        self.frames, labels, flat = voxeliser.voxelise_pdb(path, gaussian=gaussian, device=device)
+        self.labels = labels
+        self.flat_map = np.asarray(flat, dtype=str).reshape(-1, 4)
+        self._index = {(p, c, r): i for i, (p, c, r, _l) in enumerate(self.flat_map)}
+
+    def __len__(self):
+        return self.frames.shape[0]
+
+    def load_batch(self, data_point_batch):
+        rows = np.array([self._index[(str(p), str(c), str(r))] for p, c, r, *_ in data_point_batch], dtype=np.int64)
+        if len(rows) and np.array_equal(rows, np.arange(rows[0], rows[0] + len(rows))):
+            return self.frames[rows[0]: rows[0] + len(rows)], self.labels[rows[0]: rows[0] + len(rows)].astype(float)
+        return self.frames[rows], self.labels[rows].astype(float)
