@@ -85,7 +85,7 @@ def create_flat_dataset_map(
     Uncommon residue labels are mapped through aposteriori's table (:381-385)."""
     from timed_hip import framepack
     if framepack.is_pack(frame_dataset):  # packed dataset: the map was fixed when the pack was written
-        fmap = [tuple(r) for r in framepack.FramePack(frame_dataset).flat_map]
+        fmap = [tuple(r) for r in _frame_pack(frame_dataset).flat_map.tolist()]     # the cached pack load_batch will use
         return fmap, {r[0] for r in fmap}
     if framepack.is_structure(frame_dataset):   # a PDB file: voxelised on the GPU (row f-4), one frame per residue
         fmap = [tuple(str(x) for x in r) for r in _structure_pack(frame_dataset).flat_map if r[0][:4] not in filter_list]
@@ -400,6 +400,13 @@ def save_outputs_to_file(
     """reference utils.py:726-771.  APPENDS: encoded_labels.csv ('%i', first model only), datasetmap.txt
     (written once, only if absent), <model>.csv — probabilities cast to float16 then written with
     np.savetxt's default '%.18e' (so the file holds float16-rounded values)."""
+    append_outputs(np.asarray(y_true), np.array(y_pred[model], dtype=np.float16), flat_dataset_map, model, model_name, path_to_output)
+
+
+def append_outputs(y_true: np.ndarray, predictions_f16: np.ndarray, flat_dataset_map, model: int, model_name: str,
+                   path_to_output: Path = Path.cwd()):
+    """The file appends of save_outputs_to_file on arrays (no list round trip): ``y_true`` [n, 20] labels,
+    ``predictions_f16`` [n, n_classes] float16 — what ``np.array(y_pred[model], dtype=np.float16)`` yields there."""
     path_to_output = Path(path_to_output)
     if model == 0:
         with open(path_to_output / "encoded_labels.csv", "ab") as f:
@@ -408,9 +415,8 @@ def save_outputs_to_file(
     if not path_to_datasetmap.exists():
         with open(path_to_datasetmap, "a") as f:
             _savetxt_strings(f, flat_dataset_map)
-    predictions = np.array(y_pred[model], dtype=np.float16)
     with open(path_to_output / f"{model_name}.csv", "ab") as f:
-        textio.savetxt_csv(f, predictions)     # same bytes as np.savetxt(f, predictions, delimiter=","), formatted natively
+        textio.savetxt_csv(f, np.asarray(predictions_f16, dtype=np.float16))   # same bytes as np.savetxt(f, predictions, delimiter=",")
 
 
 def _savetxt_strings(f, rows) -> None:

@@ -54,17 +54,18 @@ class _OutputFiles:
         # rows already in the file (an earlier, interrupted or repeated run) are part of what the reference reads back
         self.must_reread = resume or (self.matrix_path.exists() and self.matrix_path.stat().st_size > 0)
         self._f16_rows = []
+        self._codec_matrix = (np.array([codec[k] for k in range(len(codec))], dtype=np.float16) if codec is not None else None)
 
     def append(self, probs: np.ndarray, labels: np.ndarray):
+        f16 = probs.astype(np.float16)
+        self._f16_rows.append(f16)
         if self.codec is not None:
             with open(self.matrix_path, "ab") as f:
                 textio.savetxt_csv(f, probs)            # = np.savetxt(f, y_pred_batch, delimiter=","), full precision
-            self._f16_rows.append(probs.astype(np.float16))
-            probs = np.array([self.codec[c] for c in np.argmax(probs, axis=1)])
-        else:
-            self._f16_rows.append(probs.astype(np.float16))
-        du.save_outputs_to_file(list(labels), {self.model_index: list(probs)}, self.flat_dataset_map, self.model_index,
-                                self.model_name, self.path_to_output)
+            f16 = self._codec_matrix[np.argmax(probs, axis=1)]      # one-hot residue of the arg-max rotamer
+        # the appends of utils.save_outputs_to_file, on arrays: no list-of-lists round trip under the GIL while the
+        # submitter thread is waiting to launch the next group
+        du.append_outputs(labels, f16, self.flat_dataset_map, self.model_index, self.model_name, self.path_to_output)
 
     def prediction_matrix(self) -> np.ndarray:
         """what np.genfromtxt(matrix_path, delimiter=",", dtype=np.float16) would return: '%.18e' text round-trips every
@@ -104,7 +105,17 @@ def _run_groups(models, dataset_path, flat_dataset_map, groups, consume):
     from timed_hip import framepack
     use_ring = len(groups) > ring_size and not framepack.is_pack(dataset_path) and not framepack.is_structure(dataset_path)
 
+    load_seconds = [0.0]
+
     def load(k):
+        import time
+        t0 = time.perf_counter()
+        try:
+            return _load(k)
+        finally:
+            load_seconds[0] += time.perf_counter() - t0
+
+    def _load(k):
         lo, hi = groups[k]
         slot = k % ring_size
         # float32 frames: the rounding Keras applies to load_batch's float64 anyway, done while the chunks are placed
@@ -118,28 +129,57 @@ def _run_groups(models, dataset_path, flat_dataset_map, groups, consume):
 
     pending = deque()          # tickets submitted to a GPU, oldest first
     writing = deque()          # futures of the writer thread, oldest first
+    # three Python threads share the interpreter lock; with the default 5 ms switch interval the submitter can sit behind
+    # the writer for longer than a whole group takes on the GPU (4.6 ms per 1024 frames)
+    switch = sys.getswitchinterval()
+    sys.setswitchinterval(2e-4)
+    try:
+        _pump(models, groups, load, finish, pending, writing, depth)
+    finally:
+        sys.setswitchinterval(switch)
+    if os.environ.get("TIMED_PIPELINE_TRACE"):
+        print(f"[pipeline] load_batch calls took {load_seconds[0]:.3f} s in the loader thread", file=sys.stderr)
+    del ring[:]
+
+
+def _pump(models, groups, load, finish, pending, writing, depth):
+    trace = os.environ.get("TIMED_PIPELINE_TRACE")
+    if trace:
+        import time
+        t_load = t_wait = t_submit = 0.0
+        clock = time.perf_counter
     with ThreadPoolExecutor(max_workers=1, thread_name_prefix="load_batch") as loader, \
             ThreadPoolExecutor(max_workers=1, thread_name_prefix="write_outputs") as writer:
         nxt = loader.submit(load, 0)
         for k in range(len(groups)):
+            if trace:
+                t0 = clock()
             X, y = nxt.result()
             if k + 1 < len(groups):
                 nxt = loader.submit(load, k + 1)
+            if trace:
+                t1 = clock(); t_load += t1 - t0
             # a model has 4 tickets (th_predict_async): at most 3 consecutive groups per model are outstanding here,
             # 2 on the GPU queue and 1 with the writer
             while len(pending) + len(writing) >= 3 * len(models):
                 if not writing:
                     writing.append(writer.submit(finish, *pending.popleft()))
                 writing.popleft().result()
+            if trace:
+                t2 = clock(); t_wait += t2 - t1
             pending.append((models[k % len(models)].predict_async(X), y))
             del X
+            if trace:
+                t_submit += clock() - t2
             if len(pending) >= depth:
                 writing.append(writer.submit(finish, *pending.popleft()))
         while pending:
             writing.append(writer.submit(finish, *pending.popleft()))
         while writing:
             writing.popleft().result()
-    del ring[:]
+    if trace:
+        print(f"[pipeline] {len(groups)} groups: waiting for the loader {t_load:.3f} s, for the writer/GPU {t_wait:.3f} s, "
+              f"submitting (incl. pageable host->device copies) {t_submit:.3f} s", file=sys.stderr)
 
 
 def _distributed_context(gather):
@@ -196,6 +236,7 @@ def load_dataset_and_predict(
     else:
         excluded = du.get_pdb_keys_to_filter(blacklist) if blacklist else []
         flat_dataset_map, _ = du.create_flat_dataset_map(dataset_path, excluded)
+    flat_dataset_map = np.array(flat_dataset_map)       # (the reference converts after the first model; rows slice as arrays)
     old_datasetmap = len(flat_dataset_map[0]) == 4
     codec, flat_categories = du.get_rotamer_codec() if predict_rotamers else (None, None)
     outputs = (None,) * 5
@@ -214,7 +255,7 @@ def load_dataset_and_predict(
                                          f"{predict_rotamers} needs {n_classes}")
                 if rank == 0:
                     # <model>.txt depends on the map only: written on the side thread while the GPU works
-                    srb = side.submit(du.convert_dataset_map_for_srb, np.array(flat_dataset_map), model_name, path_to_output)
+                    srb = side.submit(du.convert_dataset_map_for_srb, flat_dataset_map, model_name, path_to_output)
                 if sharded:
                     done = _predict_sharded(handles[0], gather, rank, world, dataset_path, flat_dataset_map, batch_size,
                                             start_batch, frames_per_call)
@@ -235,7 +276,6 @@ def load_dataset_and_predict(
                     h.close()
                 if srb is not None:
                     srb.result()
-            flat_dataset_map = np.array(flat_dataset_map)
             outputs = du.extract_sequence_from_pred_matrix(
                 flat_dataset_map, files.prediction_matrix(), rotamers_categories=flat_categories if predict_rotamers else None,
                 old_datasetmap=old_datasetmap, is_consensus=is_consensus)

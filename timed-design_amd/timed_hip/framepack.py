@@ -101,6 +101,7 @@ class FramePack:
         if len(self.flat_map) != self.frames.shape[0] or self.labels.shape[0] != self.frames.shape[0]:
             raise ValueError(f"{stem}: inconsistent pack (map {len(self.flat_map)}, frames {self.frames.shape[0]})")
         self._index: Optional[Dict[Tuple[str, str, str], int]] = None
+        self._cursor = 0
 
     def __len__(self):
         return self.frames.shape[0]
@@ -120,6 +121,25 @@ class FramePack:
 
     def load_batch(self, data_point_batch) -> Tuple[np.ndarray, np.ndarray]:
         """Same contract as design_utils.utils.load_batch for an arbitrary list of map rows."""
+        # the usual caller hands over a contiguous slice of the map itself: find it from its first row and confirm with
+        # one vectorised comparison instead of a dictionary lookup per residue
+        n = len(data_point_batch)
+        if n and isinstance(data_point_batch, np.ndarray) and data_point_batch.ndim == 2 and data_point_batch.shape[1] >= 3:
+            # a sequential reader continues where the previous batch ended: try that row first (no 100 k-entry
+            # dictionary needed), then the start of the map, then the dictionary
+            first = tuple(str(x) for x in data_point_batch[0, :3])
+            i0 = None
+            for guess in (self._cursor, 0):
+                if guess < len(self.flat_map) and tuple(self.flat_map[guess, :3]) == first:
+                    i0 = guess
+                    break
+            if i0 is None:
+                if self._index is None:
+                    self._index = {(str(p), str(c), str(r)): i for i, (p, c, r, _l) in enumerate(self.flat_map)}
+                i0 = self._index.get(first)
+            if i0 is not None and i0 + n <= len(self.flat_map) and np.array_equal(self.flat_map[i0:i0 + n, :3], data_point_batch[:, :3]):
+                self._cursor = i0 + n
+                return self.batch(i0, i0 + n)
         rows = self.rows_of(data_point_batch)
         if len(rows) and np.array_equal(rows, np.arange(rows[0], rows[0] + len(rows))):
             return self.batch(int(rows[0]), int(rows[0]) + len(rows))
