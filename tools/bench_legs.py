@@ -141,6 +141,33 @@ def predict_py_e2e(cfg, weights, n_pack=20000, n_hdf5=2000, batch_size=500, work
             make_frame_pack(stem, n_pack, gaussian=False)
             run(stem + ".framepack", "predict_py_framepack_u8", n_pack)
             os.remove(stem + ".frames.npy")
+        # BASELINE config 1 (the reference's own CPU-runnable case: predict.py on the 1ubq structure of its tests
+        # directory, tests/testing_files/1ubq.pdb1.gz): here the structure file is voxelised on the GPU (row f-4, parity
+        # unpinned against aposteriori) and predicted with a 5-channel TIMED-synth; beside it the CPU oracle on the very
+        # same 76 frames (the "plumbing baseline": NumPy port, not TensorFlow)
+        ubq = os.path.join(ROOT, "tests", "golden", "1ubq.pdb1.gz")
+        if os.path.exists(ubq):
+            from timed_hip import synth, voxeliser
+            cfg5, w5 = synth.timed_synth(20, in_channels=5)
+            mp5 = Path(td) / "TIMED5.pack"
+            mp5.write_bytes(pack.keras_to_pack(cfg5, w5))
+            out = Path(td) / "out_1ubq"
+            out.mkdir()
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                t0 = time.perf_counter()
+                predict.load_dataset_and_predict([mp5], ubq, batch_size=12, dataset_map_path=out / "datasetmap.txt", path_to_output=out)
+                dt = time.perf_counter() - t0
+            frames, _labels, _flat = voxeliser.voxelise_pdb(ubq)
+            from oracle import cnn_oracle
+            t0 = time.perf_counter()
+            ref = cnn_oracle.forward(cfg5, w5, frames)
+            dt_cpu = time.perf_counter() - t0
+            got = np.loadtxt(out / "TIMED5.csv", delimiter=",")
+            assert got.shape == ref.shape and np.abs(got - ref.astype(np.float16).astype(np.float64)).max() < 2e-3
+            res["config1_1ubq_pdb_frames"] = int(frames.shape[0])
+            res["config1_predict_py_from_pdb_s"] = dt
+            res["config1_cpu_oracle_forward_s"] = dt_cpu
         conda = "/opt/conda/bin/python3.9"
         if n_hdf5 > 0 and os.path.exists(conda):
             h5 = os.path.join(td, "frames.hdf5")
