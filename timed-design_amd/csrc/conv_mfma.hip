@@ -739,7 +739,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
     }
     bool staged = false;   // chunk 0 of the current group was already written to LDS from the prefetch registers
 #if N16_KNOCK & 8
-    long long prof_t0 = clock64(), prof_mfma = 0, prof_bar = 0, prof_epi = 0, prof_pf = 0;
+    long long prof_t0 = clock64(), prof_mfma = 0, prof_bar = 0, prof_epi = 0, prof_pf = 0, prof_issue = 0, prof_grp = 0;
 #endif
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         const int64_t f0 = grp * a.FB;
@@ -753,6 +753,8 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
 
 #if N16_KNOCK & 8
         long long prof_d = 0;
+        const long long prof_g0 = clock64();
+        bool prof_first = true;
 #endif
         for (int rd = 0; rd < rounds; ++rd) {
             const int blk = rd * WAVES + wave;
@@ -773,6 +775,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
                 const bool need_a = !(a.nchunks == 1 && rd > 0) && !((a.dbg & 1) && (ch > 0 || grp != blockIdx.x));
 #if N16_KNOCK & 8
                 long long prof_a = clock64();
+                if (prof_first) { prof_grp += prof_a - prof_g0; prof_first = false; }
 #endif
                 if (!(can_pf && (ch > 0 || staged))) {   // otherwise this chunk was written from registers already
                     __syncthreads();
@@ -790,7 +793,8 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
                 }
                 __syncthreads();
 #if N16_KNOCK & 8
-                prof_bar += clock64() - prof_a;
+                const long long prof_a2 = clock64();
+                prof_bar += prof_a2 - prof_a;
 #endif
                 const bool last_ch = ch + 1 == a.nchunks;
                 const bool do_pf = can_pf && (!last_ch || has_next) && !(a.dbg & 1);
@@ -827,6 +831,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
                 const float4 psh = *reinterpret_cast<const float4*>(pbn ? a.pre.shift + pc0 : a.wpk);
 #if N16_KNOCK & 8
                 long long prof_b = clock64();
+                prof_issue += prof_b - prof_a2;
 #endif
                 if (active) {
                     // A fragments: TM <= 4 keeps two register sets (ping-pong by tap).  TM = 8 has ONE set and pipelines at
@@ -1007,8 +1012,8 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
     }
 #if N16_KNOCK & 8
     if (blockIdx.x == 0 && lane == 0)
-        printf("n16 prof wave %d: total %lld  mfma-phase %lld  barrier+stage %lld  pf-write %lld  epilogue %lld cycles (s_memtime, 100 MHz)\n", wave,
-               clock64() - prof_t0, prof_mfma, prof_bar, prof_pf, prof_epi);
+        printf("n16 prof wave %d: total %lld  mfma-phase %lld  barrier+stage %lld  prefetch-issue %lld  pf-write %lld  epilogue %lld  group-setup %lld (s_memtime ticks)\n", wave,
+               clock64() - prof_t0, prof_mfma, prof_bar, prof_issue, prof_pf, prof_epi, prof_grp);
 #endif
 }
 
