@@ -181,3 +181,33 @@ def test_predict_py_takes_a_pdb_file_directly(gpu, tmp_path):
     for fn in sorted(p.name for p in a.iterdir()):
         assert (a / fn).read_bytes() == (b / fn).read_bytes(), fn
     assert (a / "M.txt").read_text().endswith("1ubqA 76\n")
+
+
+@pytest.mark.gpu
+def test_voxelised_structure_as_aposteriori_layout_hdf5(gpu, tmp_path):
+    """voxeliser -> .hdf5 in aposteriori's layout (timed_hip.h5write) -> predict.py: the files equal those of predicting
+    straight from the PDB, and the dataset reads back through the reference-named loaders"""
+    import warnings
+    import predict
+    from design_utils import utils
+    from timed_hip import pack, synth
+    X, labels, flat = voxeliser.voxelise_pdb(UBQ, device=gpu)
+    h5 = tmp_path / "1ubq.hdf5"
+    voxeliser.write_hdf5(h5, X, labels, flat, gaussian=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fmap, _ = utils.create_flat_dataset_map(h5)
+        Xb, yb = utils.load_batch(h5, fmap)
+    assert [tuple(r) for r in fmap] == flat and Xb.dtype == np.float64
+    assert np.array_equal(Xb.astype(np.float32), X) and np.array_equal(yb, labels.astype(float))
+    cfg, weights = synth.timed_synth(20, widths=(8, 16), side=21, in_channels=5, seed=3)
+    mp = tmp_path / "M.pack"
+    mp.write_bytes(pack.keras_to_pack(cfg, weights))
+    a, b = tmp_path / "a", tmp_path / "b"
+    a.mkdir(); b.mkdir()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        predict.load_dataset_and_predict([mp], UBQ, batch_size=16, dataset_map_path=a / "datasetmap.txt", path_to_output=a)
+        predict.load_dataset_and_predict([mp], h5, batch_size=16, dataset_map_path=b / "datasetmap.txt", path_to_output=b)
+    for fn in sorted(p.name for p in a.iterdir()):
+        assert (a / fn).read_bytes() == (b / fn).read_bytes(), fn

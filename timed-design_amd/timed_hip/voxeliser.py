@@ -165,3 +165,33 @@ def write_frame_pack(stem, frames: np.ndarray, labels: np.ndarray, flat_map, gau
     with open(stem + ".meta.json", "w") as f:
         json.dump(dict(frame_dims=list(frames.shape[1:]), voxels_as_gaussian=bool(gaussian), n_frames=int(frames.shape[0]),
                        source=source, make_frame_dataset_ver="timed_hip.voxeliser (unpinned vs aposteriori 2.4.0)"), f)
+
+
+def write_hdf5(path, frames: np.ndarray, labels: np.ndarray, flat_map, gaussian: bool, atom_encoder: Sequence[str] = DEFAULT_ENCODER,
+               frame_edge_length: float = 21.0, encode_cb: bool = True, compression: Optional[str] = "gzip"):
+    """Store voxelised frames in aposteriori's own layout (reference design_utils/utils.py:238-251) — pdb_code / chain /
+    residue number datasets with `label` and `encoded_residue` attributes, file attributes as make-frame-dataset writes
+    them — with timed_hip.h5write, so that h5py, the reference's predict.py and this repo's readers all open it.  Frames
+    are stored as float64 (Gaussian) or bool like the reference's loader expects (utils.py:518-521)."""
+    from design_utils.amino_acids import standard_amino_acids
+    from . import h5write
+    with h5write.File(path) as f:
+        f.attrs["make_frame_dataset_ver"] = "2.4.0"        # the layout version the reference's checks accept (utils.py:271-280)
+        f.attrs["frame_dims"] = np.asarray(frames.shape[1:], dtype=np.int64)
+        f.attrs["atom_encoder"] = list(atom_encoder)
+        f.attrs["encode_cb"] = bool(encode_cb)
+        f.attrs["atom_filter_fn"] = "timed_hip.voxeliser: backbone + idealised C-beta (unpinned vs aposteriori)"
+        f.attrs["residue_encoder"] = list(standard_amino_acids.keys())
+        f.attrs["frame_edge_length"] = float(frame_edge_length)
+        f.attrs["voxels_as_gaussian"] = bool(gaussian)
+        groups: dict = {}
+        for i, (pdb, chain, number, label) in enumerate(flat_map):
+            g = groups.get((pdb,))
+            if g is None:
+                g = groups[(pdb,)] = f.create_group(str(pdb))
+            c = groups.get((pdb, chain))
+            if c is None:
+                c = groups[(pdb, chain)] = g.create_group(str(chain))
+            data = frames[i].astype(np.float64) if gaussian else frames[i].astype(bool)
+            c.create_dataset(str(number), data, compression=compression,
+                             attrs={"label": str(label), "encoded_residue": labels[i].astype(np.float64)})

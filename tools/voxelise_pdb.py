@@ -16,6 +16,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("structures", nargs="+")
     ap.add_argument("--out", required=True, help="stem of the frame pack to write")
+    ap.add_argument("--hdf5", action="store_true", help="also write <out>.hdf5 in aposteriori's layout (gzip), readable by h5py and the reference")
     ap.add_argument("--boolean", action="store_true", help="voxels_as_gaussian=False (uint8 frames)")
     ap.add_argument("--all-states", action="store_true", help="voxelise every MODEL as <code>_<k>")
     ap.add_argument("--voxels-per-side", type=int, default=21)
@@ -30,5 +31,7 @@ if __name__ == "__main__":
         Xs.append(X); Ls.append(labels); flat += rows
     X, L = np.concatenate(Xs), np.concatenate(Ls)
     voxeliser.write_frame_pack(a.out, X, L, flat, gaussian=not a.boolean, source=",".join(os.path.basename(p) for p in a.structures))
+    if a.hdf5:
+        voxeliser.write_hdf5(a.out + ".hdf5", X, L, flat, gaussian=not a.boolean, frame_edge_length=a.frame_edge_length)
     print(f"{len(flat)} residue frames {X.shape[1:]} {X.dtype} from {len(a.structures)} structure(s) -> {a.out}.framepack "
           f"in {time.perf_counter() - t0:.2f} s")
