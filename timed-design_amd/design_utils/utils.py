@@ -279,32 +279,25 @@ def _frame_pack(path):
 
 
 # ---- rotamer codec ------------------------------------------------------------------------------------
+def _rotamer_suffixes(n_chi: int) -> t.List[str]:
+    """the 3**n_chi rotamer labels of a residue with n_chi side-chain dihedrals, each angle in bin 1, 2 or 3, first angle
+    slowest ("11", "12", "13", "21", ...); a residue without side-chain dihedrals has the single label "0" """
+    return ["".join(bins) for bins in product("123", repeat=n_chi)] if n_chi else ["0"]
+
+
 def get_rotamer_codec(return_reduction_guide: bool = False):
-    """reference utils.py:410-465.  338 categories: per residue (alphabetical one-letter order) all
-    3**n_chi rotamer combinations ("ARG_1123" ...), "_0" for residues without side-chain dihedrals.
-    Returns ({rotamer_index: one-hot(20)}, [338 names]) and optionally the first index of each residue
-    ([0, 1, 4, 13, 40, ...], the guide printed at reference :425)."""
-    flat_categories: t.List[str] = []
-    rot_to_20res = {}
-    reduction_guide = []
-    r_count = 0
-    for i, (_a, res) in enumerate(standard_amino_acids.items()):
-        reduction_guide.append(r_count)
-        if res in side_chain_dihedrals:
-            combos = list(product([1, 2, 3], repeat=len(side_chain_dihedrals[res])))
-            for r, rota in enumerate(combos):
-                flat_categories.append(f"{res}_{''.join(str(x) for x in rota)}")
-                onehot = np.array([0] * 20)
-                onehot[i] = 1
-                rot_to_20res[r_count + r] = onehot
-            r_count += len(combos)
-        else:
-            flat_categories.append(f"{res}_0")
-            onehot = np.array([0] * 20)
-            onehot[i] = 1
-            rot_to_20res[r_count] = onehot
-            r_count += 1
+    """reference utils.py:410-465.  The 338 rotamer categories: residues in alphabetical one-letter order, every residue
+    contributing its rotamer labels ("ARG_1123" ...; "ALA_0" / "GLY_0" for residues without side-chain dihedrals).
+    Returns ({rotamer_index: one-hot(20) of its residue}, [338 names]) and optionally the index of each residue's first
+    category ([0, 1, 4, 13, 40, ...] — the guide printed at reference :425)."""
+    residues = list(standard_amino_acids.values())
+    per_residue = [_rotamer_suffixes(len(side_chain_dihedrals.get(res, ()))) for res in residues]
+    flat_categories = [f"{res}_{suffix}" for res, suffixes in zip(residues, per_residue) for suffix in suffixes]
+    owner = np.repeat(np.arange(len(residues)), [len(sfx) for sfx in per_residue])       # category -> residue index
+    identity = np.eye(len(residues), dtype=int)
+    rot_to_20res = {k: identity[r].copy() for k, r in enumerate(owner)}
     if return_reduction_guide:
+        reduction_guide = np.concatenate([[0], np.cumsum([len(sfx) for sfx in per_residue])[:-1]]).tolist()
         return rot_to_20res, flat_categories, reduction_guide
     return rot_to_20res, flat_categories
 
