@@ -44,22 +44,21 @@ def _as_str(v) -> str:
 
 
 # ---- dataset map ----------------------------------------------------------------------------------------
+# dataset-map flavours: (column delimiter, header lines to skip)
+_MAP_FORMATS = {True: (",", 0),     # old maps: csv rows (pdb, chain, residue_id, label)
+                False: (" ", 3)}    # PDBench maps: three header lines, then "<pdb> <count>"
+
+
 def load_datasetmap(path_to_datasetmap: Path, is_old: bool = False) -> np.ndarray:
-    """reference utils.py:190-227.  New (PDBench) maps: three header lines then "<pdb> <count>";
-    old maps: csv of (pdb, chain, residue_id, label)."""
+    """reference utils.py:190-227: rows of the map as strings.  A map with a single row parses to a 1-D array; it is
+    wrapped in a list so that callers can still iterate rows (reference :223-225)."""
     path_to_datasetmap = Path(path_to_datasetmap)
     assert (
         path_to_datasetmap.suffix == ".txt"
     ), f"Expected Path {path_to_datasetmap} to be a .txt file but got {path_to_datasetmap.suffix}."
-    if is_old:
-        dataset_map = np.genfromtxt(path_to_datasetmap, delimiter=",", dtype=str)
-    else:
-        dataset_map = np.genfromtxt(path_to_datasetmap, delimiter=" ", dtype=str, skip_header=3)
-    dataset_map = np.asarray(dataset_map)
-    # a single-pdb map parses to a 1-D array: wrap it so callers can iterate rows (reference :223-225)
-    if isinstance(dataset_map[0], str):
-        dataset_map = [dataset_map]
-    return dataset_map
+    delimiter, header_lines = _MAP_FORMATS[bool(is_old)]
+    rows = np.asarray(np.genfromtxt(path_to_datasetmap, delimiter=delimiter, dtype=str, skip_header=header_lines))
+    return [rows] if rows.ndim == 1 else rows
 
 
 def get_pdb_keys_to_filter(pdb_key_path: Path, file_extension: str = ".txt") -> t.List[str]:
@@ -309,6 +308,44 @@ def compress_rotamer_predictions_to_20(prediction_matrix: np.ndarray) -> np.ndar
 
 
 # ---- prediction matrix -> sequences ----------------------------------------------------------------------
+def _column_letters(rotamers_categories) -> np.ndarray:
+    """one-letter residue code of every probability column: the 20 residues in one-letter order, or — for a rotamer
+    matrix — the residue of each rotamer category ("ARG_1123" -> "R"; categories already given as letters pass through)"""
+    one_letter = {three: one for one, three in standard_amino_acids.items()}
+    if not rotamers_categories:
+        return np.array(list(standard_amino_acids.keys()))
+    if len(rotamers_categories[0]) == 1:
+        return np.array(list(rotamers_categories))
+    return np.array([one_letter[name.split("_")[0]] for name in rotamers_categories])
+
+
+def _row_groups_of_map(flat_dataset_map) -> t.List[t.Tuple[str, np.ndarray, t.Optional[np.ndarray]]]:
+    """(key, matrix rows, three-letter labels or None) per key, keys in first-seen order, rows in map order.
+    4-column maps: one matrix row per map row, key = pdb + chain, repeated keys are merged.  "<pdb> <count>" maps: every
+    map row takes the next ``count`` matrix rows; a key that appears again continues its entry."""
+    fmap = np.asarray(flat_dataset_map)
+    groups: t.Dict[str, t.List] = {}
+    if fmap.shape[1] == 4:
+        keys = np.char.add(fmap[:, 0].astype(str), fmap[:, 1].astype(str))
+        uniq, first_seen, inverse = np.unique(keys, return_index=True, return_inverse=True)
+        by_key = np.argsort(inverse, kind="stable")                    # matrix rows grouped by key, map order inside
+        bounds = np.concatenate([[0], np.cumsum(np.bincount(inverse))])
+        for u in np.argsort(first_seen, kind="stable"):
+            rows = by_key[bounds[u]:bounds[u + 1]]
+            groups[str(uniq[u])] = [rows, fmap[rows, 3]]
+        return [(k, v[0], v[1]) for k, v in groups.items()]
+    cursor = 0
+    for key, count in fmap:
+        key, count = str(key), int(count)
+        rows = np.arange(cursor, cursor + count)
+        cursor += count
+        if key in groups:
+            groups[key][0] = np.concatenate([groups[key][0], rows])
+        else:
+            groups[key] = [rows, None]
+    return [(k, v[0], None) for k, v in groups.items()]
+
+
 def extract_sequence_from_pred_matrix(
     flat_dataset_map: t.List[t.Tuple],
     prediction_matrix: np.ndarray,
@@ -316,68 +353,31 @@ def extract_sequence_from_pred_matrix(
     old_datasetmap: bool = False,
     is_consensus: bool = False,
 ) -> (dict, dict, dict, dict, dict):
-    """reference utils.py:616-723.  argmax (first maximum) -> one-letter sequence per key; key =
-    pdb+chain for 4-column maps, the map's own key for "<pdb> <count>" maps.  ``old_datasetmap`` is
-    re-derived from the map width exactly as the reference does (:662).  With ``is_consensus`` the
-    states "<pdb>_<n>" of an NMR ensemble are merged by the reference's RUNNING PAIRWISE average
-    (acc+new)/2 (:699-705) — not an arithmetic mean."""
-    res_to_r_dic = dict(zip(standard_amino_acids.values(), standard_amino_acids.keys()))
-    if rotamers_categories:
-        if len(rotamers_categories[0]) == 1:
-            res_dic = list(rotamers_categories)
-        else:
-            res_dic = [res_to_r_dic[res.split("_")[0]] for res in rotamers_categories]
-    else:
-        res_dic = list(standard_amino_acids.keys())
-    res_arr = np.array(res_dic)
+    """reference utils.py:616-723.  argmax (first maximum) -> one-letter sequence per key; key = pdb+chain for 4-column
+    maps, the map's own key for "<pdb> <count>" maps (which carry no true sequence: it stays "").  ``old_datasetmap`` is
+    re-derived from the map width exactly as the reference does (:662).  With ``is_consensus`` the states
+    "<pdb>_<n>..." of an NMR ensemble are merged by the reference's RUNNING PAIRWISE average (acc+new)/2 (:699-705) —
+    not an arithmetic mean."""
+    one_letter = {three: one for one, three in standard_amino_acids.items()}
+    letters = _column_letters(rotamers_categories)
     prediction_matrix = np.asarray(prediction_matrix)
-    max_idx = np.argmax(prediction_matrix, axis=1)
-    letters = res_arr[max_idx]
-
-    pdb_to_sequence: dict = {}
-    pdb_to_probability: dict = {}
-    pdb_to_real_sequence: dict = {}
-    old_datasetmap = True if len(flat_dataset_map[0]) == 4 else False
-    if old_datasetmap:
-        # rows are consumed one-to-one; group consecutive (and repeated) keys in first-seen order
-        rows: dict = {}
-        for i in range(len(flat_dataset_map)):
-            pdb_chain, chain, _, res = flat_dataset_map[i]
-            key = str(pdb_chain) + str(chain)
-            rows.setdefault(key, []).append(i)
-        for key, idxs in rows.items():
-            ii = np.asarray(idxs)
-            pdb_to_sequence[key] = "".join(letters[ii])
-            pdb_to_probability[key] = [list(prediction_matrix[k]) for k in ii]
-            pdb_to_real_sequence[key] = "".join(res_to_r_dic[str(flat_dataset_map[k][3])] for k in ii)
-    else:
-        previous_count = 0
-        for i in range(len(flat_dataset_map)):
-            key, count = flat_dataset_map[i]
-            key, count = str(key), int(count)
-            if key not in pdb_to_sequence:
-                pdb_to_sequence[key] = ""
-                pdb_to_real_sequence[key] = ""
-                pdb_to_probability[key] = []
-            sl = slice(previous_count, previous_count + count)
-            pdb_to_sequence[key] += "".join(letters[sl])
-            pdb_to_probability[key].extend(list(row) for row in prediction_matrix[sl])
-            previous_count += count
-
+    predicted = letters[np.argmax(prediction_matrix, axis=1)]
+    pdb_to_sequence, pdb_to_probability, pdb_to_real_sequence = {}, {}, {}
+    for key, rows, labels in _row_groups_of_map(flat_dataset_map):
+        pdb_to_sequence[key] = "".join(predicted[rows])
+        pdb_to_probability[key] = [list(r) for r in prediction_matrix[rows]]
+        pdb_to_real_sequence[key] = "".join(one_letter[str(lab)] for lab in labels) if labels is not None else ""
     if not is_consensus:
         return pdb_to_sequence, pdb_to_probability, pdb_to_real_sequence, None, None
-    pdb_to_consensus: dict = {}
+    # consecutive keys with the same prefix before the first "_" are states of one structure
     pdb_to_consensus_prob: dict = {}
-    last_pdb = ""
-    for pdb_chain in pdb_to_sequence.keys():
-        curr_pdb = pdb_chain.split("_")[0]
-        if last_pdb != curr_pdb:
-            pdb_to_consensus_prob[curr_pdb] = np.array(pdb_to_probability[pdb_chain])
-            last_pdb = curr_pdb
-        else:
-            pdb_to_consensus_prob[curr_pdb] = (pdb_to_consensus_prob[curr_pdb] + np.array(pdb_to_probability[pdb_chain])) / 2
-    for pdb_chain, curr_prob in pdb_to_consensus_prob.items():
-        pdb_to_consensus[pdb_chain] = "".join(res_arr[np.argmax(curr_prob, axis=1)])
+    previous = None
+    for key in pdb_to_sequence:
+        structure = key.split("_")[0]
+        state = np.array(pdb_to_probability[key])
+        pdb_to_consensus_prob[structure] = state if structure != previous else (pdb_to_consensus_prob[structure] + state) / 2
+        previous = structure
+    pdb_to_consensus = {structure: "".join(letters[np.argmax(prob, axis=1)]) for structure, prob in pdb_to_consensus_prob.items()}
     return pdb_to_sequence, pdb_to_probability, pdb_to_real_sequence, pdb_to_consensus, pdb_to_consensus_prob
 
 
