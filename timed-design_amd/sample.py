@@ -28,12 +28,22 @@ def _one_letter_rotamer_categories():
     return [three_to_one[name.split("_")[0]] for name in names]
 
 
+def _read_matrix(path) -> np.ndarray:
+    """The prediction matrix as float64 — what ``np.genfromtxt(path, delimiter=",", dtype=np.float64)`` returns
+    (reference sample.py:31-33) — through NumPy's C parser (both convert every field with a correctly rounded
+    strtod); anything that parser refuses (missing fields, ragged rows) goes to genfromtxt and its rules."""
+    try:
+        return np.loadtxt(path, delimiter=",", dtype=np.float64, ndmin=2)
+    except ValueError:
+        return np.atleast_2d(np.genfromtxt(path, delimiter=",", dtype=np.float64))
+
+
 def main_sample(args):
     np.random.seed(args.seed)
     matrix_path, map_path = Path(args.path_to_pred_matrix), Path(args.path_to_datasetmap)
     for what, path in (("prediction matrix", matrix_path), ("dataset map", map_path)):
         assert path.exists(), f"No {what} at {path}"
-    probabilities = np.atleast_2d(np.genfromtxt(matrix_path, delimiter=",", dtype=np.float64))
+    probabilities = _read_matrix(matrix_path)
     if args.temperature != 1:           # at T == 1 the rows are used exactly as stored (not even renormalised)
         probabilities = su.apply_temp_to_probs(probabilities, t=args.temperature)
     categories = _one_letter_rotamer_categories() if args.predict_rotamers else None
