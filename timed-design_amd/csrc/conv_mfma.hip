@@ -37,6 +37,10 @@ constexpr size_t kLdsLimit = 160 * 1024;
 #ifndef STAGE_U
 #define STAGE_U 8  // staging loads in flight per thread
 #endif
+// -DCONV_PROF=1: per-wave s_memtime phase totals of k_conv_mfma printed by workgroup 0 (timing experiments)
+#ifndef CONV_PROF
+#define CONV_PROF 0
+#endif
 
 struct ConvMfmaArgs {
     const float* in; int64_t in_fs; int in_cs, in_coff, Din, Hin, Win, Cin, vec_ok;
@@ -69,6 +73,10 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
     const int CS4 = a.CS >> 2;
+#if CONV_PROF
+    const long long cp_t0 = clock64();
+    long long cp_tab = 0, cp_stage = 0, cp_mfma = 0, cp_epi = 0;
+#endif
 
     // ---- workgroup -> (frame group, z brick, channel block) ---------------------------------
     int bid = blockIdx.x;
@@ -178,6 +186,9 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
                 for (int i = 0; i < 16; ++i) acc[tm][tn][i] = 0.f;
 
         if (rd == 0) __syncthreads();  // row tables visible
+#if CONV_PROF
+        if (rd == 0) cp_tab = clock64() - cp_t0;
+#endif
         // a wave's TM m-tiles are interleaved (mb, mb + nmb, ...) so that every wave gets its share of the
         // boundary-plane tiles that skip taps
         const int nmb = (a.n_mtiles + TM - 1) / TM;
@@ -195,6 +206,9 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
             constexpr bool kLdsEpi = (TM * TN > 2);  // the LDS epilogue clobbers the staging area
             const bool need_a = (kLdsEpi || !(a.nchunks == 1 && rd > 0)) && !((a.dbg & 1) && ch > 0);
             const bool need_b = BRES == 2 ? false : (BRES ? need_a : true);
+#if CONV_PROF
+            const long long cp_a = clock64();
+#endif
             __syncthreads();  // everyone is done reading the previous A image / B slabs
             if (need_a) {
                 // ---- stage the haloed input brick for channels [ch*CI, ch*CI+CI) ------------------
@@ -259,6 +273,10 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
                 for (int i = tid; i < n4; i += NTHREADS) B4[i] = wch4[i];
             }
             __syncthreads();
+#if CONV_PROF
+            const long long cp_b = clock64();
+            cp_stage += cp_b - cp_a;
+#endif
 
             if (BRES == 2) {
                 // weights streamed L2 -> registers, one tap ahead: every lane fetches exactly its own MFMA
@@ -451,7 +469,13 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
                             }
                         }
             }
+#if CONV_PROF
+            cp_mfma += clock64() - cp_b;
+#endif
         }  // chunks
+#if CONV_PROF
+        const long long cp_e = clock64();
+#endif
 
         // ---- epilogue: bias, activation / BN-affine chain, optional 2x2x2 pool, store ------------
         constexpr bool REG_EPI = (TM * TN <= 2);
@@ -564,7 +588,15 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
                 }
             }
         }
+#if CONV_PROF
+        cp_epi += clock64() - cp_e;
+#endif
     }  // rounds
+#if CONV_PROF
+    if (blockIdx.x == 0 && lane == 0)
+        printf("conv_mfma prof wave %d: total %lld  tables %lld  staging+barriers %lld  mfma-phase %lld  epilogue %lld (s_memtime ticks)\n", wave,
+               clock64() - cp_t0, cp_tab, cp_stage, cp_mfma, cp_epi);
+#endif
 }
 
 // =====================================================================================================
