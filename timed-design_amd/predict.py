@@ -224,6 +224,12 @@ def load_dataset_and_predict(
     loader = model_loader or engine.load_model
     if world > 1:
         device_ids = [local_rank if devices is None else list(devices)[local_rank % len(devices)]]
+        if model_loader is None:
+            from timed_hip import _lib
+            visible = _lib.device_count()
+            if device_ids[0] >= visible:
+                raise RuntimeError(f"rank {rank} (local rank {local_rank}) needs HIP device {device_ids[0]} but only {visible} "
+                                   f"device(s) are visible: launch one process per GPU")
     elif sharded:
         device_ids = [device]
     else:
