@@ -638,7 +638,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
     constexpr int NTHREADS = WAVES * 64;
     constexpr int CI = 16, CI4 = 4, NTAPS = 27;
     constexpr int BR = 9;                       // weight-ring depth (taps in flight)
-    constexpr int PF = (TM <= 4) ? 11 : 14;   // float4 per thread of next-chunk prefetch
+    constexpr int PF = (TM <= 4) ? 6 : 8;     // float4 per thread of next-chunk prefetch (REAL voxels only, see pf_off)
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -703,7 +703,14 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
     // next-chunk prefetch: when the whole staged image is <= PF float4 per thread, the global loads of the
     // NEXT chunk (or of chunk 0 of this workgroup's next frame group) are issued before the MFMA phase of the
     // current chunk and land in registers underneath it
-    const bool can_pf = rounds == 1 && nvec <= PF * NTHREADS && a.vec_ok && (a.Cin & 3) == 0 && !(a.dbg & 64);
+    // Only voxels that exist in the input are prefetched: the halo of the staged image is written (with zeros) by
+    // the first, plain staging pass of the workgroup and never changes afterwards, so re-writing it every chunk
+    // (42 % of a 12^3 image, 64 % of a 7^3 one) would only cost load issue slots, registers and LDS writes.
+    const int zlo = max(a.pz, 0), ylo = max(a.py, 0), xlo = max(a.px, 0);
+    const int nzr = min(a.Zp, a.Din + a.pz) - zlo, nyr = min(a.Hp, a.Hin + a.py) - ylo, nxr = min(a.Wp, a.Win + a.px) - xlo;
+    const int real_pf = nzr * nyr * nxr;          // real voxels of one staged frame
+    const int nreal4 = a.FB * real_pf * CI4;
+    const bool can_pf = rounds == 1 && nreal4 <= PF * NTHREADS && nzr > 0 && nyr > 0 && nxr > 0 && a.vec_ok && (a.Cin & 3) == 0 && !(a.dbg & 64);
 
     // nvalid: frames of the group that exist (the last group of a batch may be ragged)
     auto load_vec = [&](const float* inb, int nvalid, int ch, int i, bool* okp) -> float4 {
@@ -763,11 +770,19 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
         }
     }
 
-    int pf_off[PF];        // this thread's prefetch sources (staged voxel -> input offset, -1 = halo / nothing)
+    int pf_off[PF];        // this thread's prefetch sources: input offset of real voxel (tid + u * NTHREADS) / 4, -1 = nothing
+    int pf_dst[PF];        // ... and where it goes in the staged image (float4 index)
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
         const int i = tid + u * NTHREADS;
-        pf_off[u] = (can_pf && i < nvec) ? voxsrc[i / CI4] : -1;
+        pf_off[u] = -1; pf_dst[u] = 0;
+        if (can_pf && i < nreal4) {
+            const int r = i / CI4, f = r / real_pf, rr = r - f * real_pf;
+            const int xa = rr % nxr, t = rr / nxr, ya = t % nyr, za = t / nyr;
+            const int v = ((f * a.Zp + za + zlo) * a.Hp + ya + ylo) * a.Wp + xa + xlo;
+            pf_off[u] = voxsrc[v];
+            pf_dst[u] = v * CS4 + (i % CI4);
+        }
     }
     bool staged = false;   // chunk 0 of the current group was already written to LDS from the prefetch registers
 #if N16_KNOCK & 8
@@ -846,7 +861,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
                         // the source offsets do not depend on the chunk or the frame group: looked up once per workgroup
                         // (pf_off, below the tables) instead of 14 LDS reads + divisions in front of every MFMA phase
                         int off = do_pf ? pf_off[u] : -1;
-                        if (pnv < a.FB && off >= 0 && ((tid + u * NTHREADS) / CI4) / vox_pf >= pnv) off = -1;
+                        if (pnv < a.FB && off >= 0 && ((tid + u * NTHREADS) / CI4) / real_pf >= pnv) off = -1;
                         const bool ld = off >= 0 && gok;
                         const float4* src = ld ? reinterpret_cast<const float4*>(pin + off + g * 4)
                                                : reinterpret_cast<const float4*>(a.wpk);
@@ -966,10 +981,8 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
                     }
                     __syncthreads();   // every wave is done reading chunk ch
 #pragma unroll
-                    for (int u = 0; u < PF; ++u) {
-                        const int i = tid + u * NTHREADS;
-                        if (i < nvec) A4[(size_t)(i / CI4) * CS4 + (i % CI4)] = pfv[u];
-                    }
+                    for (int u = 0; u < PF; ++u)
+                        if (pf_off[u] >= 0) A4[pf_dst[u]] = pfv[u];   // also for frames missing from a ragged group (zeros)
                 }
 #if N16_KNOCK & 8
                 prof_pf += clock64() - prof_c;
