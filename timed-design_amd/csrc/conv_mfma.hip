@@ -59,7 +59,8 @@ struct ConvMfmaArgs {
     int sd, sh, sw;    // convolution stride (k_conv_mfma only; 1 elsewhere)
 };
 
-template <int WAVES, int TM, int TN, int NT, int CI, int BRES, int POOL>
+// GEO > 0 (streamed 16-channel variants, 3x3x3, stride 1): Hp = Wp = GEO at compile time; see the tap loop.
+template <int WAVES, int TM, int TN, int NT, int CI, int BRES, int POOL, int GEO = 0>
 __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(const ConvMfmaArgs a) {
     constexpr int NTHREADS = WAVES * 64;
     constexpr int BN = NT * 32;
@@ -300,7 +301,73 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
                         else if (tz + 1 < a.kd) { tx = 0; ty = 0; ++tz; }
                         return ((tz * a.Hp + ty) * a.Wp + tx) * CS4;
                     };
-                    if (KK == 2) {
+                    if constexpr (GEO > 0 && KK == 2) {
+                        // Compile-time geometry: the nine in-plane taps of a dz plane are unrolled and their staged-voxel
+                        // offsets are IMMEDIATES of the ds_read_b128 instructions (relative to a per-dz base), the weight
+                        // pointer just advances — no scalar tap counters, no v_add per fragment read.  Every non-MFMA
+                        // instruction in this loop delays the next MFMA issue by about its own issue time: on the bare
+                        // stage structure (tools/microbench/stage_bench.hip) the address arithmetic costs 2.4 % of the
+                        // matrix pipe (151.8 -> 155.4 TFLOP/s).
+                        constexpr int C5 = (CI + 4) / 4;          // float4 per staged voxel (CS = CI + 4)
+                        constexpr int PLANE = GEO * GEO * C5;     // one dz step
+                        float4 bc[2][TN], avA[TM], avB[TM];
+#pragma unroll
+                        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                            for (int tn = 0; tn < TN; ++tn) bc[kk][tn] = wf[(kk * NT + tn) * 64];
+                        int az[TM];
+#pragma unroll
+                        for (int tm = 0; tm < TM; ++tm) { az[tm] = aidx[tm]; avA[tm] = A4[az[tm]]; }
+                        const float4* wt = wf;   // the current tap's fragments
+                        for (int dz = 0; dz < 3; ++dz) {
+                            const int nxt_plane = dz < 2 ? PLANE : (2 * GEO + 2) * C5;   // after the last tap: re-read it
+#pragma unroll
+                            for (int t9 = 0; t9 < 9; ++t9) {
+                                const int cur = ((t9 / 3) * GEO + t9 % 3) * C5;
+                                const int nxt = (((t9 + 1) / 3) * GEO + (t9 + 1) % 3) * C5;
+                                const float4* wn = (t9 == 8 && dz == 2) ? wt : wt + TAPSTRIDE;
+                                // ---- stage 0 ----
+#pragma unroll
+                                for (int tm = 0; tm < TM; ++tm) avB[tm] = A4[az[tm] + cur + 2];
+                                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                for (int tm = 0; tm < TM; ++tm) {
+                                    if ((skp[tm] >> dz) & 1) continue;  // whole tile sees only the zero halo for this dz
+#pragma unroll
+                                    for (int tn = 0; tn < TN; ++tn) {
+                                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(avA[tm].x, bc[0][tn].x, acc[tm][tn], 0, 0, 0);
+                                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(avA[tm].y, bc[0][tn].y, acc[tm][tn], 0, 0, 0);
+                                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(avA[tm].z, bc[0][tn].z, acc[tm][tn], 0, 0, 0);
+                                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(avA[tm].w, bc[0][tn].w, acc[tm][tn], 0, 0, 0);
+                                    }
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                for (int tn = 0; tn < TN; ++tn) bc[0][tn] = wn[tn * 64];
+                                // ---- stage 1 ----
+#pragma unroll
+                                for (int tm = 0; tm < TM; ++tm) avA[tm] = A4[az[tm] + (t9 < 8 ? nxt : nxt_plane)];
+                                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                for (int tm = 0; tm < TM; ++tm) {
+                                    if ((skp[tm] >> dz) & 1) continue;
+#pragma unroll
+                                    for (int tn = 0; tn < TN; ++tn) {
+                                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(avB[tm].x, bc[1][tn].x, acc[tm][tn], 0, 0, 0);
+                                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(avB[tm].y, bc[1][tn].y, acc[tm][tn], 0, 0, 0);
+                                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(avB[tm].z, bc[1][tn].z, acc[tm][tn], 0, 0, 0);
+                                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(avB[tm].w, bc[1][tn].w, acc[tm][tn], 0, 0, 0);
+                                    }
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                for (int tn = 0; tn < TN; ++tn) bc[1][tn] = wn[(NT + tn) * 64];
+                                wt = wn;
+                            }
+#pragma unroll
+                            for (int tm = 0; tm < TM; ++tm) az[tm] += PLANE;
+                        }
+                    } else if (KK == 2) {
                         float4 bc[2][TN], avA[TM], avB[TM];
 #pragma unroll
                         for (int kk = 0; kk < 2; ++kk)
@@ -319,7 +386,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
                             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                             for (int tm = 0; tm < TM; ++tm) {
-                                if ((skp[tm] >> cz) & 1) continue;  // whole tile sees only the zero halo for this dz
+                                if (__builtin_expect((skp[tm] >> cz) & 1, 0)) continue;  // whole tile sees only the zero halo for this dz
 #pragma unroll
                                 for (int tn = 0; tn < TN; ++tn) {
                                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(avA[tm].x, bc[0][tn].x, acc[tm][tn], 0, 0, 0);
@@ -337,7 +404,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
                             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                             for (int tm = 0; tm < TM; ++tm) {
-                                if ((skp[tm] >> cz) & 1) continue;  // whole tile sees only the zero halo for this dz
+                                if (__builtin_expect((skp[tm] >> cz) & 1, 0)) continue;  // whole tile sees only the zero halo for this dz
 #pragma unroll
                                 for (int tn = 0; tn < TN; ++tn) {
                                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(avB[tm].x, bc[1][tn].x, acc[tm][tn], 0, 0, 0);
@@ -632,7 +699,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // 12 of 32 columns on zeros; the round-1 version ran these channels as 64 scalar FMAs per tap per wave on the VALU
 // pipe and could not afford the next-chunk prefetch).  The four blocks of a row group hold partial sums over the
 // channel quarters q; they are added with two cross-lane exchanges in the epilogue.
-template <int WAVES, int TM, int POOL, int XC = 0>
+// GEO > 0: Hp = Wp = GEO at compile time.  The 27 tap offsets then are immediates of the ds_read_b128 instructions
+// instead of a scalar offset + one v_add_u32 per read: measured on the bare tap loop (tools/microbench/
+// n16_tap_bench.hip) the address arithmetic alone costs 5-6 % of the matrix pipe (92 -> 98.6 % at TM = 8).
+template <int WAVES, int TM, int POOL, int XC = 0, int GEO = 0>
 __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(const ConvMfmaArgs a) {
     static_assert(XC == 0 || (XC == 4 && TM <= 4 && POOL == 0), "side channels: 4 channels (one 4x4x1 block column), ping-pong variant, no pooling");
     constexpr int NTHREADS = WAVES * 64;
@@ -644,47 +714,60 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, q = lane >> 4;
-    const int CS4 = a.CS >> 2;
+    constexpr int CS4 = 5;                    // plan_n16: CS = 20 floats per staged voxel
 
-    const int vox_pf = a.Zp * a.Hp * a.Wp;   // staged (haloed) voxels per frame; whole frames only (nzb == 1)
+    const int vox_pf = a.Zp * a.Hp * a.Wp;   // staged (haloed) voxels per frame and z slab
     const int nvox = a.FB * vox_pf;
     float4* A4 = smem;
-    int* rowvox = (int*)(reinterpret_cast<char*>(smem) + a.tab_off);
-    int* rowout = rowvox + a.nrows;
-    int* voxsrc = rowout + (POOL ? a.nrows / 8 : a.nrows);
+    // The three tables live INSIDE the staged image: a voxel occupies CS = 20 floats of which the fragment reads and the
+    // staging writes touch 16; floats 16, 17, 18 of voxel i hold rowvox[i], rowout[i], voxsrc[i] (nrows <= nvox).  No
+    // LDS beyond the image itself, so two slabs of a 10^3 frame (2 x 80 640 B) share a CU.
+    int* tabs = reinterpret_cast<int*>(smem);
+    const int TS = a.CS;
+#define ROWVOX(i) tabs[(i) * TS + 16]
+#define ROWOUT(i) tabs[(i) * TS + 17]
+#define VOXSRC(i) tabs[(i) * TS + 18]
+
+    // z slabs (nzb > 1): a unit of work is (frame group, slab); gridDim.x is a multiple of nzb, so a persistent
+    // workgroup keeps its slab and the tables are still built once.  The planner only emits nzb = 1 today: two 4-wave
+    // workgroups per CU on 5-plane slabs of a 10^3 frame (2 x 80 640 B) were measured at 124.0 TFLOP/s against 125.2
+    // for one 8-wave workgroup on the whole frame — the extra halo planes eat what the overlap gives.
+    const int zb = blockIdx.x % a.nzb;
+    const int z0 = zb * a.ZB;
+    const int ZBv = min(a.ZB, a.Dc - z0);
 
     // ---- tables, relative to the first frame of a group: built ONCE per (persistent) workgroup -------
     for (int v = tid; v < nvox; v += NTHREADS) {
         const int xl = v % a.Wp; int t = v / a.Wp;
         const int yl = t % a.Hp; t /= a.Hp;
         const int zl = t % a.Zp; const int f = t / a.Zp;
-        const int zi = zl - a.pz, yi = yl - a.py, xi = xl - a.px;
+        const int zi = z0 + zl - a.pz, yi = yl - a.py, xi = xl - a.px;
         const bool ok = zi >= 0 && zi < a.Din && yi >= 0 && yi < a.Hin && xi >= 0 && xi < a.Win;
-        voxsrc[v] = ok ? f * (int)a.in_fs + ((zi * a.Hin + yi) * a.Win + xi) * a.in_cs : -1;
+        VOXSRC(v) = ok ? f * (int)a.in_fs + ((zi * a.Hin + yi) * a.Win + xi) * a.in_cs : -1;
     }
     for (int r = tid; r < a.nrows; r += NTHREADS) {
         const int f = r / a.rows_pf, qq = r - f * a.rows_pf;
         int vox = 0, oo = -1;
         if (POOL == 0) {
             const int hw = a.Hc * a.Wc;
-            if (qq < a.Dc * hw) {
+            if (qq < ZBv * hw) {
                 const int zl = qq / hw, rem = qq - zl * hw, y = rem / a.Wc, x = rem - y * a.Wc;
                 vox = ((f * a.Zp + zl) * a.Hp + y) * a.Wp + x;
-                oo = f * (int)a.out_fs + ((zl * a.Ho + y) * a.Wo + x) * a.out_cs;
+                oo = f * (int)a.out_fs + (((z0 + zl) * a.Ho + y) * a.Wo + x) * a.out_cs;
             }
-            rowout[r] = oo;
+            ROWOUT(r) = oo;
         } else {
             const int pq = qq >> 3, mate = qq & 7;
             const int PH = a.Hc >> 1, PW = a.Wc >> 1;
-            if (pq < (a.Dc >> 1) * PH * PW) {
+            if (pq < (ZBv >> 1) * PH * PW) {
                 const int pzz = pq / (PH * PW), rem = pq - pzz * (PH * PW), pyy = rem / PW, pxx = rem - pyy * PW;
                 const int zl = 2 * pzz + (mate >> 2), y = 2 * pyy + ((mate >> 1) & 1), x = 2 * pxx + (mate & 1);
                 vox = ((f * a.Zp + zl) * a.Hp + y) * a.Wp + x;
-                oo = f * (int)a.out_fs + ((pzz * a.Ho + pyy) * a.Wo + pxx) * a.out_cs;
+                oo = f * (int)a.out_fs + ((((z0 >> 1) + pzz) * a.Ho + pyy) * a.Wo + pxx) * a.out_cs;
             }
-            if (mate == 0) rowout[r >> 3] = oo;
+            if (mate == 0) ROWOUT(r >> 3) = oo;
         }
-        rowvox[r] = vox;
+        ROWVOX(r) = vox;
     }
     __syncthreads();
 
@@ -692,22 +775,21 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
     const int total_blocks = (n_mt + TM - 1) / TM;
     const int rounds = (total_blocks + WAVES - 1) / WAVES;
     const float4* wpk4 = reinterpret_cast<const float4*>(a.wpk) + lane;  // [chunk][tap][lane]
-    const int wcount = a.nchunks * NTAPS;
     const int co = i16;
     const bool cvalid = co < a.Cout;
     const int cc = cvalid ? co : 0;
     const float bv = a.bias ? a.bias[cc] : 0.f;
     const int nvec = nvox * CI4;
     const bool has_pre = a.pre.scale || a.pre.act != ACT_LINEAR;
-    const int64_t ngroups = (a.nframes + a.FB - 1) / a.FB;
+    const int64_t ngroups = (a.nframes + a.FB - 1) / a.FB * a.nzb;   // units: (frame group, slab), slab fastest
     // next-chunk prefetch: when the whole staged image is <= PF float4 per thread, the global loads of the
     // NEXT chunk (or of chunk 0 of this workgroup's next frame group) are issued before the MFMA phase of the
     // current chunk and land in registers underneath it
     // Only voxels that exist in the input are prefetched: the halo of the staged image is written (with zeros) by
     // the first, plain staging pass of the workgroup and never changes afterwards, so re-writing it every chunk
     // (42 % of a 12^3 image, 64 % of a 7^3 one) would only cost load issue slots, registers and LDS writes.
-    const int zlo = max(a.pz, 0), ylo = max(a.py, 0), xlo = max(a.px, 0);
-    const int nzr = min(a.Zp, a.Din + a.pz) - zlo, nyr = min(a.Hp, a.Hin + a.py) - ylo, nxr = min(a.Wp, a.Win + a.px) - xlo;
+    const int zlo = max(a.pz - z0, 0), ylo = max(a.py, 0), xlo = max(a.px, 0);
+    const int nzr = min(a.Zp, a.Din + a.pz - z0) - zlo, nyr = min(a.Hp, a.Hin + a.py) - ylo, nxr = min(a.Wp, a.Win + a.px) - xlo;
     const int real_pf = nzr * nyr * nxr;          // real voxels of one staged frame
     const int nreal4 = a.FB * real_pf * CI4;
     const bool can_pf = rounds == 1 && nreal4 <= PF * NTHREADS && nzr > 0 && nyr > 0 && nxr > 0 && a.vec_ok && (a.Cin & 3) == 0 && !(a.dbg & 64);
@@ -715,7 +797,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
     // nvalid: frames of the group that exist (the last group of a batch may be ragged)
     auto load_vec = [&](const float* inb, int nvalid, int ch, int i, bool* okp) -> float4 {
         float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-        int off = (i < nvec) ? voxsrc[i / CI4] : -1;
+        int off = (i < nvec) ? VOXSRC(i / CI4) : -1;
         if (nvalid < a.FB && off >= 0 && (i / CI4) / vox_pf >= nvalid) off = -1;
         const int g = i % CI4;
         const int c0 = ch * CI + g * 4;
@@ -753,20 +835,35 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
     };
 
     // weight ring: slot t % BR holds tap t's fragment and is refilled with tap t + BR right after its last
-    // use; the packed image is [chunk][tap][lane], the index runs on into the next chunk and wraps to chunk 0
-    // for the next frame group
+    // use.  The packed image is [chunk][tap][lane] + the first BR taps once more at the end, so the index simply runs
+    // on (into the next chunk, and past the last chunk into the copy of chunk 0 for the next frame group) — and the
+    // refill address is (uniform chunk base) + (one of 7 loop-invariant per-lane offsets) + (immediate): NO address
+    // arithmetic in the tap loop.  On the bare loop 8 scalar + 1 vector instruction per refill cost 3-5 % of the
+    // matrix pipe (tools/microbench/n16_tap_bench.hip).
     float4 breg[BR];
+    unsigned voff[9];      // lane * 16 + k * 4096 bytes; (t + BR) * 1024 = voff[(t + BR) >> 2] + ((t + BR) & 3) * 1024
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        voff[k] = (unsigned)lane * 16u + (unsigned)k * 4096u;
+        asm volatile("" : "+v"(voff[k]));   // keep them as registers: re-deriving them would put the adds back
+    }
     // XC: this lane's B operand of the 4x4x1 blocks, xw[t % 3] = W_t[4q..4q+3][16 + (i16 & 3)] (packed image
-    // [chunk][tap][q][c][4]); a slot is refilled with tap t + 3 right after use (27 taps = 9 turns of the ring, so
-    // slots line up across chunks)
+    // [chunk][tap][q][c][4] + 3 taps of padding); a slot is refilled with tap t + 3 right after use (27 taps = 9 turns
+    // of the ring, so slots line up across chunks)
     const f32x4* wx4 = reinterpret_cast<const f32x4*>(a.wx) + q * (XC ? XC : 1) + (XC ? (i16 & 3) : 0);
+    unsigned voffx[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        voffx[k] = (unsigned)(q * (XC ? XC : 1) + (XC ? (i16 & 3) : 0)) * 16u + (unsigned)k * 4096u;
+        asm volatile("" : "+v"(voffx[k]));
+    }
     f32x4 xw[3];
     if (wave < total_blocks) {
 #pragma unroll
-        for (int t = 0; t < BR; ++t) breg[t] = wpk4[(size_t)(t % wcount) * 64];
+        for (int t = 0; t < BR; ++t) breg[t] = wpk4[(size_t)t * 64];
         if (XC) {
 #pragma unroll
-            for (int r = 0; r < 3; ++r) xw[r] = wx4[(size_t)(r % wcount) * 4 * XC];
+            for (int r = 0; r < 3; ++r) xw[r] = wx4[(size_t)r * 4 * XC];
         }
     }
 
@@ -780,7 +877,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
             const int r = i / CI4, f = r / real_pf, rr = r - f * real_pf;
             const int xa = rr % nxr, t = rr / nxr, ya = t % nyr, za = t / nyr;
             const int v = ((f * a.Zp + za + zlo) * a.Hp + ya + ylo) * a.Wp + xa + xlo;
-            pf_off[u] = voxsrc[v];
+            pf_off[u] = VOXSRC(v);
             pf_dst[u] = v * CS4 + (i % CI4);
         }
     }
@@ -789,14 +886,15 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
     long long prof_t0 = clock64(), prof_mfma = 0, prof_bar = 0, prof_epi = 0, prof_pf = 0, prof_issue = 0, prof_grp = 0;
 #endif
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-        const int64_t f0 = grp * a.FB;
+        const int64_t f0 = grp / a.nzb * a.FB;
         const int nvalid = (int)min((int64_t)a.FB, a.nframes - f0);
         const float* inb0 = a.in + f0 * a.in_fs + a.in_coff;
         float* outb = a.out + f0 * a.out_fs + a.out_coff;
-        const int64_t gnext = grp + gridDim.x;
+        const int64_t gnext = grp + gridDim.x;   // same slab: gridDim.x % nzb == 0
         const bool has_next = gnext < ngroups;
-        const float* inb_next = a.in + (has_next ? gnext : grp) * a.FB * a.in_fs + a.in_coff;
-        const int nvalid_next = has_next ? (int)min((int64_t)a.FB, a.nframes - gnext * a.FB) : nvalid;
+        const int64_t f0_next = (has_next ? gnext : grp) / a.nzb * a.FB;
+        const float* inb_next = a.in + f0_next * a.in_fs + a.in_coff;
+        const int nvalid_next = has_next ? (int)min((int64_t)a.FB, a.nframes - f0_next) : nvalid;
 
 #if N16_KNOCK & 8
         long long prof_d = 0;
@@ -816,7 +914,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
                 const int mt = blk * TM + tm;
-                aidx[tm] = ((active && mt < n_mt) ? rowvox[mt * 16 + i16] : 0) * CS4 + q;
+                aidx[tm] = ((active && mt < n_mt) ? ROWVOX(mt * 16 + i16) : 0) * CS4 + q;
             }
             for (int ch = 0; ch < a.nchunks; ++ch) {
                 const bool need_a = !(a.nchunks == 1 && rd > 0) && !((a.dbg & 1) && (ch > 0 || grp != blockIdx.x));
@@ -880,6 +978,8 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
                 long long prof_b = clock64();
                 prof_issue += prof_b - prof_a2;
 #endif
+                const char* wsc = reinterpret_cast<const char*>(a.wpk) + (size_t)ch * (NTAPS * 1024);          // uniform
+                const char* wxs = reinterpret_cast<const char*>(a.wx) + (size_t)ch * (NTAPS * 4 * (XC ? XC : 1) * 16);
                 if (active) {
                     // A fragments: TM <= 4 keeps two register sets (ping-pong by tap).  TM = 8 has ONE set and pipelines at
                     // half-tap granularity instead: as soon as the MFMAs of tiles 0..3 of tap t have issued, their
@@ -894,10 +994,10 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
 #pragma unroll
                     for (int t = 0; t < NTAPS; ++t) {
                         const int nt = t + 1;
-                        int noff = (((nt / 9) * a.Hp + (nt / 3) % 3) * a.Wp + nt % 3) * CS4;
-                        // opaque to LICM: otherwise hipcc hoists all 27*TM read addresses out of the chunk loop
-                        // and spills them to scratch
-                        asm volatile("" : "+s"(noff));
+                        int noff = (((nt / 9) * (GEO ? GEO : a.Hp) + (nt / 3) % 3) * (GEO ? GEO : a.Wp) + nt % 3) * CS4;
+                        // runtime geometry: opaque to LICM, otherwise hipcc hoists all 27*TM read addresses out of the
+                        // chunk loop and spills them to scratch
+                        if (!GEO) asm volatile("" : "+s"(noff));
                         if (PING && nt < NTAPS && !(N16_KNOCK & 4)) {
 #pragma unroll
                             for (int tm = 0; tm < TM; ++tm) av[nt & 1][tm] = (N16_KNOCK & 2) ? A4v[tid + tm * NTHREADS + (nt & 1) * 64] : A4v[aidx[tm] + noff];
@@ -929,9 +1029,8 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
                         }
                         __builtin_amdgcn_sched_barrier(0);
                         if (XC) {
-                            int widx = ch * NTAPS + t + 3;
-                            widx = widx >= wcount ? widx - wcount : widx;
-                            xw[t % 3] = wx4[(size_t)min(widx, wcount - 1) * 4 * XC];
+                            const int xb = (t + 3) * 4 * XC * 16;   // bytes from the chunk's first tap
+                            xw[t % 3] = *reinterpret_cast<const f32x4*>(wxs + voffx[xb >> 12] + (xb & 4095));
                         }
                         if (!PING) {
                             if (nt < NTAPS && !(N16_KNOCK & 4)) {
@@ -949,11 +1048,8 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
                             }
                             __builtin_amdgcn_sched_barrier(0);
                         }
-                        if (!(N16_KNOCK & 1)) {
-                            int widx = ch * NTAPS + t + BR;
-                            widx = widx >= wcount ? widx - wcount : widx;
-                            breg[t % BR] = wpk4[(size_t)min(widx, wcount - 1) * 64];
-                        }
+                        if (!(N16_KNOCK & 1))
+                            breg[t % BR] = *reinterpret_cast<const float4*>(wsc + voff[(t + BR) >> 2] + ((t + BR) & 3) * 1024);
                         if (!PING && nt < NTAPS && !(N16_KNOCK & 4)) {
 #pragma unroll
                             for (int tm = HT; tm < TM; ++tm) av[0][tm] = (N16_KNOCK & 2) ? A4v[tid + tm * NTHREADS + (nt & 1) * 64] : A4v[aidx[tm] + noff];
@@ -1010,7 +1106,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
                         if (POOL == 0) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
-                                const int oo = ok ? rowout[mt * 16 + 4 * q + r] : -1;
+                                const int oo = ok ? ROWOUT(mt * 16 + 4 * q + r) : -1;
                                 if (oo >= 0) outb[oo + co] = x[4 * g + r];
                             }
                         } else {
@@ -1020,7 +1116,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
                             else m = (x[4 * g] + x[4 * g + 1]) + (x[4 * g + 2] + x[4 * g + 3]);
                             const float o2 = __shfl_xor(m, 16);
                             m = (POOL == 1) ? fmaxf(m, o2) : (m + o2) * 0.125f;
-                            const int oo = ok ? rowout[mt * 2 + (q >> 1)] : -1;
+                            const int oo = ok ? ROWOUT(mt * 2 + (q >> 1)) : -1;
                             if (oo >= 0 && (q & 1) == 0) outb[oo + co] = m;
                         }
                     }
@@ -1044,7 +1140,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
                         const int mt = blk * TM + tm;
                         const int row = mt * 16 + 4 * (i16 >> 2) + q;
                         const bool ok = xvalid && mt < n_mt && (nvalid == a.FB || row / a.rows_pf < nvalid);
-                        const int oo = ok ? rowout[row] : -1;
+                        const int oo = ok ? ROWOUT(row) : -1;
                         if (oo >= 0) outb[oo + cx] = th_post(mine + bx, cx, a.post);
                     }
                 }
@@ -1061,6 +1157,10 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
                clock64() - prof_t0, prof_mfma, prof_bar, prof_issue, prof_pf, prof_epi, prof_grp);
 #endif
 }
+
+#undef ROWVOX
+#undef ROWOUT
+#undef VOXSRC
 
 // ---- tile configurations ------------------------------------------------------------------------
 struct CfgDesc { int WAVES, TM, TN, NT, CI, BRES; };
@@ -1090,6 +1190,13 @@ const ConvKernel kKernels[kNumCfgs][3] = {
     CFG_ROW(8, 4, 2, 2, 16, 2), CFG_ROW(8, 4, 2, 4, 16, 2), CFG_ROW(8, 2, 1, 1, 16, 2),
     CFG_ROW(4, 4, 2, 2, 16, 2), CFG_ROW(4, 4, 2, 4, 16, 2), CFG_ROW(4, 2, 1, 1, 16, 2),
     CFG_ROW(8, 2, 1, 1, 8, 2), CFG_ROW(8, 2, 2, 2, 8, 2),
+};
+
+// compile-time staged row geometry (Hp = Wp) for the TIMED layers after the first: 3x3x3, stride 1
+struct MfmaGeo { int cfg, pool, geo; ConvKernel k; };
+const MfmaGeo kMfmaGeo[] = {
+    {9, 0, 7, k_conv_mfma<4, 4, 2, 4, 16, 2, 0, 7>},     // 5^3 volumes, two frames per workgroup
+    {5, 1, 12, k_conv_mfma<8, 4, 2, 2, 16, 2, 1, 12>},   // 10^3 + 2^3 max-pool
 };
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -1186,9 +1293,19 @@ static bool plan_with_cfg(int cfg, size_t lds_limit, bool whole_frames_only, con
 // ---- narrow-output (Cout <= 16) kernel: planning, packing, launch ------------------------------------------
 namespace {
 struct N16Cfg { int WAVES, TM; };
-const N16Cfg kN16[] = {{8, 8}, {4, 4}, {4, 4}};   // [2] = {4,4} with 4 VALU side channels (Cout 17..20)
+// [2] = {4,4} with 4 side channels on 4x4x1 MFMA blocks (Cout 17..20)
+const N16Cfg kN16[] = {{8, 8}, {4, 4}, {4, 4}};
+constexpr int kNumN16 = 3;
 typedef void (*ConvKernelN16)(const ConvMfmaArgs);
-const ConvKernelN16 kN16Kernels[3][3] = {
+// compile-time staged row geometry (Hp = Wp) for the shapes the DenseCPD / TIMED topologies use, unpooled
+struct N16Geo { int variant, geo; ConvKernelN16 k; };
+const N16Geo kN16Geo[] = {
+    {0, 12, k_conv_n16<8, 8, 0, 0, 12>},
+    {1, 7, k_conv_n16<4, 4, 0, 0, 7>},
+    {2, 7, k_conv_n16<4, 4, 0, 4, 7>},
+    {1, 4, k_conv_n16<4, 4, 0, 0, 4>},
+};
+const ConvKernelN16 kN16Kernels[kNumN16][3] = {
     {k_conv_n16<8, 8, 0>, k_conv_n16<8, 8, 1>, k_conv_n16<8, 8, 2>},
     {k_conv_n16<4, 4, 0>, k_conv_n16<4, 4, 1>, k_conv_n16<4, 4, 2>},
     {k_conv_n16<4, 4, 0, 4>, nullptr, nullptr},
@@ -1203,30 +1320,29 @@ bool plan_n16(int variant, size_t lds_limit, const TView& in, const TView& oc, c
     p->Wc = pool ? (oc.W / 2) * 2 : oc.W;
     p->Hp = p->Hc + 2; p->Wp = p->Wc + 2;
     auto rows_for = [&](int zb) { return round_up(pool ? 8 * ((zb / 2) * (p->Hc / 2) * (p->Wc / 2)) : zb * p->Hc * p->Wc, 16); };
-    auto tab_bytes = [&](int fb, int zb) {
-        const size_t nvox = (size_t)fb * (zb + 2) * p->Hp * p->Wp;
-        const int nrows = fb * rows_for(zb);
-        return (size_t)nrows * 4 + (size_t)(pool ? nrows / 8 : nrows) * 4 + nvox * 4;
-    };
-    auto lds_for = [&](int fb, int zb) { return (size_t)fb * (zb + 2) * p->Hp * p->Wp * p->CS * 4 + tab_bytes(fb, zb); };
+    // the row / voxel tables live in the 4 spare floats of every staged voxel (CS = 20): the image is all the LDS there is
+    auto lds_for = [&](int fb, int zb) { return (size_t)fb * (zb + 2) * p->Hp * p->Wp * p->CS * 4; };
     const int max_mt = c.WAVES * c.TM;
-    if (lds_for(1, p->Dc) > lds_limit) return false;              // whole frames only
-    if (p->nchunks > 1 && rows_for(p->Dc) / 16 > max_mt) return false;
     int FB = 1;
+    const int ZB = p->Dc, nzb = 1;                                   // whole frames only (see the kernel on z slabs)
+    if (lds_for(1, p->Dc) > lds_limit) return false;
+    if (p->nchunks > 1 && rows_for(p->Dc) / 16 > max_mt) return false;
     while (FB < 32 && lds_for(FB + 1, p->Dc) <= lds_limit && (FB + 1) * rows_for(p->Dc) / 16 <= max_mt) ++FB;
-    p->FB = FB; p->ZB = p->Dc; p->nzb = 1; p->Zp = p->Dc + 2;
-    p->rows_pf = rows_for(p->Dc);
-    p->lds_bytes = lds_for(FB, p->Dc);
-    p->tab_off = p->lds_bytes - tab_bytes(FB, p->Dc);
+    p->FB = FB; p->ZB = ZB; p->nzb = nzb; p->Zp = ZB + 2;
+    p->rows_pf = rows_for(ZB);
+    p->lds_bytes = lds_for(FB, ZB);
+    p->tab_off = 0;
+    if ((size_t)FB * p->rows_pf > (size_t)FB * p->Zp * p->Hp * p->Wp) return false;   // tables ride in the image: rows <= staged voxels
     const int xc = variant == 2 ? 4 : 0;   // VALU side channels
     if (xc && pool) return false;
     p->BN = 16 + xc;
-    p->wpk_floats = (size_t)p->nchunks * 27 * 64 * 4 + (size_t)p->nchunks * 27 * 4 * xc * 4;
-    p->exec_flops = 2.0 * (double)p->rows_pf * 16.0 * (double)(p->nchunks * 16) * 27;   // MFMA only
+    // both images carry the first taps once more at the end (9 resp. 3: the ring depths), so the kernel's refill index never wraps
+    p->wpk_floats = ((size_t)p->nchunks * 27 + 9) * 64 * 4 + (xc ? ((size_t)p->nchunks * 27 + 3) * 4 * xc * 4 : 0);
+    p->exec_flops = 2.0 * (double)p->rows_pf * p->nzb * 16.0 * (double)(p->nchunks * 16) * 27;   // MFMA only
     if ((int64_t)FB * oc.fs > 0x7fffffffLL || (int64_t)FB * in.D * in.H * in.W * std::max(in.cs, in.C) > 0x7fffffffLL) return false;
     char buf[224];
-    snprintf(buf, sizeof buf, "conv_n16<w%d,tm%d,pool%d%s> FB%d rows%d lds%zuK (16x16x4 MFMA, weight ring%s) [k_conv_n16<%d,%d,%d%s>]",
-             c.WAVES, c.TM, pool, xc ? ",xc4" : "", FB, p->rows_pf, p->lds_bytes / 1024,
+    snprintf(buf, sizeof buf, "conv_n16<w%d,tm%d,pool%d%s> FB%d ZB%d/%d rows%d lds%zuK (16x16x4 MFMA, weight ring%s) [k_conv_n16<%d,%d,%d%s>]",
+             c.WAVES, c.TM, pool, xc ? ",xc4" : "", FB, ZB, p->Dc, p->rows_pf, p->lds_bytes / 1024,
              xc ? ", channels 16.. on 4x4x1 MFMA blocks" : "", c.WAVES, c.TM, pool, xc ? ",4" : "");
     p->label = buf;
     return true;
@@ -1280,9 +1396,10 @@ void conv_mfma_pack_weights(const ConvMfmaPlan& p, const ConvGeom& g, int Cin, i
                             const int ci = ch * 16 + 4 * q + e;
                             if (ci < Cin) dst[((((size_t)ch * ntaps + t) * 4 + q) * 16 + j) * 4 + e] = w[((size_t)t * Cin + ci) * Cout + j];
                         }
-        // VALU side channels (BN = 16 + xc): [chunk][tap][q][c][e] appended after the MFMA image
+        std::memcpy(dst + (size_t)p.nchunks * ntaps * 256, dst, (size_t)9 * 256 * sizeof(float));   // ring run-on: taps 0..8 again
+        // side channels (BN = 16 + xc): [chunk][tap][q][c][e] appended after the MFMA image
         const int xc = p.BN - 16;
-        float* wx = dst + (size_t)p.nchunks * ntaps * 256;
+        float* wx = dst + ((size_t)p.nchunks * ntaps + 9) * 256;
         for (int ch = 0; ch < p.nchunks; ++ch)
             for (int t = 0; t < ntaps; ++t)
                 for (int q = 0; q < 4; ++q)
@@ -1291,6 +1408,7 @@ void conv_mfma_pack_weights(const ConvMfmaPlan& p, const ConvGeom& g, int Cin, i
                             const int ci = ch * 16 + 4 * q + e, co = 16 + c;
                             if (ci < Cin && co < Cout) wx[((((size_t)ch * ntaps + t) * 4 + q) * xc + c) * 4 + e] = w[((size_t)t * Cin + ci) * Cout + co];
                         }
+        if (xc) std::memcpy(wx + (size_t)p.nchunks * ntaps * 4 * xc * 4, wx, (size_t)3 * 4 * xc * 4 * sizeof(float));
         return;
     }
     if (p.bres == 2) {
@@ -1332,7 +1450,7 @@ void conv_mfma_pack_weights(const ConvMfmaPlan& p, const ConvGeom& g, int Cin, i
 
 int launch_conv_mfma(hipStream_t s, int64_t n, const ConvMfmaPlan& p, TView in, TView out, ConvGeom g, int Cin, int Cout,
                      const float* wpk, const float* bias, PreOp pre, PostOps post) {
-    const bool n16 = p.cfg >= 200 && p.cfg < 203;
+    const bool n16 = p.cfg >= 200 && p.cfg < 200 + kNumN16;
     if (!n16 && (p.cfg < 0 || p.cfg >= kNumCfgs)) TH_FAIL(TH_EINVAL, "conv_mfma: bad plan");
     const CfgDesc c16 = {n16 ? kN16[p.cfg - 200].WAVES : 0, 0, 0, 0, 16, 3};
     const CfgDesc& c = n16 ? c16 : kCfgs[p.cfg];
@@ -1351,7 +1469,7 @@ int launch_conv_mfma(hipStream_t s, int64_t n, const ConvMfmaPlan& p, TView in, 
     { static const bool nozm = getenv("TH_CONV_NOZMAJOR") != nullptr; a.zmajor = (!nozm && !n16 && p.pool == 0 && p.bres == 2 && c.CI == 16 && g.sd == 1 && g.sh == 1 && g.sw == 1) ? 1 : 0; }
     { static const int dbg = getenv("TH_CONV_DBG") ? atoi(getenv("TH_CONV_DBG")) : 0; a.dbg = dbg; }
     a.wpk = wpk; a.Cout = Cout; a.bias = bias; a.pre = pre; a.post = post;
-    a.wx = n16 ? wpk + (size_t)p.nchunks * 27 * 256 : wpk;
+    a.wx = n16 ? wpk + ((size_t)p.nchunks * 27 + 9) * 256 : wpk;
     a.out = out.p; a.out_fs = out.fs; a.out_cs = out.cs; a.out_coff = out.coff; a.Ho = out.H; a.Wo = out.W;
     a.nframes = n;
     const int64_t groups = (n + p.FB - 1) / p.FB;
@@ -1365,12 +1483,21 @@ int launch_conv_mfma(hipStream_t s, int64_t n, const ConvMfmaPlan& p, TView in, 
         }
         int64_t resident = (int64_t)ncu * (c.WAVES == 4 ? 2 : 1);
         if (const char* e = getenv("TH_N16_RESIDENT")) resident = std::max(1, atoi(e));   // tests: force multi-trip workgroups
-        // equal trip counts: ceil(groups / ceil(groups / resident)) workgroups
-        const int64_t trips = (groups + resident - 1) / resident;
-        grid = std::max<int64_t>(1, (groups + trips - 1) / std::max<int64_t>(trips, 1));
+        // units = (frame group, slab); equal trip counts: ceil(units / ceil(units / resident)) workgroups, and a
+        // workgroup keeps its slab: the stride is a multiple of nzb
+        const int64_t units = groups * p.nzb;
+        const int64_t trips = (units + resident - 1) / resident;
+        grid = std::max<int64_t>(1, (units + trips - 1) / std::max<int64_t>(trips, 1));
+        grid = (grid + p.nzb - 1) / p.nzb * p.nzb;
     }
     if (grid > 0x7fffffffLL) TH_FAIL(TH_EINVAL, "conv_mfma: grid too large");
     ConvKernel k = n16 ? kN16Kernels[p.cfg - 200][p.pool] : kKernels[p.cfg][p.pool];
+    if (!n16 && a.ntaps == 27 && g.kd == 3 && g.kh == 3 && g.sd == 1 && g.sh == 1 && g.sw == 1 && p.Hp == p.Wp && p.CS == 20 && !getenv("TH_CONV_NOGEO"))
+        for (const MfmaGeo& ge : kMfmaGeo)
+            if (ge.cfg == p.cfg && ge.pool == p.pool && ge.geo == p.Hp) k = ge.k;
+    if (n16 && p.pool == 0 && p.Hp == p.Wp && p.CS == 20 && !getenv("TH_N16_NOGEO"))
+        for (const N16Geo& ge : kN16Geo)
+            if (ge.variant == p.cfg - 200 && ge.geo == p.Hp) k = ge.k;
     HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     static const size_t lds_pad = getenv("TH_CONV_LDSPAD") ? (size_t)atoi(getenv("TH_CONV_LDSPAD")) : 0;  // occupancy experiments
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(c.WAVES * 64), std::min(p.lds_bytes + lds_pad, kLdsLimit), s, a);

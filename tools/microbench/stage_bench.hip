@@ -4,7 +4,7 @@
 #include <cstdio>
 #include <type_traits>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-template <int LDSR, int GLB, int ORDER>
+template <int LDSR, int GLB, int ORDER, int IMM = 0>
 __global__ void __launch_bounds__(256, 2) k(float* out, const float4* __restrict__ w, int stages, int ldsz) {
     extern __shared__ float4 sm[];
     const int lane = threadIdx.x & 63;
@@ -20,15 +20,16 @@ __global__ void __launch_bounds__(256, 2) k(float* out, const float4* __restrict
     const float4* wp = w + lane;
     auto stage = [&](int s, auto CUR) {
         constexpr int cur = decltype(CUR)::value, nxt = cur ^ 1;
-        int off = (s * 29) & 4095;
-        asm volatile("" : "+s"(off));
+        // IMM: what a fully unrolled tap loop with compile-time geometry would give — offsets are instruction immediates
+        int off = IMM ? ((cur * 29 + 7) & 1023) : (s * 29) & 4095;
+        if (!IMM) asm volatile("" : "+s"(off));
         if (LDSR) {
 #pragma unroll
             for (int a = 0; a < 4; ++a) av[nxt][a] = sm[aidx[a] + off];
         }
         if (GLB) {
 #pragma unroll
-            for (int b = 0; b < 2; ++b) bv[nxt][b] = wp[(size_t)((s * 2 + b) & 1023) * 64];
+            for (int b = 0; b < 2; ++b) bv[nxt][b] = IMM ? wp[(cur * 2 + b) * 64] : wp[(size_t)((s * 2 + b) & 1023) * 64];
         }
         __builtin_amdgcn_sched_barrier(0);
         auto mf = [&](int q, int a, int b) {
@@ -93,5 +94,7 @@ int main() {
                run(k<0, 0, 0>, wgs, st, d, w, ldsz), run(k<1, 1, 0>, wgs, st, d, w, ldsz), run(k<0, 0, 1>, wgs, st, d, w, ldsz),
                run(k<1, 1, 1>, wgs, st, d, w, ldsz), run(k<0, 0, 2>, wgs, st, d, w, ldsz), run(k<1, 1, 2>, wgs, st, d, w, ldsz));
     }
+    printf("wgs=512 q-major, +lds+glb with immediate offsets (no address arithmetic): %.1f TF\n", run(k<1, 1, 0, 1>, 512, st, d, w, ldsz));
+    printf("wgs=512 q-major, +lds only: runtime offsets %.1f, immediates %.1f TF\n", run(k<1, 0, 0, 0>, 512, st, d, w, ldsz), run(k<1, 0, 0, 1>, 512, st, d, w, ldsz));
     return 0;
 }
