@@ -57,6 +57,7 @@ struct ConvMfmaArgs {
     int64_t nframes;
     const float* wx;   // k_conv_n16 XC > 0: weights of output channels 16..16+XC-1, [chunk][tap][q][c][4]
     int sd, sh, sw;    // convolution stride (k_conv_mfma only; 1 elsewhere)
+    int geo_compact;   // k_conv_mfma GEO kernels: chunks after the first re-stage real voxels only (see the staging loop)
 };
 
 // GEO > 0 (streamed 16-channel variants, 3x3x3, stride 1): Hp = Wp = GEO at compile time; see the tap loop.
@@ -220,6 +221,45 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
                 const int nvec = nvox * CI4;
                 const float* inb = a.in + f0 * a.in_fs + a.in_coff + ch * CI;
                 const bool has_pre = a.pre.scale || a.pre.act != ACT_LINEAR;
+                if (GEO > 0 && ch > 0 && a.geo_compact) {
+                    // Chunks after the first: only voxels that exist are re-staged.  The halo (42 % of a 12^3 image, 64 % of
+                    // two 7^3 ones) was zeroed by chunk 0's pass and nothing writes it until the epilogue.  geo_compact
+                    // (host): 'same' padding, the whole frame in one brick, Hin = Win = GEO - 2, float4-aligned full chunks
+                    // — so real voxel rr of a frame is input voxel rr, and its staged position follows from constant divisions.
+                    constexpr int N = GEO - 2;
+                    const int per_frame = a.Din * N * N;
+                    const int nfv = (int)min((int64_t)a.FB, a.nframes - f0);
+                    const int nreal4 = nfv * per_frame * CI4;
+                    for (int base = tid; base < nreal4; base += NTHREADS * U) {
+                        float4 val[U];
+                        int dst[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const int i = min(base + u * NTHREADS, nreal4 - 1);
+                            const int r = i / CI4, g = i % CI4;
+                            const int f = r / per_frame, rr = r - f * per_frame;
+                            const int z = rr / (N * N), y = (rr / N) % N, x = rr % N;
+                            dst[u] = (((f * a.Zp + z + 1) * GEO + y + 1) * GEO + x + 1) * CS4 + g;
+                            val[u] = *reinterpret_cast<const float4*>(inb + f * a.in_fs + rr * a.in_cs + g * 4);
+                        }
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            if (base + u * NTHREADS >= nreal4) continue;
+                            if (has_pre) {
+                                const int c0 = ch * CI + (dst[u] % CS4) * 4;
+                                float e[4] = {val[u].x, val[u].y, val[u].z, val[u].w};
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    float x = e[k];
+                                    if (a.pre.scale) x = fmaf(x, a.pre.scale[c0 + k], a.pre.shift[c0 + k]);
+                                    e[k] = th_act(x, a.pre.act, a.pre.alpha);
+                                }
+                                val[u] = make_float4(e[0], e[1], e[2], e[3]);
+                            }
+                            A4[dst[u]] = val[u];
+                        }
+                    }
+                } else
                 for (int base = tid; base < nvec; base += NTHREADS * U) {
                     int off[U];
                     float4 val[U];
@@ -1494,7 +1534,11 @@ int launch_conv_mfma(hipStream_t s, int64_t n, const ConvMfmaPlan& p, TView in, 
     ConvKernel k = n16 ? kN16Kernels[p.cfg - 200][p.pool] : kKernels[p.cfg][p.pool];
     if (!n16 && a.ntaps == 27 && g.kd == 3 && g.kh == 3 && g.sd == 1 && g.sh == 1 && g.sw == 1 && p.Hp == p.Wp && p.CS == 20 && !getenv("TH_CONV_NOGEO"))
         for (const MfmaGeo& ge : kMfmaGeo)
-            if (ge.cfg == p.cfg && ge.pool == p.pool && ge.geo == p.Hp) k = ge.k;
+            if (ge.cfg == p.cfg && ge.pool == p.pool && ge.geo == p.Hp) {
+                k = ge.k;
+                a.geo_compact = (g.pz == 1 && g.py == 1 && g.px == 1 && p.nzb == 1 && p.Zp == in.D + 2 && in.H == ge.geo - 2 && in.W == ge.geo - 2 &&
+                                 a.vec_ok && Cin % 16 == 0 && !getenv("TH_CONV_NOCOMPACT")) ? 1 : 0;
+            }
     if (n16 && p.pool == 0 && p.Hp == p.Wp && p.CS == 20 && !getenv("TH_N16_NOGEO"))
         for (const N16Geo& ge : kN16Geo)
             if (ge.variant == p.cfg - 200 && ge.geo == p.Hp) k = ge.k;
