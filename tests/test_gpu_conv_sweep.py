@@ -219,3 +219,29 @@ def test_nan_and_extreme_inputs_propagate_like_numpy(gpu):
     ok = np.isfinite(want)
     np.testing.assert_allclose(got[ok], want[ok], rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(want[ok]).max())))
     assert np.array_equal(got[0], engine.HipFrameModel.from_keras(cfg, weights).predict(fr[:1])[0])  # frame independence
+
+
+@pytest.mark.parametrize("side,cmid,cout,pool,n,tag", [
+    (5, 64, 128, None, 5, ",7>]"),      # k_conv_mfma<4,4,2,4,16,2,0,7>: two frames per workgroup, ragged last group
+    (10, 32, 64, "max", 3, ",12>]"),    # k_conv_mfma<8,4,2,2,16,2,1,12>
+    (10, 48, 16, None, 3, ",12>]"),     # k_conv_n16<8,8,0,0,12>
+    (5, 48, 16, None, 5, ",7>]"),       # k_conv_n16<4,4,0,0,7>
+    (5, 64, 20, None, 3, ",7>]"),       # k_conv_n16<4,4,0,4,7> (20-class head)
+    (2, 32, 16, None, 19, ",4>]"),      # k_conv_n16<4,4,0,0,4>, 16 frames per workgroup + 3
+])
+def test_compile_time_geometry_kernels_with_preactivation(gpu, side, cmid, cout, pool, n, tag):
+    """The instantiations with the staged row geometry fixed at compile time (tap offsets as ds_read immediates; chunks
+    after the first re-stage real voxels only): BN -> ReLU in front of the convolution, several Cin chunks, ragged last
+    workgroup; the plan label must name the specialised kernel."""
+    def build(b, x):
+        x = b.conv3d(x, cmid, 1, padding="same")
+        y = b.relu(b.batchnorm(x))
+        y = b.conv3d(y, cout, 3, padding="same")
+        y = b.batchnorm(b.elu(y))
+        return b.maxpool(y, 2) if pool == "max" else y
+
+    cfg, weights = _net((side,) * 3, 8, build, seed=side * 100 + cout)
+    frames = _frames(n, (side,) * 3, 8, seed=n)
+    labels = _check(cfg, weights, frames)
+    assert any(l.endswith(tag) and "conv_" in l for l in labels), labels
+    _check(cfg, weights, frames, chunk=3)

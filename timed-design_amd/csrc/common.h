@@ -107,6 +107,7 @@ struct ConvMfmaPlan {
     size_t tab_off = 0;           // byte offset of the row tables inside the LDS allocation
     size_t wpk_floats = 0;        // size of the prepacked weight image
     double exec_flops = 0;        // MFMA FLOPs actually issued per frame
+    int geo = 0;                  // > 0: the kernel instantiation with Hp = Wp = geo at compile time (tap offsets as immediates)
     std::string label;
 };
 // choose a tiling for this convolution; returns false when the MFMA kernel does not apply

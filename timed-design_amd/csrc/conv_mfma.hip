@@ -1321,10 +1321,15 @@ static bool plan_with_cfg(int cfg, size_t lds_limit, bool whole_frames_only, con
         if (full > 0) p->exec_flops *= issued / full;
     }
     if ((int64_t)FB * oc.fs > 0x7fffffffLL || (int64_t)FB * in.D * in.H * in.W * std::max(in.cs, in.C) > 0x7fffffffLL) return false;
-    char buf[224];
-    snprintf(buf, sizeof buf, "conv_mfma<w%d,%dx%d,nt%d,ci%d,%s,pool%d> FB%d ZB%d/%d rows%d lds%zuK [k_conv_mfma<%d,%d,%d,%d,%d,%d,%d>]",
+    p->geo = 0;
+    if (g.kd == 3 && g.kh == 3 && g.kw == 3 && g.sd == 1 && g.sh == 1 && g.sw == 1 && p->Hp == p->Wp && p->CS == 20 && !getenv("TH_CONV_NOGEO"))
+        for (const MfmaGeo& ge : kMfmaGeo)
+            if (ge.cfg == cfg && ge.pool == pool && ge.geo == p->Hp) p->geo = ge.geo;
+    char buf[224], geo[16];
+    snprintf(geo, sizeof geo, ",%d", p->geo);   // the full instantiation, as rocprofv3 prints it
+    snprintf(buf, sizeof buf, "conv_mfma<w%d,%dx%d,nt%d,ci%d,%s,pool%d> FB%d ZB%d/%d rows%d lds%zuK [k_conv_mfma<%d,%d,%d,%d,%d,%d,%d%s>]",
              c.WAVES, c.TM, c.TN, c.NT, c.CI, c.BRES == 2 ? "stream" : (c.BRES ? "res" : "dbuf"), pool, FB, ZB, p->Dc, p->rows_pf,
-             p->lds_bytes / 1024, c.WAVES, c.TM, c.TN, c.NT, c.CI, c.BRES, pool);
+             p->lds_bytes / 1024, c.WAVES, c.TM, c.TN, c.NT, c.CI, c.BRES, pool, geo);
     p->label = buf;
     return true;
 }
@@ -1380,10 +1385,15 @@ bool plan_n16(int variant, size_t lds_limit, const TView& in, const TView& oc, c
     p->wpk_floats = ((size_t)p->nchunks * 27 + 9) * 64 * 4 + (xc ? ((size_t)p->nchunks * 27 + 3) * 4 * xc * 4 : 0);
     p->exec_flops = 2.0 * (double)p->rows_pf * p->nzb * 16.0 * (double)(p->nchunks * 16) * 27;   // MFMA only
     if ((int64_t)FB * oc.fs > 0x7fffffffLL || (int64_t)FB * in.D * in.H * in.W * std::max(in.cs, in.C) > 0x7fffffffLL) return false;
-    char buf[224];
-    snprintf(buf, sizeof buf, "conv_n16<w%d,tm%d,pool%d%s> FB%d ZB%d/%d rows%d lds%zuK (16x16x4 MFMA, weight ring%s) [k_conv_n16<%d,%d,%d%s>]",
+    p->geo = 0;
+    if (pool == 0 && p->Hp == p->Wp && !getenv("TH_N16_NOGEO"))
+        for (const N16Geo& ge : kN16Geo)
+            if (ge.variant == variant && ge.geo == p->Hp) p->geo = ge.geo;
+    char buf[224], geo[24];
+    snprintf(geo, sizeof geo, "%s,%d", xc ? "" : ",0", p->geo);   // the full instantiation, as rocprofv3 prints it
+    snprintf(buf, sizeof buf, "conv_n16<w%d,tm%d,pool%d%s> FB%d ZB%d/%d rows%d lds%zuK (16x16x4 MFMA, weight ring%s) [k_conv_n16<%d,%d,%d%s%s>]",
              c.WAVES, c.TM, pool, xc ? ",xc4" : "", FB, ZB, p->Dc, p->rows_pf, p->lds_bytes / 1024,
-             xc ? ", channels 16.. on 4x4x1 MFMA blocks" : "", c.WAVES, c.TM, pool, xc ? ",4" : "");
+             xc ? ", channels 16.. on 4x4x1 MFMA blocks" : "", c.WAVES, c.TM, pool, xc ? ",4" : "", geo);
     p->label = buf;
     return true;
 }
@@ -1532,16 +1542,16 @@ int launch_conv_mfma(hipStream_t s, int64_t n, const ConvMfmaPlan& p, TView in, 
     }
     if (grid > 0x7fffffffLL) TH_FAIL(TH_EINVAL, "conv_mfma: grid too large");
     ConvKernel k = n16 ? kN16Kernels[p.cfg - 200][p.pool] : kKernels[p.cfg][p.pool];
-    if (!n16 && a.ntaps == 27 && g.kd == 3 && g.kh == 3 && g.sd == 1 && g.sh == 1 && g.sw == 1 && p.Hp == p.Wp && p.CS == 20 && !getenv("TH_CONV_NOGEO"))
+    if (!n16 && p.geo)
         for (const MfmaGeo& ge : kMfmaGeo)
-            if (ge.cfg == p.cfg && ge.pool == p.pool && ge.geo == p.Hp) {
+            if (ge.cfg == p.cfg && ge.pool == p.pool && ge.geo == p.geo) {
                 k = ge.k;
                 a.geo_compact = (g.pz == 1 && g.py == 1 && g.px == 1 && p.nzb == 1 && p.Zp == in.D + 2 && in.H == ge.geo - 2 && in.W == ge.geo - 2 &&
                                  a.vec_ok && Cin % 16 == 0 && !getenv("TH_CONV_NOCOMPACT")) ? 1 : 0;
             }
-    if (n16 && p.pool == 0 && p.Hp == p.Wp && p.CS == 20 && !getenv("TH_N16_NOGEO"))
+    if (n16 && p.geo)
         for (const N16Geo& ge : kN16Geo)
-            if (ge.variant == p.cfg - 200 && ge.geo == p.Hp) k = ge.k;
+            if (ge.variant == p.cfg - 200 && ge.geo == p.geo) k = ge.k;
     HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     static const size_t lds_pad = getenv("TH_CONV_LDSPAD") ? (size_t)atoi(getenv("TH_CONV_LDSPAD")) : 0;  // occupancy experiments
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(c.WAVES * 64), std::min(p.lds_bytes + lds_pad, kLdsLimit), s, a);
