@@ -627,7 +627,40 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
                 }
             }
         } else {
-            // big per-wave tiles: each 32x32 accumulator tile goes registers -> a per-wave LDS scratch
+            // big per-wave tiles.  Max-pool in front of a monotone chain (TIMED block 2) needs no scratch at all:
+            // a lane holds pool-mates 0-3 (h = 0) or 4-7 (h = 1) of 4 pooled voxels, so 3 max + one cross-half
+            // exchange per voxel leave the pooled sums in registers, and the chain runs on 2 values per tile —
+            // no LDS round trip, no workgroup barrier in front of the epilogue.
+            const bool reg_pool = POOL == 1 && a.post.monotone;
+            if (reg_pool) {
+                if (active) {
+                    float* outb = a.out + f0 * a.out_fs + a.out_coff;
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) {
+                        const int mt = a.zmajor ? mb + tm * nmb : mb * TM + tm;
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn) {
+                            const int co = nb * BN + (nbw * TN + tn) * 32 + j;
+                            const bool cok = co < a.Cout && mt < a.n_mtiles;
+                            const int cc = co < a.Cout ? co : 0;
+                            const float bv = a.bias ? a.bias[cc] : 0.f;
+                            float m[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float mq = fmaxf(fmaxf(acc[tm][tn][4 * q], acc[tm][tn][4 * q + 1]), fmaxf(acc[tm][tn][4 * q + 2], acc[tm][tn][4 * q + 3]));
+                                m[q] = fmaxf(mq, __shfl_xor(mq, 32));
+                            }
+                            // lane half h finishes pooled voxels 2h and 2h + 1 (max commutes with the bias add bit for bit)
+                            float v0 = (h ? m[2] : m[0]) + bv, v1 = (h ? m[3] : m[1]) + bv;
+                            th_post2(v0, v1, cc, a.post);
+                            const int o0 = cok ? rowout[mt * 4 + 2 * h] : -1, o1 = cok ? rowout[mt * 4 + 2 * h + 1] : -1;
+                            if (o0 >= 0) outb[o0 + co] = v0;
+                            if (o1 >= 0) outb[o1 + co] = v1;
+                        }
+                    }
+                }
+            } else {
+            // otherwise each 32x32 accumulator tile goes registers -> a per-wave LDS scratch
             // tile -> a compact runtime loop (keeps the activation switch out of a 128-way unroll, so
             // the accumulators stay in VGPRs).  The scratch aliases the A/B staging area (hence the
             // barrier, and hence A is re-staged every round in this mode).
@@ -693,6 +726,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
                         __builtin_amdgcn_wave_barrier();
                     }
                 }
+            }
             }
         }
 #if CONV_PROF
