@@ -88,7 +88,9 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
     const int z0 = zb * a.ZB;
 
     // ---- LDS carve-up ---------------------------------------------------------------------------
-    const int nvox = a.FB * a.Zp * a.Hp * a.Wp;
+    // GEO kernels: 3x3x3, stride 1, Hp = Wp = GEO and Hc = Wc = GEO - 2, so the table arithmetic divides by constants
+    const int gHp = GEO ? GEO : a.Hp, gWp = GEO ? GEO : a.Wp, gHc = GEO ? GEO - 2 : a.Hc, gWc = GEO ? GEO - 2 : a.Wc;
+    const int nvox = a.FB * a.Zp * gHp * gWp;
     float4* A4 = smem;
     float4* B4 = A4 + (size_t)nvox * CS4;
     const int bslab4 = BN * CS4;  // one tap's weights
@@ -97,12 +99,12 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
     int* tapoff = rowout + (POOL ? a.nrows / 8 : a.nrows);  // staged-voxel offset of every tap
     for (int t = tid; t < a.ntaps; t += NTHREADS) {
         const int dz = t / (a.kh * a.kw), r2 = t - dz * (a.kh * a.kw), dy = r2 / a.kw, dx = r2 - dy * a.kw;
-        tapoff[t] = (dz * a.Hp + dy) * a.Wp + dx;
+        tapoff[t] = (dz * gHp + dy) * gWp + dx;
     }
     int* voxsrc = tapoff + a.ntaps;  // staged voxel -> source offset (floats, relative to frame f0) or -1
     for (int v = tid; v < nvox; v += NTHREADS) {
-        const int xl = v % a.Wp; int t = v / a.Wp;
-        const int yl = t % a.Hp; t /= a.Hp;
+        const int xl = v % gWp; int t = v / gWp;
+        const int yl = t % gHp; t /= gHp;
         const int zl = t % a.Zp; const int f = t / a.Zp;
         const int zi = z0 * a.sd + zl - a.pz, yi = yl - a.py, xi = xl - a.px;   // staged plane zl of the brick = input plane z0*sd + zl - pz
         const bool ok = (f0 + f) < a.nframes && zi >= 0 && zi < a.Din && yi >= 0 && yi < a.Hin && xi >= 0 && xi < a.Win;
@@ -115,7 +117,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
         int mask = 0;
         if (POOL == 0 && a.zmajor) {
             const int ZBv = min(a.ZB, a.Dc - z0);
-            const int fhw = a.FB * a.Hc * a.Wc, total = ZBv * fhw;
+            const int fhw = a.FB * gHc * gWc, total = ZBv * fhw;
             if (mt * 32 >= total) mask = 0xff;
             else {
                 const int zlo = z0 + (mt * 32) / fhw, zhi = z0 + min(mt * 32 + 31, total - 1) / fhw;
@@ -134,7 +136,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
             bool fok = (f0 + f) < a.nframes;
             int vox = 0, oo = -1;
             if (POOL == 0) {
-                const int hw = a.Hc * a.Wc;
+                const int hw = gHc * gWc;
                 bool rok = q < ZBv * hw;
                 if (a.zmajor) {
                     // rows ordered (z, frame, y, x): a 32-row tile then usually lies inside ONE z-plane, and
@@ -147,18 +149,18 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
                     fok = (f0 + f) < a.nframes;
                 }
                 if (fok && rok) {
-                    const int zl = q / hw, rem = q - zl * hw, y = rem / a.Wc, x = rem - y * a.Wc;
-                    vox = ((f * a.Zp + zl * a.sd) * a.Hp + y * a.sh) * a.Wp + x * a.sw;   // window origin of output voxel (zl, y, x)
+                    const int zl = q / hw, rem = q - zl * hw, y = rem / gWc, x = rem - y * gWc;
+                    vox = ((f * a.Zp + zl * a.sd) * gHp + y * a.sh) * gWp + x * a.sw;   // window origin of output voxel (zl, y, x)
                     oo = f * (int)a.out_fs + (((z0 + zl) * a.Ho + y) * a.Wo + x) * a.out_cs;
                 }
                 rowout[r] = oo;
             } else {
                 const int pq = q >> 3, mate = q & 7;
-                const int PH = a.Hc >> 1, PW = a.Wc >> 1;
+                const int PH = gHc >> 1, PW = gWc >> 1;
                 if (fok && pq < (ZBv >> 1) * PH * PW) {
                     const int pzz = pq / (PH * PW), rem = pq - pzz * (PH * PW), pyy = rem / PW, pxx = rem - pyy * PW;
                     const int zl = 2 * pzz + (mate >> 2), y = 2 * pyy + ((mate >> 1) & 1), x = 2 * pxx + (mate & 1);
-                    vox = ((f * a.Zp + zl) * a.Hp + y) * a.Wp + x;
+                    vox = ((f * a.Zp + zl) * gHp + y) * gWp + x;
                     oo = f * (int)a.out_fs + ((((z0 >> 1) + pzz) * a.Ho + pyy) * a.Wo + pxx) * a.out_cs;
                 }
                 if (mate == 0) rowout[r >> 3] = oo;
@@ -221,15 +223,26 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
                 const int nvec = nvox * CI4;
                 const float* inb = a.in + f0 * a.in_fs + a.in_coff + ch * CI;
                 const bool has_pre = a.pre.scale || a.pre.act != ACT_LINEAR;
-                if (GEO > 0 && ch > 0 && a.geo_compact) {
-                    // Chunks after the first: only voxels that exist are re-staged.  The halo (42 % of a 12^3 image, 64 % of
-                    // two 7^3 ones) was zeroed by chunk 0's pass and nothing writes it until the epilogue.  geo_compact
-                    // (host): 'same' padding, the whole frame in one brick, Hin = Win = GEO - 2, float4-aligned full chunks
-                    // — so real voxel rr of a frame is input voxel rr, and its staged position follows from constant divisions.
+                if (GEO > 0 && a.geo_compact) {
+                    // Only voxels that exist are staged from memory: real voxel rr of a frame is input voxel rr, and its
+                    // staged position follows from constant divisions.  The halo (42 % of a 12^3 image, 64 % of two 7^3
+                    // ones) is zeroed with the first chunk — plain LDS writes, no table lookups, no loads — and nothing
+                    // writes it again until an LDS-scratch epilogue.  geo_compact (host): 'same' padding, the whole frame in
+                    // one brick, Hin = Win = GEO - 2, float4-aligned full chunks.
                     constexpr int N = GEO - 2;
                     const int per_frame = a.Din * N * N;
                     const int nfv = (int)min((int64_t)a.FB, a.nframes - f0);
                     const int nreal4 = nfv * per_frame * CI4;
+                    if (ch == 0) {
+                        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                        for (int v = tid; v < nvox; v += NTHREADS) {
+                            const int x = v % GEO, t = v / GEO, y = t % GEO, t2 = t / GEO, z = t2 % a.Zp, f = t2 / a.Zp;
+                            if (x == 0 || x == GEO - 1 || y == 0 || y == GEO - 1 || z == 0 || z == a.Zp - 1 || f >= nfv) {
+#pragma unroll
+                                for (int g = 0; g < CI4; ++g) A4[(size_t)v * CS4 + g] = zero4;
+                            }
+                        }
+                    }
                     for (int base = tid; base < nreal4; base += NTHREADS * U) {
                         float4 val[U];
                         int dst[U];
