@@ -55,7 +55,10 @@ __device__ __forceinline__ float load_elem(const void* base, int dtype, int64_t 
 
 // PMODE: 0 no pool, 1 max 2x2x2, 2 avg 2x2x2, 3 max 2x2x2 taken BEFORE the epilogue chain (planner proved the chain
 // monotone non-decreasing: PostOps::monotone)
-template <int WAVES, int NST, int PMODE>
+// GEO > 0: Hp = Wp = GEO, Hc = Wc = GEO - 2 at compile time (3x3x3 'same' on cubic frames).  A workgroup lives for only
+// ~13 us of MFMAs per wave, and building its row table and decoding its 1936 staged voxels costs ~29 integer divisions
+// per thread: by run-time divisors that is ~1000 VALU instructions, by constants a tenth of that.
+template <int WAVES, int NST, int PMODE, int GEO = 0>
 __global__ void __launch_bounds__(WAVES * 64, 3) k_conv_first(const ConvFirstArgs a) {
     constexpr int POOL = PMODE == 3 ? 1 : PMODE;
     constexpr bool POOL_FIRST = PMODE == 3;
@@ -69,7 +72,8 @@ __global__ void __launch_bounds__(WAVES * 64, 3) k_conv_first(const ConvFirstArg
     const int zb = blockIdx.x % a.nzb;
     const int64_t f = blockIdx.x / a.nzb;
     const int z0 = zb * a.ZB;
-    const int nvox = a.Zp * a.Hp * a.Wp;
+    const int gHp = GEO ? GEO : a.Hp, gWp = GEO ? GEO : a.Wp, gHc = GEO ? GEO - 2 : a.Hc, gWc = GEO ? GEO - 2 : a.Wc;
+    const int nvox = a.Zp * gHp * gWp;
     // voxel record of REC = 2*NST floats; MFMA step t contracts channels (2t, 2t+1), lane half h supplies 2t+h.
     //   NST=4: [c0 c2 c4 c6 | c1 c3 c5 c7]  one ds_read_b128 at 4h
     //   NST=3: [c0 c2 | c1 c3 | c4 | c5]    ds_read_b64 at 2h + ds_read_b32 at 4+h   (24-byte records)
@@ -94,20 +98,20 @@ __global__ void __launch_bounds__(WAVES * 64, 3) k_conv_first(const ConvFirstArg
         for (int r = tid; r < a.rows; r += NTHREADS) {
             int vox = 0, oo = -1;
             if (POOL == 0) {
-                const int hw = a.Hc * a.Wc;
+                const int hw = gHc * gWc;
                 if (r < ZBv * hw) {
-                    const int zl = r / hw, rem = r - zl * hw, y = rem / a.Wc, x = rem - y * a.Wc;
-                    vox = (zl * a.Hp + y) * a.Wp + x;
+                    const int zl = r / hw, rem = r - zl * hw, y = rem / gWc, x = rem - y * gWc;
+                    vox = (zl * gHp + y) * gWp + x;
                     oo = (((z0 + zl) * a.Ho + y) * a.Wo + x) * a.out_cs;
                 }
                 rowout[r] = oo;
             } else {
                 const int pq = r >> 3, mate = r & 7;
-                const int PH = a.Hc >> 1, PW = a.Wc >> 1;
+                const int PH = gHc >> 1, PW = gWc >> 1;
                 if (pq < (ZBv >> 1) * PH * PW) {
                     const int pzz = pq / (PH * PW), rem = pq - pzz * (PH * PW), pyy = rem / PW, pxx = rem - pyy * PW;
                     const int zl = 2 * pzz + (mate >> 2), y = 2 * pyy + ((mate >> 1) & 1), x = 2 * pxx + (mate & 1);
-                    vox = (zl * a.Hp + y) * a.Wp + x;
+                    vox = (zl * gHp + y) * gWp + x;
                     oo = ((((z0 >> 1) + pzz) * a.Ho + pyy) * a.Wo + pxx) * a.out_cs;
                 }
                 if (mate == 0) rowout[r >> 3] = oo;
@@ -128,8 +132,8 @@ __global__ void __launch_bounds__(WAVES * 64, 3) k_conv_first(const ConvFirstArg
 #pragma unroll
                 for (int c = 0; c < 8; ++c) e[u][c] = 0.f;
                 const int v = vb + u * NTHREADS;
-                const int xl = v % a.Wp; int t = v / a.Wp;
-                const int yl = t % a.Hp; const int zl = t / a.Hp;
+                const int xl = v % gWp; int t = v / gWp;
+                const int yl = t % gHp; const int zl = t / gHp;
                 const int zi = z0 + zl - a.pz, yi = yl - a.py, xi = xl - a.px;
                 if (v < nvox && zi >= 0 && zi < a.Din && yi >= 0 && yi < a.Hin && xi >= 0 && xi < a.Win) {
                     const int64_t base = fbase + ((int64_t)(zi * a.Hin + yi) * a.Win + xi) * a.Cin;
@@ -183,7 +187,7 @@ __global__ void __launch_bounds__(WAVES * 64, 3) k_conv_first(const ConvFirstArg
         // fully unrolled over the 27 taps; tap t+1's LDS reads are issued before tap t's MFMAs (ping-pong
         // registers, pinned with sched_barrier) so the wave never sits on an LDS round trip
         auto fetch = [&](int dz, int dy, int dx, float (&av)[4]) {
-            const float* rec = arow + ((dz * a.Hp + dy) * a.Wp + dx) * REC;
+            const float* rec = arow + ((dz * gHp + dy) * gWp + dx) * REC;
             if (NST == 4) {
                 const float4 q = *reinterpret_cast<const float4*>(rec + 4 * h);
                 av[0] = q.x; av[1] = q.y; av[2] = q.z; av[3] = q.w;
@@ -257,6 +261,13 @@ typedef void (*FirstKernel)(const ConvFirstArgs);
 constexpr int kWaves = 4;
 #define ROW(NST) { k_conv_first<kWaves, NST, 0>, k_conv_first<kWaves, NST, 1>, k_conv_first<kWaves, NST, 2>, k_conv_first<kWaves, NST, 3> }
 const FirstKernel kFirstKernels[4][4] = {ROW(1), ROW(2), ROW(3), ROW(4)};
+// compile-time row geometry for 21^3 x 6 aposteriori frames: pooled first block (20 + 2) and unpooled 'same' (21 + 2)
+struct FirstGeo { int nst, pmode, geo; FirstKernel k; };
+const FirstGeo kFirstGeo[] = {
+    {3, 3, 22, k_conv_first<kWaves, 3, 3, 22>},
+    {3, 1, 22, k_conv_first<kWaves, 3, 1, 22>},
+    {3, 0, 23, k_conv_first<kWaves, 3, 0, 23>},
+};
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
@@ -342,7 +353,11 @@ int launch_conv_first(hipStream_t s, int64_t n, const ConvMfmaPlan& p, const voi
     if (grid > 0x7fffffffLL) TH_FAIL(TH_EINVAL, "conv_first: grid too large");
     const int nst = (Cin + 1) / 2;
     const bool no_pool_first = getenv("TH_NO_POOL_FIRST") != nullptr;   // A/B comparisons and tests
-    FirstKernel k = kFirstKernels[nst - 1][(p.pool == 1 && post.monotone && !no_pool_first) ? 3 : p.pool];
+    const int pmode = (p.pool == 1 && post.monotone && !no_pool_first) ? 3 : p.pool;
+    FirstKernel k = kFirstKernels[nst - 1][pmode];
+    if (p.Hp == p.Wp && p.Hc == p.Hp - 2 && p.Wc == p.Wp - 2 && !getenv("TH_CONV_NOGEO"))
+        for (const FirstGeo& ge : kFirstGeo)
+            if (ge.nst == nst && ge.pmode == pmode && ge.geo == p.Hp) k = ge.k;
     HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kWaves * 64), p.lds_bytes, s, a);
     hipError_t e = hipGetLastError();
