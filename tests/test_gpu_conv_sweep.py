@@ -56,6 +56,10 @@ SWEEP = [
     ((7, 5, 9), 18, 100, 1, "same", "max", "elu_bn", 3),        # 1x1x1: Cin % 4 != 0, 4 output tiles, max pool on odd extents
     ((5, 5, 5), 136, 48, 1, "valid", "avg", "none", 5),         # 1x1x1: K > 128 (two K passes) + avg pool (transition layer)
     ((3, 3, 3), 12, 130, 1, "same", None, "relu", 4),           # 1x1x1 with Cout > 128 -> generic MFMA kernel
+    ((8, 8, 8), 32, 64, 1, "same", None, "bn_relu", 3),         # 1x1x1, Cin % 8 == 0 -> pipelined k_conv_pw2<4,2,0>
+    ((6, 6, 6), 96, 48, 1, "valid", "avg", "none", 5),          # k_conv_pw2<16,2,2> (transition: avg pool), ragged last tile
+    ((4, 4, 4), 64, 100, 1, "same", "max", "elu_bn", 9),        # k_conv_pw2<8,4,1>, four output tiles
+    ((5, 5, 5), 56, 20, 1, "same", None, "relu", 4),            # k_conv_pw2<8,1,0>: K8 = 7 of 8 slots
     ((7, 7, 7), 6, 16, 5, "same", None, "relu", 2),             # 5x5x5 kernel (125 taps)
     ((8, 6, 7), 12, 40, (3, 1, 3), "same", None, "elu", 3),     # anisotropic kernel
     ((2, 2, 2), 96, 16, 3, "same", None, "none", 17),           # tiny volume (DenseCPD block 3)

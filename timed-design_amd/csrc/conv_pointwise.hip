@@ -40,6 +40,7 @@ struct ConvPwArgs {
     float* out; int64_t out_fs; int out_cs, out_coff, out_dense;
     unsigned nrows;     // GEMM rows: frames*V, or frames*Vo*8 when pooled
     unsigned ntiles;
+    unsigned in_bytes, out_bytes;   // k_conv_pw2: byte spans of the activation views (buffer descriptors, < 4 GiB)
 };
 
 // this lane's input row for a tile: lane j supplies GEMM row tile*32 + j (POOL: pooled voxel tile*4 + j/8, mate j%8);
@@ -189,6 +190,160 @@ __global__ void __launch_bounds__(256, NT == 4 ? 2 : (KMAX == 16 && NT == 2 ? 3 
     }
 }
 
+// ---- the same GEMM with buffer addressing and a software pipeline ----------------------------------------------
+// k_conv_pw above takes the SUM of its phases: per 4096 frames of 96 -> 64 channels at 10^3 it needs 0.90 ms where the
+// loads alone take 0.29, the MFMAs 0.36 and the epilogue 0.20 (knock-outs: 0.70 without the epilogue, 0.60 without the
+// loads, 0.36 without both).  Every wave alternates "issue loads, wait" and "MFMAs, stores"; the matrix pipe serves the
+// ready waves of a SIMD round-robin, so they finish together, reload together and wait together.  Prefetching the next
+// tile inside the wave only helps if hipcc can COUNT the memory operations in flight (gfx9 has one vmcnt for loads and
+// stores): one conditional load or store and it waits with vmcnt(0), i.e. for the prefetch and for every store of the
+// previous tile.  So here every memory instruction is unconditional — buffer loads / stores whose out-of-range lanes
+// carry an offset beyond the descriptor (the hardware returns 0 / drops the store) — the next tile's KMAX loads are
+// issued before this tile's MFMAs, and the wait in front of a tile's MFMAs is vmcnt(KMAX + 16 NT), not 0.
+// Requirements (launch_conv_pw): 16-byte aligned views, Cin % 8 == 0, one K pass (K8 <= KMAX), views under 4 GiB.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <int KMAX, int NT, int POOL>
+__global__ void __launch_bounds__(256, (NT == 4 || KMAX == 16 || (KMAX == 8 && NT == 2)) ? 2 : 3) k_conv_pw2(const ConvPwArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float4 smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int K8 = a.K8;
+    constexpr unsigned OOB = 0xffffffffu;
+
+    float4* Bs = smem;
+    float* psc = reinterpret_cast<float*>(smem + (size_t)K8 * NT * 64);
+    float* psh = psc + K8 * 8;
+    {
+        const float4* src = reinterpret_cast<const float4*>(a.wpk);
+        for (int i = tid; i < K8 * NT * 64; i += 256) Bs[i] = src[i];
+        for (int i = tid; i < K8 * 8; i += 256) {
+            psc[i] = (a.pre.scale && i < a.Cin) ? a.pre.scale[i] : 1.f;
+            psh[i] = (a.pre.shift && i < a.Cin) ? a.pre.shift[i] : 0.f;
+        }
+    }
+    __syncthreads();
+    const bool has_pre = a.pre.scale != nullptr || a.pre.act != ACT_LINEAR;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, (int)a.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)a.out_bytes, 0x00020000);
+
+    // byte offset of this lane's first float4 of a tile (OOB for rows past the end: they load zeros, are never stored)
+    auto row_off = [&](unsigned tile) -> unsigned {
+        unsigned e;   // element offset
+        if (POOL == 0) {
+            const unsigned r = tile * 32 + j;
+            if (r >= a.nrows) return OOB;
+            if (a.in_dense) e = r * (unsigned)a.in_cs;
+            else { const unsigned f = r / (unsigned)a.V; e = f * (unsigned)a.in_fs + (r - f * a.V) * (unsigned)a.in_cs; }
+        } else {
+            const unsigned p = tile * 4 + (j >> 3), m = j & 7;
+            if (p * 8 >= a.nrows) return OOB;
+            const unsigned f = p / (unsigned)a.Vo, vo = p - f * a.Vo;
+            const unsigned zo = vo / (unsigned)(a.Ho * a.Wo), rem = vo - zo * (a.Ho * a.Wo);
+            const unsigned yo = rem / (unsigned)a.Wo, xo = rem - yo * a.Wo;
+            const unsigned v = ((2 * zo + (m >> 2)) * a.H + 2 * yo + ((m >> 1) & 1)) * a.W + 2 * xo + (m & 1);
+            e = f * (unsigned)a.in_fs + v * (unsigned)a.in_cs;
+        }
+        return (e + (unsigned)a.in_coff + 4u * h) * 4u;
+    };
+    auto load_tile = [&](u32x4 (&av)[KMAX], unsigned tile) {
+        const unsigned base = row_off(tile);
+#pragma unroll
+        for (int u = 0; u < KMAX; ++u) {
+            const unsigned off = (u < K8 && base != OOB) ? base + (unsigned)u * 32u : OOB;
+            av[u] = __builtin_amdgcn_raw_buffer_load_b128(rin, off, 0, 0);
+        }
+    };
+    auto compute_store = [&](const u32x4 (&av)[KMAX], unsigned tile) {
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+#pragma unroll
+        for (int u = 0; u < KMAX; ++u) {
+            if (u < K8) {
+                const f32x4v vv = __builtin_bit_cast(f32x4v, av[u]);   // whole-vector cast (element-wise bit_cast of a vector lvalue reads .x four times)
+                float4 v = make_float4(vv.x, vv.y, vv.z, vv.w);
+                if (has_pre) {
+                    const float4 sc = *reinterpret_cast<const float4*>(psc + u * 8 + 4 * h);
+                    const float4 sh = *reinterpret_cast<const float4*>(psh + u * 8 + 4 * h);
+                    v.x = th_act(fmaf(v.x, sc.x, sh.x), a.pre.act, a.pre.alpha);
+                    v.y = th_act(fmaf(v.y, sc.y, sh.y), a.pre.act, a.pre.alpha);
+                    v.z = th_act(fmaf(v.z, sc.z, sh.z), a.pre.act, a.pre.alpha);
+                    v.w = th_act(fmaf(v.w, sc.w, sh.w), a.pre.act, a.pre.alpha);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float4 b = Bs[(u * NT + nt) * 64 + lane];
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, b.x, acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, b.y, acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.z, b.z, acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.w, b.w, acc[nt], 0, 0, 0);
+                }
+            }
+        }
+        // epilogue: lane holds output channel (nt*32 + j) of rows (r&3) + 8*(r>>2) + 4h; every store is issued, masked by offset
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int co = nt * 32 + j;
+            const bool cok = co < a.Cout;
+            const int cc = cok ? co : 0;
+            float x[16];
+            const float bv = a.bias ? a.bias[cc] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[r] = acc[nt][r] + bv;
+            th_post16(x, cc, a.post);
+            if (POOL == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned row = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    unsigned e;
+                    if (a.out_dense) e = row * (unsigned)a.out_cs;
+                    else { const unsigned f = row / (unsigned)a.V; e = f * (unsigned)a.out_fs + (row - f * a.V) * (unsigned)a.out_cs; }
+                    const unsigned off = (cok && row < a.nrows) ? (e + (unsigned)a.out_coff + (unsigned)co) * 4u : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x[r]), rout, off, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    float s;
+                    if (POOL == 1) s = fmaxf(fmaxf(x[4 * o], x[4 * o + 1]), fmaxf(x[4 * o + 2], x[4 * o + 3]));
+                    else s = (x[4 * o] + x[4 * o + 1]) + (x[4 * o + 2] + x[4 * o + 3]);
+                    const float t = __shfl_xor(s, 32, 64);
+                    s = POOL == 1 ? fmaxf(s, t) : (s + t) * 0.125f;
+                    const unsigned p = tile * 4 + o;
+                    unsigned e;
+                    if (a.out_dense) e = p * (unsigned)a.out_cs;
+                    else { const unsigned f = p / (unsigned)a.Vo; e = f * (unsigned)a.out_fs + (p - f * a.Vo) * (unsigned)a.out_cs; }
+                    const unsigned off = (h == 0 && cok && p * 8 < a.nrows) ? (e + (unsigned)a.out_coff + (unsigned)co) * 4u : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, s), rout, off, 0, 0);
+                }
+            }
+        }
+    };
+
+    const unsigned wstride = gridDim.x * 4;
+    unsigned tile = blockIdx.x * 4 + wave;
+    if (tile >= a.ntiles) return;
+    u32x4 avA[KMAX], avB[KMAX];
+    load_tile(avA, tile);
+    while (true) {
+        const unsigned t1 = tile + wstride;      // past the end: all offsets out of range, nothing moves
+        load_tile(avB, t1);
+        compute_store(avA, tile);
+        if (t1 >= a.ntiles) break;
+        const unsigned t2 = t1 + wstride;
+        load_tile(avA, t2);
+        compute_store(avB, t1);
+        if (t2 >= a.ntiles) break;
+        tile = t2;
+    }
+}
+
 typedef void (*PwKernel)(const ConvPwArgs);
 // [kmax index: 4, 8, 16][nt index: 1, 2, 4][pool]
 const PwKernel kPw[3][3][3] = {
@@ -201,6 +356,12 @@ const PwKernel kPw[3][3][3] = {
     {{k_conv_pw<16, 1, 0>, k_conv_pw<16, 1, 1>, k_conv_pw<16, 1, 2>},
      {k_conv_pw<16, 2, 0>, k_conv_pw<16, 2, 1>, k_conv_pw<16, 2, 2>},
      {k_conv_pw<16, 4, 0>, k_conv_pw<16, 4, 1>, k_conv_pw<16, 4, 2>}},
+};
+#define PW2_ROW(K, N) {k_conv_pw2<K, N, 0>, k_conv_pw2<K, N, 1>, k_conv_pw2<K, N, 2>}
+const PwKernel kPw2[3][3][3] = {
+    {PW2_ROW(4, 1), PW2_ROW(4, 2), PW2_ROW(4, 4)},
+    {PW2_ROW(8, 1), PW2_ROW(8, 2), PW2_ROW(8, 4)},
+    {PW2_ROW(16, 1), PW2_ROW(16, 2), {nullptr, nullptr, nullptr}},   // 16 x 4: no room for the second register set
 };
 const int kPwKmax[3] = {4, 8, 16};
 const int kPwNt[3] = {1, 2, 4};
@@ -234,8 +395,11 @@ bool conv_pw_plan(const TView& in, const TView& oc, const ConvGeom& g, int Cin, 
     p->wpk_floats = (size_t)K8 * NT * 256;
     p->exec_flops = 2.0 * (double)p->rows_pf * (double)(32 * NT) * (double)(K8 * 8);
     char buf[224];
-    snprintf(buf, sizeof buf, "conv_pw<k%d,nt%d,pool%d> K8=%d lds%zuK (streaming 1x1x1, weights in LDS) [k_conv_pw<%d,%d,%d>]",
-             kPwKmax[kmi], NT, pool, K8, lds / 1024, kPwKmax[kmi], NT, pool);
+    // the pipelined kernel when the layer allows it (launch_conv_pw falls back to k_conv_pw for unaligned or > 4 GiB views)
+    const bool pipe = !getenv("TH_PW_NOPIPE") && kPw2[kmi][nti][pool] && Cin % 8 == 0 && K8 <= kPwKmax[kmi];
+    snprintf(buf, sizeof buf, "conv_pw<k%d,nt%d,pool%d> K8=%d lds%zuK (streaming 1x1x1, weights in LDS%s) [k_conv_pw%s<%d,%d,%d>]",
+             kPwKmax[kmi], NT, pool, K8, lds / 1024, pipe ? ", next tile prefetched, buffer addressing" : "", pipe ? "2" : "",
+             kPwKmax[kmi], NT, pool);
     p->label = buf;
     (void)in;
     return true;
@@ -284,6 +448,15 @@ int launch_conv_pw(hipStream_t s, int64_t n, const ConvMfmaPlan& p, TView in, TV
     const unsigned want = (a.ntiles + 3) / 4;
     const unsigned grid = std::min(want, 256u * 8u);   // persistent: up to 8 workgroups per CU queued, waves stride over tiles
     PwKernel k = kPw[kmi][nti][p.pool];
+    // the pipelined buffer-addressing kernel when the views allow it (see k_conv_pw2)
+    const int64_t in_span = ((n - 1) * in.fs + (int64_t)(a.V - 1) * in.cs + in.coff + Cin) * 4;
+    const int64_t out_span = ((n - 1) * out.fs + (out_v - 1) * out.cs + out.coff + Cout) * 4;
+    static const bool no_pw2 = getenv("TH_PW_NOPIPE") != nullptr;   // A/B comparisons
+    if (!no_pw2 && kPw2[kmi][nti][p.pool] && a.vec_ok && Cin % 8 == 0 && a.K8 <= kPwKmax[kmi] && in_span < 0xfffffff0LL &&
+        out_span < 0xfffffff0LL) {
+        a.in_bytes = (unsigned)in_span; a.out_bytes = (unsigned)out_span;
+        k = kPw2[kmi][nti][p.pool];
+    }
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), p.lds_bytes, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) TH_FAIL(TH_EHIP, "conv_pw launch failed: %s (%s)", hipGetErrorString(e), p.label.c_str());
