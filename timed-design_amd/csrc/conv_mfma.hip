@@ -57,6 +57,7 @@ struct ConvMfmaArgs {
     int64_t nframes;
     const float* wx;   // k_conv_n16 XC > 0: weights of output channels 16..16+XC-1, [chunk][tap][q][c][4]
     int sd, sh, sw;    // convolution stride (k_conv_mfma only; 1 elsewhere)
+    unsigned in_grp_bytes;   // k_conv_n16: bytes from a frame group's first input element to its last (buffer descriptor)
     int geo_compact;   // k_conv_mfma GEO kernels: chunks after the first re-stage real voxels only (see the staging loop)
 };
 
@@ -769,6 +770,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4n __attribute__((ext_vector_type(4)));
 
 // Compile-time knock-outs for timing experiments on k_conv_n16's inner loop (results are WRONG when set; build a
 // second library with -DN16_KNOCK=n and load it through TIMED_HIP_LIB): 1 no weight-ring refills, 2 A fragments read
@@ -954,17 +956,23 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
         }
     }
 
-    int pf_off[PF];        // this thread's prefetch sources: input offset of real voxel (tid + u * NTHREADS) / 4, -1 = nothing
-    int pf_dst[PF];        // ... and where it goes in the staged image (float4 index)
+    // this thread's prefetch slots: BYTE offset (from the frame group's first input element) of the float4 it fetches for
+    // real voxel (tid + u * NTHREADS) / 4, or OOB = nothing (the buffer load then returns zeros without touching memory)
+    // — and where it goes in the staged image (float4 index).  The loads are buffer loads: a per-group descriptor, this
+    // per-slot offset in a VGPR and the chunk's channel offset in an SGPR, i.e. NO address arithmetic and no select per
+    // load in front of the MFMA phase (the 64-bit pointer form cost ~6 VALU instructions per load).
+    constexpr unsigned OOB = 0xffffffffu;
+    unsigned pf_boff[PF];
+    int pf_dst[PF];
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
         const int i = tid + u * NTHREADS;
-        pf_off[u] = -1; pf_dst[u] = 0;
+        pf_boff[u] = OOB; pf_dst[u] = 0;
         if (can_pf && i < nreal4) {
             const int r = i / CI4, f = r / real_pf, rr = r - f * real_pf;
             const int xa = rr % nxr, t = rr / nxr, ya = t % nyr, za = t / nyr;
             const int v = ((f * a.Zp + za + zlo) * a.Hp + ya + ylo) * a.Wp + xa + xlo;
-            pf_off[u] = VOXSRC(v);
+            pf_boff[u] = (unsigned)(VOXSRC(v) + (i % CI4) * 4) * 4u;
             pf_dst[u] = v * CS4 + (i % CI4);
         }
     }
@@ -982,6 +990,11 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
         const int64_t f0_next = (has_next ? gnext : grp) / a.nzb * a.FB;
         const float* inb_next = a.in + f0_next * a.in_fs + a.in_coff;
         const int nvalid_next = has_next ? (int)min((int64_t)a.FB, a.nframes - f0_next) : nvalid;
+        // a ragged group (the last one of a launch) takes the plain staging path, which knows about missing frames
+        const bool grp_pf = can_pf && nvalid == a.FB && !(a.dbg & 1);
+        const bool nxt_pf = can_pf && has_next && nvalid_next == a.FB && !(a.dbg & 1);
+        const __amdgpu_buffer_rsrc_t rs_cur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(inb0), 0, (int)a.in_grp_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_nxt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(inb_next), 0, (int)a.in_grp_bytes, 0x00020000);
 
 #if N16_KNOCK & 8
         long long prof_d = 0;
@@ -1009,7 +1022,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
                 long long prof_a = clock64();
                 if (prof_first) { prof_grp += prof_a - prof_g0; prof_first = false; }
 #endif
-                if (!(can_pf && (ch > 0 || staged))) {   // otherwise this chunk was written from registers already
+                if (!(ch > 0 ? grp_pf : staged)) {   // otherwise this chunk was written from registers already
                     __syncthreads();
                     if (need_a) {
                         constexpr int U = 4;
@@ -1029,30 +1042,24 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
                 prof_bar += prof_a2 - prof_a;
 #endif
                 const bool last_ch = ch + 1 == a.nchunks;
-                const bool do_pf = can_pf && (!last_ch || has_next) && !(a.dbg & 1);
+                const bool do_pf = last_ch ? nxt_pf : grp_pf;
                 const int pch = last_ch ? 0 : ch + 1;
-                // The PF loads are issued UNCONDITIONALLY (a dummy aligned address when there is nothing to fetch):
-                // hipcc can then count them and waits for the weight ring with vmcnt(N) instead of vmcnt(0),
-                // which would drain the prefetch in front of the first MFMA.
+                // The PF loads are issued UNCONDITIONALLY (also when their result will not be used): hipcc can then count
+                // them and waits for the weight ring with vmcnt(N) instead of vmcnt(0), which would drain the prefetch in
+                // front of the first MFMA.
                 float4 pfv[PF];
-                unsigned pfok = 0, pfld = 0;
                 {
-                    const float* pin = (last_ch ? inb_next : inb0) + pch * CI;
-                    const int pnv = last_ch ? nvalid_next : nvalid;
                     const int g = tid % CI4;                 // NTHREADS % CI4 == 0: the same channel group for every u
-                    const bool gok = pch * CI + g * 4 + 4 <= a.Cin;
+                    // nothing is fetched for channels past Cin in the last chunk, nor from a ragged group (frames that do not
+                    // exist must not be touched; such a group is staged by the plain path)
+                    const bool full = last_ch ? nvalid_next == a.FB : nvalid == a.FB;
+                    const unsigned gmask = (full && pch * CI + g * 4 + 4 <= a.Cin) ? 0u : OOB;
+                    const unsigned soff = (unsigned)(pch * CI) * 4u;
 #pragma unroll
                     for (int u = 0; u < PF; ++u) {
-                        // the source offsets do not depend on the chunk or the frame group: looked up once per workgroup
-                        // (pf_off, below the tables) instead of 14 LDS reads + divisions in front of every MFMA phase
-                        int off = do_pf ? pf_off[u] : -1;
-                        if (pnv < a.FB && off >= 0 && ((tid + u * NTHREADS) / CI4) / real_pf >= pnv) off = -1;
-                        const bool ld = off >= 0 && gok;
-                        const float4* src = ld ? reinterpret_cast<const float4*>(pin + off + g * 4)
-                                               : reinterpret_cast<const float4*>(a.wpk);
-                        pfv[u] = *src;
-                        pfok |= off >= 0 ? (1u << u) : 0u;
-                        pfld |= ld ? (1u << u) : 0u;
+                        const u32x4n raw = last_ch ? __builtin_amdgcn_raw_buffer_load_b128(rs_nxt, pf_boff[u] | gmask, soff, 0)
+                                                   : __builtin_amdgcn_raw_buffer_load_b128(rs_cur, pf_boff[u] | gmask, soff, 0);
+                        pfv[u] = __builtin_bit_cast(float4, raw);
                     }
                 }
                 // a thread's prefetched vectors all cover the same 4 channels (NTHREADS % 4 == 0): their BN constants
@@ -1151,8 +1158,8 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
                     // BN -> activation prologue in registers BEFORE the barrier (overlaps the other waves' last MFMAs)
 #pragma unroll
                     for (int u = 0; u < PF; ++u) {
-                        float4 v = ((pfld >> u) & 1u) ? pfv[u] : make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (has_pre && ((pfok >> u) & 1u) && pch * CI + (tid % CI4) * 4 < a.Cin) {
+                        float4 v = pfv[u];   // zeros where nothing was fetched
+                        if (has_pre && pf_boff[u] != OOB && pch * CI + (tid % CI4) * 4 < a.Cin) {
                             if (a.pre.scale) {
                                 v.x = fmaf(v.x, psc.x, psh.x); v.y = fmaf(v.y, psc.y, psh.y);
                                 v.z = fmaf(v.z, psc.z, psh.z); v.w = fmaf(v.w, psc.w, psh.w);
@@ -1165,7 +1172,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
                     __syncthreads();   // every wave is done reading chunk ch
 #pragma unroll
                     for (int u = 0; u < PF; ++u)
-                        if (pf_off[u] >= 0) A4[pf_dst[u]] = pfv[u];   // also for frames missing from a ragged group (zeros)
+                        if (pf_boff[u] != OOB) A4[pf_dst[u]] = pfv[u];
                 }
 #if N16_KNOCK & 8
                 prof_pf += clock64() - prof_c;
@@ -1236,7 +1243,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
 #if N16_KNOCK & 8
         prof_epi += clock64() - prof_d;
 #endif
-        staged = can_pf && has_next && !(a.dbg & 1);
+        staged = nxt_pf;
     }
 #if N16_KNOCK & 8
     if (blockIdx.x == 0 && lane == 0)
@@ -1567,6 +1574,7 @@ int launch_conv_mfma(hipStream_t s, int64_t n, const ConvMfmaPlan& p, TView in, 
     { static const int dbg = getenv("TH_CONV_DBG") ? atoi(getenv("TH_CONV_DBG")) : 0; a.dbg = dbg; }
     a.wpk = wpk; a.Cout = Cout; a.bias = bias; a.pre = pre; a.post = post;
     a.wx = n16 ? wpk + ((size_t)p.nchunks * 27 + 9) * 256 : wpk;
+    a.in_grp_bytes = (unsigned)std::min<int64_t>(0xfffffff0LL, ((int64_t)(p.FB - 1) * in.fs + ((int64_t)in.D * in.H * in.W - 1) * in.cs + Cin) * 4);
     a.out = out.p; a.out_fs = out.fs; a.out_cs = out.cs; a.out_coff = out.coff; a.Ho = out.H; a.Wo = out.W;
     a.nframes = n;
     const int64_t groups = (n + p.FB - 1) / p.FB;
