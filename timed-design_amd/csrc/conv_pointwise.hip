@@ -205,7 +205,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 template <int KMAX, int NT, int POOL>
-__global__ void __launch_bounds__(256, (NT == 4 || KMAX == 16 || (KMAX == 8 && NT == 2)) ? 2 : 3) k_conv_pw2(const ConvPwArgs a) {
+__global__ void __launch_bounds__(256, (NT == 4 || KMAX == 16 || (KMAX == 8 && NT == 2)) ? 2 : 3) k_conv_pw2(const ConvPwArgs a) {   // KMAX = 12: three per CU
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -363,6 +363,9 @@ const PwKernel kPw2[3][3][3] = {
     {PW2_ROW(8, 1), PW2_ROW(8, 2), PW2_ROW(8, 4)},
     {PW2_ROW(16, 1), PW2_ROW(16, 2), {nullptr, nullptr, nullptr}},   // 16 x 4: no room for the second register set
 };
+// 12 slots for 72..96 input channels (most of DenseCPD's bottleneck layers): two register sets of 12 float4 leave room for
+// three workgroups per CU where 16 slots allow two
+const PwKernel kPw2_12[2][3] = {PW2_ROW(12, 1), PW2_ROW(12, 2)};
 const int kPwKmax[3] = {4, 8, 16};
 const int kPwNt[3] = {1, 2, 4};
 constexpr size_t kPwLdsLimit = 64 * 1024;
@@ -397,9 +400,10 @@ bool conv_pw_plan(const TView& in, const TView& oc, const ConvGeom& g, int Cin, 
     char buf[224];
     // the pipelined kernel when the layer allows it (launch_conv_pw falls back to k_conv_pw for unaligned or > 4 GiB views)
     const bool pipe = !getenv("TH_PW_NOPIPE") && kPw2[kmi][nti][pool] && Cin % 8 == 0 && K8 <= kPwKmax[kmi];
+    const int kmax = (pipe && K8 > 8 && K8 <= 12 && nti <= 1) ? 12 : kPwKmax[kmi];
     snprintf(buf, sizeof buf, "conv_pw<k%d,nt%d,pool%d> K8=%d lds%zuK (streaming 1x1x1, weights in LDS%s) [k_conv_pw%s<%d,%d,%d>]",
-             kPwKmax[kmi], NT, pool, K8, lds / 1024, pipe ? ", next tile prefetched, buffer addressing" : "", pipe ? "2" : "",
-             kPwKmax[kmi], NT, pool);
+             kmax, NT, pool, K8, lds / 1024, pipe ? ", next tile prefetched, buffer addressing" : "", pipe ? "2" : "",
+             kmax, NT, pool);
     p->label = buf;
     (void)in;
     return true;
@@ -455,7 +459,7 @@ int launch_conv_pw(hipStream_t s, int64_t n, const ConvMfmaPlan& p, TView in, TV
     if (!no_pw2 && kPw2[kmi][nti][p.pool] && a.vec_ok && Cin % 8 == 0 && a.K8 <= kPwKmax[kmi] && in_span < 0xfffffff0LL &&
         out_span < 0xfffffff0LL) {
         a.in_bytes = (unsigned)in_span; a.out_bytes = (unsigned)out_span;
-        k = kPw2[kmi][nti][p.pool];
+        k = (a.K8 > 8 && a.K8 <= 12 && nti <= 1) ? kPw2_12[nti][p.pool] : kPw2[kmi][nti][p.pool];
     }
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), p.lds_bytes, s, a);
     hipError_t e = hipGetLastError();
