@@ -205,7 +205,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 template <int KMAX, int NT, int POOL>
-__global__ void __launch_bounds__(256, (NT == 4 || KMAX == 16 || (KMAX == 8 && NT == 2)) ? 2 : 3) k_conv_pw2(const ConvPwArgs a) {   // KMAX = 12: three per CU
+__global__ void __launch_bounds__(256, (NT == 4 || KMAX == 16) ? 2 : 3) k_conv_pw2(const ConvPwArgs a) {   // KMAX = 12: three per CU
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
