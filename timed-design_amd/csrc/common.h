@@ -121,6 +121,7 @@ int launch_conv_mfma(hipStream_t s, int64_t n, const ConvMfmaPlan& p, TView in, 
                      int Cout, const float* wpk, const float* bias, PreOp pre, PostOps post);
 
 // ---- first-layer convolution (conv_first.hip): Cin <= 8, Cout <= 32, 3x3x3, reads the caller's frames ----
+std::string conv_first_label(const ConvMfmaPlan& p, int Cin, const PostOps& post);
 bool conv_first_plan(int Din, int Hin, int Win, int Cin, const TView& out_conv, const ConvGeom& g, int Cout, int pool,
                      ConvMfmaPlan* plan);
 void conv_first_pack_weights(int Cin, int Cout, const float* w_keras, float* dst);

@@ -336,6 +336,35 @@ void conv_first_pack_weights(int Cin, int Cout, const float* w, float* dst) {
                 dst[(((size_t)tap * 2 + (c & 1)) * 32 + co) * 4 + (c >> 1)] = w[((size_t)tap * Cin + c) * Cout + co];
 }
 
+namespace {
+// the instantiation a plan runs with a given epilogue chain: pool-first (PMODE 3) when the chain is monotone, the
+// compile-time geometry when there is one for this frame size
+FirstKernel pick_first_kernel(const ConvMfmaPlan& p, int nst, const PostOps& post, int* pmode, int* geo) {
+    const bool no_pool_first = getenv("TH_NO_POOL_FIRST") != nullptr;   // A/B comparisons and tests
+    *pmode = (p.pool == 1 && post.monotone && !no_pool_first) ? 3 : p.pool;
+    *geo = 0;
+    FirstKernel k = kFirstKernels[nst - 1][*pmode];
+    if (p.Hp == p.Wp && p.Hc == p.Hp - 2 && p.Wc == p.Wp - 2 && !getenv("TH_CONV_NOGEO"))
+        for (const FirstGeo& ge : kFirstGeo)
+            if (ge.nst == nst && ge.pmode == *pmode && ge.geo == p.Hp) { k = ge.k; *geo = ge.geo; }
+    return k;
+}
+}  // namespace
+
+// the plan's label with the kernel that launch_conv_first will actually run for this epilogue chain (as rocprofv3 prints it)
+std::string conv_first_label(const ConvMfmaPlan& p, int Cin, const PostOps& post) {
+    int pmode, geo;
+    pick_first_kernel(p, (Cin + 1) / 2, post, &pmode, &geo);
+    std::string l = p.label;
+    const size_t b = l.rfind('[');
+    if (b != std::string::npos) {
+        char buf[64];
+        snprintf(buf, sizeof buf, "[k_conv_first<%d,%d,%d,%d>]", kWaves, (Cin + 1) / 2, pmode, geo);
+        l = l.substr(0, b) + buf;
+    }
+    return l;
+}
+
 int launch_conv_first(hipStream_t s, int64_t n, const ConvMfmaPlan& p, const void* frames, int dtype, int Din, int Hin,
                       int Win, int Cin, TView out, ConvGeom g, int Cout, const float* wpk, const float* bias, PostOps post) {
     ConvFirstArgs a;
@@ -352,12 +381,8 @@ int launch_conv_first(hipStream_t s, int64_t n, const ConvMfmaPlan& p, const voi
     const int64_t grid = n * p.nzb;
     if (grid > 0x7fffffffLL) TH_FAIL(TH_EINVAL, "conv_first: grid too large");
     const int nst = (Cin + 1) / 2;
-    const bool no_pool_first = getenv("TH_NO_POOL_FIRST") != nullptr;   // A/B comparisons and tests
-    const int pmode = (p.pool == 1 && post.monotone && !no_pool_first) ? 3 : p.pool;
-    FirstKernel k = kFirstKernels[nst - 1][pmode];
-    if (p.Hp == p.Wp && p.Hc == p.Hp - 2 && p.Wc == p.Wp - 2 && !getenv("TH_CONV_NOGEO"))
-        for (const FirstGeo& ge : kFirstGeo)
-            if (ge.nst == nst && ge.pmode == pmode && ge.geo == p.Hp) k = ge.k;
+    int pmode, geo;
+    FirstKernel k = pick_first_kernel(p, nst, post, &pmode, &geo);
     HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kWaves * 64), p.lds_bytes, s, a);
     hipError_t e = hipGetLastError();

@@ -504,7 +504,7 @@ int plan(th_model* m) {
                         float* dw;
                         if ((rc = upload(M, packed.data(), packed.size(), &dw))) return rc;
                         st.exec_flops = mp.exec_flops;
-                        st.label = n.name + ": " + mp.label;
+                        st.label = n.name + ": " + conv_first_label(mp, Cin, po);
                         const int iD = sn.D, iH = sn.H, iW = sn.W;
                         st.run = [=](hipStream_t s, int64_t cnt) {
                             return launch_conv_first(s, cnt, mp, M->cur_in, M->cur_dtype, iD, iH, iW, Cin, M->view(dst), g, Cout,
