@@ -10,8 +10,14 @@
  *   - every function returns 0 (TH_OK) or a negative TH_E* code; th_last_error() returns a
  *     thread-local human-readable message for the last failure on the calling thread.
  *   - the caller owns every host buffer; the library owns device buffers it allocates.
- *   - a th_model handle is bound to one device and is NOT re-entrant; distinct handles may be
- *     driven from distinct threads (ctypes releases the GIL).
+ *   - threading: a th_model handle is bound to one device.  Submissions on one handle (th_predict,
+ *     th_predict_async, th_predict_device) are serialised by a lock inside the handle, and
+ *     th_predict_wait may be called from a DIFFERENT thread than the one that submitted the ticket
+ *     (predict.py waits on its writer thread while the main thread keeps submitting): a ticket slot
+ *     is only handed out again after its waiter has returned, whether it succeeded or failed.  One
+ *     waiter per ticket (a second concurrent wait on the same ticket gets TH_EBUSY).  th_model_free,
+ *     th_model_set_chunk and th_model_profile must not run concurrently with anything else on the
+ *     handle.  Distinct handles may be driven from distinct threads (ctypes releases the GIL).
  *   - frames are channels-last [n, D, H, W, C], C fastest — the layout
  *     design_utils/utils.py:519-527 (load_batch) builds and Keras consumes.
  */

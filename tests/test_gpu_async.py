@@ -120,3 +120,63 @@ def test_logits_async(small):
     _, _, model = small
     x = _frames(6, 7)
     assert np.array_equal(model.predict_async(x, logits=True).result(), model.predict(x, logits=True))
+
+
+def test_submit_and_wait_on_different_threads_pinned(small):
+    """predict.py waits on its writer thread while the main thread keeps submitting to the SAME handle, and
+    with page-locked frames th_predict_async returns in microseconds — a slot released before its waiter has copied the
+    rows out would be re-used underneath it.  Distinct batches (so a mixed-up slot cannot pass), pinned inputs, a
+    waiter thread that lags behind the submitter; every batch must come back with ITS rows, bit for bit."""
+    import queue
+    import threading
+
+    _, _, model = small
+    n_batches, per = 64, 24
+    src = _frames(n_batches * per, 21)
+    want = model.predict(src).reshape(n_batches, per, 20)
+    X, owner = engine.pinned_empty(src.shape, np.float32)
+    X[...] = src
+    q: "queue.Queue" = queue.Queue(maxsize=3)                  # <= 3 in the queue + 1 being waited on = 4 tickets
+    got, errors = {}, []
+
+    def waiter():
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    return
+                i, pend = item
+                got[i] = pend.result().copy()
+        except Exception as e:                                 # pragma: no cover - reported by the assert below
+            errors.append(e)
+
+    th = threading.Thread(target=waiter)
+    th.start()
+    try:
+        for i in range(n_batches):
+            while True:
+                try:
+                    pend = model.predict_async(X[i * per:(i + 1) * per])
+                    break
+                except _lib.TimedHipError as e:                # all four slots still owned by the waiter: not an error
+                    assert e.code == -7
+            q.put((i, pend))
+    finally:
+        q.put(None)
+        th.join()
+    assert not errors, errors
+    for i in range(n_batches):
+        assert np.array_equal(got[i], want[i]), f"batch {i} came back with another batch's rows"
+    del X
+    owner.free()
+
+
+def test_double_wait_on_one_ticket_is_refused(small, lib):
+    _, _, model = small
+    x = _frames(4, 8)
+    out = np.empty((4, 20), np.float32)
+    t = C.c_int(-1)
+    _lib.check(lib.th_predict_async(model._h, x.ctypes.data, _lib.TH_F32, 4, out.ctypes.data, 0, C.byref(t)))
+    _lib.check(lib.th_predict_wait(model._h, t.value))
+    assert lib.th_predict_wait(model._h, t.value) == -1       # returned already: not in flight any more
+    assert np.array_equal(out, model.predict(x))

@@ -1,0 +1,90 @@
+"""Parity of the configuration bench.py times (VERDICT r2 "missing" 3 / "weak" 2): chunk 4096, several full chunks plus a
+ragged tail, frames resident in HBM, through th_predict_device — for every BASELINE topology.  The kernels whose grids,
+persistent-workgroup trip counts and buffer-descriptor views depend on the chunk size (k_conv_n16's persistent loop,
+k_conv_pw2's tile stride, < 4 GiB views) run here exactly as in the timed region.
+
+The loop this replaces is reference predict.py:125-155 (one Model.predict per batch); what must hold:
+  * the 8 golden frames of tests/golden/cnn_golden.npz (torch fp64 fixtures), planted at frame 0, at both sides of
+    every chunk boundary and at the very end of a device-generated batch, give the fixture's probabilities (5e-6);
+  * the whole [N, n_classes] matrix of the chunk-4096 run equals the chunk-64 run bit for bit (frame independence:
+    a frame's arithmetic does not depend on its position, its launch or its neighbours);
+  * every row is a probability vector.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from timed_hip import _lib, engine, synth
+
+pytestmark = pytest.mark.gpu
+TIGHT = 5e-6
+CHUNK = 4096
+N = 2 * CHUNK + 1696            # two full launches + the tail length of bench.py's 100 000-frame step (100000 % 4096)
+
+
+def _golden_frames(meta, name):
+    m = next(x for x in meta if x["name"] == name)
+    cfg, weights = getattr(synth, m["builder"])(**m["kwargs"])
+    return cfg, weights, synth.synthetic_frames(m["n"], **m["frame_kwargs"]).astype(np.float32)
+
+
+@pytest.mark.parametrize("name", ["timed20", "timed338", "densecpd20"])
+def test_chunk4096_multi_chunk_ragged_tail_matches_golden_and_chunk64(gpu, lib, cnn_golden, name):
+    z, meta = cnn_golden
+    cfg, weights, gold = _golden_frames(meta, name)
+    want = z[f"{name}__torch64"]
+    assert gold.shape[0] == 8 and gold.shape[1:] == (21, 21, 21, 6)
+    model = engine.HipFrameModel.from_keras(cfg, weights, device=gpu)
+    ncls = model.n_classes
+    frame_bytes = 21 * 21 * 21 * 6 * 4
+    d_frames = engine.DeviceBuffer(N * frame_bytes, gpu)
+    d_a = engine.DeviceBuffer(N * ncls * 4, gpu)
+    d_b = engine.DeviceBuffer(N * ncls * 4, gpu)
+    _lib.check(lib.th_dev_synth_frames(gpu, C.c_void_p(d_frames.ptr), N, 21, 6, 200, 77))
+    # first / last frame of every launch, both sides of each chunk boundary, and the end of the ragged tail
+    spots = [0, CHUNK - 1, CHUNK, 2 * CHUNK - 1, 2 * CHUNK, N - 1, 1234, CHUNK + 4000]
+    for g, pos in enumerate(spots):
+        d_frames.upload(gold[g], offset=pos * frame_bytes)
+    model.set_chunk(CHUNK)
+    model.predict_device(d_frames.ptr, N, d_a.ptr)
+    a = d_a.download((N, ncls), np.float32)
+    model.set_chunk(64)
+    model.predict_device(d_frames.ptr, N, d_b.ptr)
+    b = d_b.download((N, ncls), np.float32)
+    assert np.all(np.isfinite(a))
+    np.testing.assert_allclose(a.sum(1), 1.0, atol=1e-5)
+    for g, pos in enumerate(spots):
+        np.testing.assert_allclose(a[pos], want[g], atol=TIGHT, rtol=0, err_msg=f"golden frame {g} planted at {pos}")
+        assert a[pos].argmax() == want[g].argmax()
+    assert np.array_equal(a, b), f"chunk-4096 and chunk-64 runs differ in {np.count_nonzero((a != b).any(1))} rows"
+    # logits of the same run (north-star: 1e-4 on the logits; asserted at the tight bound)
+    m = next(x for x in meta if x["name"] == name)
+    if m["logits_layer"]:
+        model.set_chunk(CHUNK)
+        model.predict_device(d_frames.ptr, N, d_b.ptr, logits=True)
+        lg = d_b.download((N, ncls), np.float32)
+        for g, pos in enumerate(spots):
+            np.testing.assert_allclose(lg[pos], z[f"{name}__logits64"][g], atol=TIGHT, rtol=0)
+    model.close()
+    for d in (d_frames, d_a, d_b):
+        d.free()
+
+
+def test_chunk4096_host_resident_async_equals_device_resident(gpu, lib):
+    """th_predict_async over host memory at chunk 4096 (pieces through the 3-buffer ring) == the device-resident result"""
+    cfg, weights = synth.timed_synth(20)
+    model = engine.HipFrameModel.from_keras(cfg, weights, device=gpu)
+    model.set_chunk(CHUNK)
+    n = CHUNK + 300
+    frame_bytes = 21 * 21 * 21 * 6 * 4
+    d_frames = engine.DeviceBuffer(n * frame_bytes, gpu)
+    d_p = engine.DeviceBuffer(n * 20 * 4, gpu)
+    _lib.check(lib.th_dev_synth_frames(gpu, C.c_void_p(d_frames.ptr), n, 21, 6, 200, 5))
+    model.predict_device(d_frames.ptr, n, d_p.ptr)
+    ref = d_p.download((n, 20), np.float32)
+    host = d_frames.download((n, 21, 21, 21, 6), np.float32)
+    assert np.array_equal(model.predict(host), ref)
+    model.close()
+    d_frames.free()
+    d_p.free()

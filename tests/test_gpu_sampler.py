@@ -238,6 +238,31 @@ def test_sequence_metrics_on_device_match_host_restatement(gpu):
     sm.close()
 
 
+def test_sequence_metrics_on_device_match_independent_oracle(gpu):
+    """f-2 against a checker that is NOT product code: oracle/seqmetrics_oracle.py (scalar, Counter order, its own constant
+    tables; pinned to 50-digit values in tests/test_oracle_seqmetrics.py).  Accumulation order differs, so the bound is
+    order noise, not bit equality; the pI grid point must be the same unless two grid points tie."""
+    from oracle import seqmetrics_oracle as sq
+    rng = np.random.default_rng(18)
+    sizes = [300, 76, 12, 1]
+    mats, off = _keys(rng, 20, sizes)
+    sm = sampler.Sampler(gpu)
+    sm.load(np.concatenate(mats))
+    d = sm.draw(off, 20, rng="philox", seed=3, letters="ACDEFGHIKLMNPQRSTVWY", want_metrics=True)
+    for k in range(len(sizes)):
+        seqs = [row.tobytes().decode() for row in sm.split(d["letters"], off, 20)[k]]
+        got = d["metrics"][k * 20:(k + 1) * 20]
+        for s, g in zip(seqs, got):
+            c, pi, mw, ext = sq.seq_metrics(s)
+            assert abs(g[0] - c) <= 1e-12 * max(1.0, abs(c)), s
+            if g[1] != pi:
+                _, series = sq.charge_series(s)
+                a = sorted(abs(x) for x in series)
+                assert a[1] - a[0] < 1e-12, (s, g[1], pi)
+            assert abs(g[2] - mw) <= 1e-9 * mw and g[3] == ext, s
+    sm.close()
+
+
 def test_sample_with_multiprocessing_is_one_stream_in_key_order(gpu):
     """reference sampling_utils.py:164-197 / :118-125 replayed under np.random.seed: for key: for sample: rand(n_res)"""
     from design_utils import sampling_utils as su

@@ -184,6 +184,38 @@ def test_predict_py_takes_a_pdb_file_directly(gpu, tmp_path):
 
 
 @pytest.mark.gpu
+def test_config1_predict_py_on_1ubq_matches_cnn_oracle(gpu, tmp_path):
+    """BASELINE config 1 (predict.py on the reference's own tests/testing_files/1ubq.pdb1.gz): the probabilities predict.py
+    writes (reference predict.py:142 -> utils.py:768, float16-rounded CSV) against oracle/cnn_oracle.py evaluated on the
+    same 76 voxelised frames with a full-width 5-channel TIMED-synth; argmax sequence in the FASTA included."""
+    import warnings
+    import predict
+    from oracle import cnn_oracle
+    from timed_hip import pack, synth
+    cfg, weights = synth.timed_synth(20, in_channels=5)
+    mp = tmp_path / "TIMED5.pack"
+    mp.write_bytes(pack.keras_to_pack(cfg, weights))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        predict.load_dataset_and_predict([mp], UBQ, batch_size=12, dataset_map_path=tmp_path / "datasetmap.txt", path_to_output=tmp_path)
+    X, _labels, flat = voxeliser.voxelise_pdb(UBQ, device=gpu)
+    assert X.shape == (76, 21, 21, 21, 5)
+    ref = cnn_oracle.forward(cfg, weights, X)
+    got = np.loadtxt(tmp_path / "TIMED5.csv", delimiter=",")
+    assert got.shape == (76, 20)
+    ref16 = ref.astype(np.float16).astype(np.float64)
+    # a value within 5e-6 of a float16 rounding boundary may round the other way: at most one float16 step apart, and rare
+    step = np.spacing(np.maximum(ref16, 2.0 ** -14).astype(np.float16)).astype(np.float64)
+    assert np.all(np.abs(got - ref16) <= step)
+    assert np.mean(got == ref16) > 0.99
+    letters = np.array(list("ACDEFGHIKLMNPQRSTVWY"))
+    clear = np.sort(ref, 1)[:, -1] - np.sort(ref, 1)[:, -2] > 2e-3
+    fasta = (tmp_path / "TIMED5.fasta").read_text().split("\n")
+    assert fasta[0] == ">1ubqA" and len(fasta[1]) == 76
+    assert all(a == b for a, b, c in zip(fasta[1], "".join(letters[ref.argmax(1)]), clear) if c)
+
+
+@pytest.mark.gpu
 def test_voxelised_structure_as_aposteriori_layout_hdf5(gpu, tmp_path):
     """voxeliser -> .hdf5 in aposteriori's layout (timed_hip.h5write) -> predict.py: the files equal those of predicting
     straight from the PDB, and the dataset reads back through the reference-named loaders"""

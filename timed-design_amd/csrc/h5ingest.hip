@@ -266,21 +266,25 @@ bool header_messages(const uint8_t* f, int64_t flen, int64_t base, uint64_t addr
         if (flags & 0x20) p += 16;
         if (flags & 0x10) p += 4;
         const int szbytes = 1 << (flags & 3);
+        if (p + szbytes > flen) return false;          // prefix (times, phase-change values, chunk-0 size) inside the file
         uint64_t chunk0 = 0;
         std::memcpy(&chunk0, f + p, szbytes);
+        if (chunk0 > (uint64_t)flen) return false;
         p += szbytes;
         const bool track = flags & 4;
         blocks.push_back({p, (int64_t)chunk0});
         for (size_t b = 0; b < blocks.size() && b < 64; ++b) {
             int64_t q = blocks[b].p;
+            if (q < 0 || blocks[b].len < 0 || blocks[b].len > flen || q > flen - blocks[b].len) return false;
             const int64_t end = q + blocks[b].len;
-            if (q < 0 || end > flen) return false;
-            while (q + 4 <= end) {
+            while (q + 4 + (track ? 2 : 0) <= end) {
                 const int mtype = f[q], msize = rd<uint16_t>(f + q + 1), mflags = f[q + 3];
                 q += 4 + (track ? 2 : 0);
                 if (q + msize > end) break;
                 if (mtype == 0x10) {
+                    if (msize < 16) return false;
                     const uint64_t co = rd<uint64_t>(f + q), cl = rd<uint64_t>(f + q + 8);
+                    if (co > (uint64_t)flen || cl > (uint64_t)flen || cl < 8) return false;
                     blocks.push_back({base + (int64_t)co + 4, (int64_t)cl - 8});
                 } else if (mtype != 0) {
                     out->push_back({mtype, mflags, f + q, msize});
@@ -295,14 +299,16 @@ bool header_messages(const uint8_t* f, int64_t flen, int64_t base, uint64_t addr
     blocks.push_back({a + 16, (int64_t)hsize});
     for (size_t b = 0; b < blocks.size() && b < 64; ++b) {
         int64_t q = blocks[b].p;
+        if (q < 0 || blocks[b].len < 0 || blocks[b].len > flen || q > flen - blocks[b].len) return false;
         const int64_t end = q + blocks[b].len;
-        if (q < 0 || end > flen) return false;
         while (q + 8 <= end) {
             const int mtype = rd<uint16_t>(f + q), msize = rd<uint16_t>(f + q + 2), mflags = f[q + 4];
             q += 8;
             if (q + msize > end) break;
             if (mtype == 0x10) {
+                if (msize < 16) return false;
                 const uint64_t co = rd<uint64_t>(f + q), cl = rd<uint64_t>(f + q + 8);
+                if (co > (uint64_t)flen || cl > (uint64_t)flen) return false;
                 blocks.push_back({base + (int64_t)co, (int64_t)cl});
             } else if (mtype != 0) {
                 out->push_back({mtype, mflags, f + q, msize});
@@ -323,7 +329,13 @@ int64_t dataspace_count(const uint8_t* d, int64_t n, int64_t* dims, int* rank_ou
     else return -1;
     if (rank > 7 || p + 8 * rank > n) return -1;
     int64_t cnt = 1;
-    for (int i = 0; i < rank; ++i) { const int64_t v = (int64_t)rd<uint64_t>(d + p + 8 * i); if (dims) dims[i] = v; cnt *= v; }
+    for (int i = 0; i < rank; ++i) {
+        const uint64_t v = rd<uint64_t>(d + p + 8 * i);
+        if (v > (uint64_t)1 << 40) return -1;                          // hostile / unlimited dimension
+        if (dims) dims[i] = (int64_t)v;
+        if (v && cnt > ((int64_t)1 << 56) / (int64_t)v) return -1;     // product would overflow
+        cnt *= (int64_t)v;
+    }
     if (rank_out) *rank_out = rank;
     return cnt;
 }
@@ -422,7 +434,8 @@ extern "C" int th_h5_resolve(const void* file, int64_t file_len, int64_t base, i
             }
             for (uint32_t k = 0; v && k < sz; ++k) if (v[k]) nonzero_fill = true;
         }
-        if (space && type && layout && !shared && !nonzero_fill) {
+        if (space && type && layout && !shared && !nonzero_fill && type->size >= 8 && layout->size >= 2 &&
+            (!filt || filt->size >= 2)) {
             int rank = 0;
             int64_t dims[8];
             const int64_t cnt = dataspace_count(space->data, space->size, dims, &rank);
@@ -430,6 +443,7 @@ extern "C" int th_h5_resolve(const void* file, int64_t file_len, int64_t base, i
             const uint8_t* l = layout->data;
             int cls = t[0] & 0x0F;
             int esz = (int)rd<uint32_t>(t + 4);
+            if (esz < 1 || esz > 16) cls = -1;                          // numeric element sizes only
             bool big = t[1] & 1, sgn = (cls == 0) && (t[1] & 8);
             if (cls == 8 && type->size >= 16) { const uint8_t* b = t + 8; big = b[1] & 1; if ((b[0] & 0x0F) != 0) cls = -1; }   // enum over an integer (h5py bool)
             if (cnt > 0 && rank >= 1 && (cls == 0 || cls == 1 || cls == 8) && !big && layout->size >= 18 && l[0] == 3 && l[1] == 1) {
@@ -438,7 +452,10 @@ extern "C" int th_h5_resolve(const void* file, int64_t file_len, int64_t base, i
                 for (int d = 0; d < rank; ++d) g->v[1 + d] = dims[d];
                 g->v[15] = esz; g->v[16] = cls; g->v[17] = sgn; g->v[27] = 1;
                 const uint64_t daddr = rd<uint64_t>(l + 2), dsize = rd<uint64_t>(l + 10);
-                if (!filt && (daddr == kUndef || (dsize >= (uint64_t)(cnt * esz) && base + (int64_t)daddr + cnt * esz <= file_len))) {
+                // cnt <= file_len / esz first: cnt * esz and the end address cannot overflow after that
+                const bool fits = cnt <= file_len / esz && daddr <= (uint64_t)file_len && base >= 0 && base <= file_len &&
+                                  (int64_t)daddr <= file_len - base - cnt * esz && dsize >= (uint64_t)(cnt * esz);
+                if (!filt && (daddr == kUndef || fits)) {
                     g->ok = true; g->btree = daddr;
                 }
             } else if (cnt > 0 && rank >= 1 && (cls == 0 || cls == 1 || cls == 8) && !big && layout->size >= 11 && l[0] == 3 && l[1] == 2 &&
@@ -459,6 +476,7 @@ extern "C" int th_h5_resolve(const void* file, int64_t file_len, int64_t base, i
                         if (p + 8 > filt->size) { fok = false; break; }
                         const int fid = rd<uint16_t>(d + p);
                         int ncd;
+                        if (ver != 1 && ver != 2) { fok = false; break; }
                         if (ver == 1 || fid >= 256) {
                             const int nlen = rd<uint16_t>(d + p + 2);
                             ncd = rd<uint16_t>(d + p + 6);
@@ -568,7 +586,7 @@ extern "C" int th_h5_read_contiguous_as(const void* file, int64_t file_len, int6
         uint8_t* dest = (uint8_t*)dests[i];
         if (data_addrs[i] < 0) { std::memset(dest, 0, (size_t)(count * out_esz)); continue; }
         const int64_t a = base + data_addrs[i];
-        if (a < 0 || a + count * esz > file_len) TH_FAIL(TH_EIO, "th_h5_read_contiguous_as: dataset %lld lies outside the file", (long long)i);
+        if (a < 0 || a > file_len || count > (file_len - a) / esz) TH_FAIL(TH_EIO, "th_h5_read_contiguous_as: dataset %lld lies outside the file", (long long)i);
         if (conv == 1) {
             float* o = reinterpret_cast<float*>(dest);
             for (int64_t e = 0; e < count; ++e) { double v; std::memcpy(&v, f + a + 8 * e, 8); o[e] = (float)v; }

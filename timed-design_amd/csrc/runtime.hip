@@ -22,6 +22,7 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
 
 // ---- errors ---------------------------------------------------------------------------------
 static thread_local char g_err[1024] = "";
@@ -124,8 +125,14 @@ struct th_model {
     hipEvent_t ev_free[kRing] = {nullptr, nullptr, nullptr};
     bool ring_used[kRing] = {false, false, false};
     uint64_t piece_counter = 0;
+    // Threading contract (include/timed_hip.h): submissions (th_predict_async / th_predict / th_predict_device) on one
+    // handle are serialised by `mu`; th_predict_wait may run on another thread than the submitter.  A ticket slot stays
+    // `busy` until its waiter has synchronised on `done` AND copied the rows out, so a concurrent submission can never
+    // re-record its events or reallocate its buffers underneath the waiter.
+    std::mutex mu;
     struct Ticket {
         bool busy = false;
+        bool waiting = false;     // a th_predict_wait call owns this slot right now
         hipEvent_t computed = nullptr, done = nullptr;
         float* d_out = nullptr;  size_t d_out_floats = 0;
         float* h_out = nullptr;  size_t h_out_floats = 0;   // pinned
@@ -848,11 +855,12 @@ int th_model_load(const char* pack_path, int device, unsigned flags, th_model** 
 void th_model_free(th_model* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
-    for (float* p : m->dev_allocs) (void)hipFree(p);
-    for (Buffer& b : m->bufs) if (b.dev) (void)hipFree(b.dev);
+    // queued kernels and copies may still read the arenas: drain the three streams before anything is released
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     if (m->copy_stream) (void)hipStreamSynchronize(m->copy_stream);
     if (m->d2h_stream) (void)hipStreamSynchronize(m->d2h_stream);
+    for (float* p : m->dev_allocs) (void)hipFree(p);
+    for (Buffer& b : m->bufs) if (b.dev) (void)hipFree(b.dev);
     for (int r = 0; r < th_model::kRing; ++r) {
         if (m->d_in_ring[r]) (void)hipFree(m->d_in_ring[r]);
         if (m->ev_h2d[r]) (void)hipEventDestroy(m->ev_h2d[r]);
@@ -895,6 +903,7 @@ int th_model_set_chunk(th_model* m, int frames_per_chunk) {
 int th_predict_device(th_model* m, const void* d_frames, int dtype, int64_t n, float* d_probs, unsigned flags) {
     if (n < 0) TH_FAIL(TH_EINVAL, "negative frame count");
     if (!m || (n > 0 && (!d_frames || !d_probs))) TH_FAIL(TH_EINVAL, "null argument");
+    std::lock_guard<std::mutex> lock(m->mu);
     return run_device(m, d_frames, dtype, n, d_probs, flags);
 }
 
@@ -906,9 +915,27 @@ static bool host_ptr_is_pinned(const void* p) {
     return a.type == hipMemoryTypeHost;
 }
 
+static int predict_async_locked(th_model* m, const void* frames, int dtype, int64_t n, float* probs_out, unsigned flags, int* ticket);
+
 int th_predict_async(th_model* m, const void* frames, int dtype, int64_t n, float* probs_out, unsigned flags, int* ticket) {
     if (n < 0) TH_FAIL(TH_EINVAL, "negative frame count");
     if (!m || !ticket || (n > 0 && (!frames || !probs_out))) TH_FAIL(TH_EINVAL, "null argument");
+    std::lock_guard<std::mutex> lock(m->mu);
+    int rc = predict_async_locked(m, frames, dtype, n, probs_out, flags, ticket);
+    if (rc) {
+        // part of the batch may already be queued: nothing of it may still read the caller's frames (or write a ticket
+        // buffer the next submission reallocates) once the error has been returned
+        const std::string keep = th_last_error();
+        (void)hipStreamSynchronize(m->copy_stream);
+        (void)hipStreamSynchronize(m->stream);
+        (void)hipStreamSynchronize(m->d2h_stream);
+        (void)hipGetLastError();
+        th_set_error("%s", keep.c_str());
+    }
+    return rc;
+}
+
+static int predict_async_locked(th_model* m, const void* frames, int dtype, int64_t n, float* probs_out, unsigned flags, int* ticket) {
     const size_t esz = dtype_size(dtype);
     if (!esz) TH_FAIL(TH_EINVAL, "unknown frame dtype %d", dtype);
     HIP_TRY(hipSetDevice(m->device));
@@ -991,12 +1018,27 @@ int th_predict_async(th_model* m, const void* frames, int dtype, int64_t n, floa
 int th_predict_wait(th_model* m, int ticket) {
     if (!m || ticket < 0 || ticket >= th_model::kTickets) TH_FAIL(TH_EINVAL, "bad ticket");
     th_model::Ticket& t = m->tickets[ticket];
-    if (!t.busy) TH_FAIL(TH_EINVAL, "ticket %d is not in flight", ticket);
-    HIP_TRY(hipSetDevice(m->device));
-    t.busy = false;      // whatever happens below, the slot is returned
-    HIP_TRY(hipEventSynchronize(t.done));
-    if (t.floats) std::memcpy(t.user_out, t.h_out, t.floats * sizeof(float));
-    return TH_OK;
+    {
+        std::lock_guard<std::mutex> lock(m->mu);
+        if (!t.busy) TH_FAIL(TH_EINVAL, "ticket %d is not in flight", ticket);
+        if (t.waiting) TH_FAIL(TH_EBUSY, "ticket %d is already being waited on by another thread", ticket);
+        t.waiting = true;
+    }
+    // the blocking part runs WITHOUT the model lock (the submitter keeps queueing the next batches meanwhile); the slot
+    // stays busy, so nothing can re-record t.done or touch t.h_out / t.user_out until the rows have been copied out
+    int rc = TH_OK;
+    hipError_t e = hipSetDevice(m->device);
+    if (e == hipSuccess) e = hipEventSynchronize(t.done);
+    if (e != hipSuccess) {
+        th_set_error("th_predict_wait: %s", hipGetErrorString(e));
+        rc = TH_EHIP;
+    } else if (t.floats) {
+        std::memcpy(t.user_out, t.h_out, t.floats * sizeof(float));
+    }
+    std::lock_guard<std::mutex> lock(m->mu);
+    t.waiting = false;
+    t.busy = false;      // success or failure, the slot is returned — but only now
+    return rc;
 }
 
 int th_predict(th_model* m, const void* frames, int dtype, int64_t n, float* probs_out, unsigned flags) {

@@ -339,6 +339,14 @@ struct th_sampler {
 
 namespace {
 
+// Scope guard: every exit path after the first enqueue — a failed Scratch::ensure, a HIP error — synchronises the
+// sampler's stream before returning, so no queued copy can still read a local vector / a caller buffer and no queued
+// kernel can still use a scratch buffer that the next call reallocates.
+struct StreamDrain {
+    hipStream_t s;
+    ~StreamDrain() { if (s) { (void)hipStreamSynchronize(s); } }
+};
+
 int sampler_load(th_sampler* S, const double* probs, int64_t n_rows, int n_cls, double t, int mode, int cum_dtype, double* q_out) {
     if (!S || !probs || n_rows <= 0 || n_cls <= 0) TH_FAIL(TH_EINVAL, "th_sampler_load: bad shape");
     if (cum_dtype != TH_F64 && cum_dtype != TH_F32 && cum_dtype != TH_F16) TH_FAIL(TH_EINVAL, "th_sampler_load: running-sum dtype %d", cum_dtype);
@@ -346,6 +354,7 @@ int sampler_load(th_sampler* S, const double* probs, int64_t n_rows, int n_cls, 
     if (mode != TH_TEMPER_NONE && t == 0.0)
         TH_FAIL(TH_EINVAL, "th_sample: temperature 0 (the reference divides by it: sampling_utils.py:159)");
     HIP_TRY(hipSetDevice(S->device));
+    StreamDrain drain{S->stream};   // any return below (errors included) leaves nothing queued on caller / scratch memory
     const size_t cells = (size_t)n_rows * n_cls, bytes = cells * sizeof(double);
     int rc;
     if ((rc = S->dp.ensure(bytes)) || (rc = S->dq.ensure(bytes)) || (rc = S->dc.ensure(bytes)) ||
@@ -404,6 +413,7 @@ int sampler_draw(th_sampler* S, int64_t n_keys, const int64_t* row_off, int64_t 
     HIP_TRY(hipSetDevice(S->device));
     // draws are numbered from the first requested row: shift the offsets so that key 0 starts at draw 0
     std::vector<int64_t> off(n_keys + 1);
+    StreamDrain drain{S->stream};   // declared after `off`: the stream is drained before the vector (a copy source) dies
     const int64_t base_row = row_off[0];
     for (int64_t k = 0; k <= n_keys; ++k) off[k] = row_off[k] - base_row;
     const int64_t total = n_samples * off[n_keys];

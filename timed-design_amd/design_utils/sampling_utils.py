@@ -118,10 +118,11 @@ def _sample_keys(keys, sample_n: int, pdb_to_probability: dict, rotamer_categori
     one_letter = all(len(c) == 1 for c in cats[:n_cls])
     r = np.random.rand(int(sample_n) * int(row_off[-1]))
     sm = _sampler.default_sampler(device)
-    sm.load(np.concatenate(mats).astype(np.float64), cum_dtype=cum)
     on_device = one_letter and METRICS_SOURCE != "ampal"
-    d = sm.draw(row_off, sample_n, uniforms=r, letters="".join(cats[:n_cls]) if one_letter else None,
-                want_idx=not one_letter, want_metrics=on_device)
+    with sm.lock:       # the process-wide sampler is shared between threads: load + draw is one operation
+        sm.load(np.concatenate(mats).astype(np.float64), cum_dtype=cum)
+        d = sm.draw(row_off, sample_n, uniforms=r, letters="".join(cats[:n_cls]) if one_letter else None,
+                    want_idx=not one_letter, want_metrics=on_device)
     out = {}
     for k, key in enumerate(keys):
         lo, hi = int(row_off[k]), int(row_off[k + 1])

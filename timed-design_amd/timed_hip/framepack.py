@@ -161,7 +161,10 @@ class StructurePack:
     ``predict.py --path_to_dataset structure.pdb.gz`` needs neither aposteriori nor an HDF5 file."""
 
     def __init__(self, path, device: int = 0, gaussian: bool = True):
+        import warnings
         from . import voxeliser
+        warnings.warn(f"{os.fspath(path)}: frames are built by {voxeliser.PROVENANCE}; expect small differences from a "
+                      "make-frame-dataset .hdf5 of the same structure", stacklevel=2)
         self.frames, labels, flat = voxeliser.voxelise_pdb(path, gaussian=gaussian, device=device)
         self.labels = labels
         self.flat_map = np.asarray(flat, dtype=str).reshape(-1, 4)

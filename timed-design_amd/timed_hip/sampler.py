@@ -7,6 +7,7 @@ These are the numeric halves of reference design_utils/sampling_utils.py:
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import Optional, Sequence
 
 import numpy as np
@@ -50,6 +51,10 @@ class Sampler:
         self._h = C.c_void_p()
         self.device = device
         self.n_rows = self.n_cls = 0
+        # `load` then `draw` is ONE logical operation on a resident sampler: callers that share a Sampler between
+        # threads (the process-wide default_sampler) hold this re-entrant lock across the pair; the C mutex only
+        # protects each call on its own
+        self.lock = threading.RLock()
         _lib.check(self._lib.th_sampler_create(device, C.byref(self._h)))
 
     def load(self, probs, temperature: float = 1.0, apply_temperature: Optional[bool] = None, cum_dtype=np.float64,
@@ -126,12 +131,15 @@ class Sampler:
 
 
 _DEFAULT: dict = {}
+_DEFAULT_LOCK = threading.Lock()
 
 
 def default_sampler(device: int = 0) -> Sampler:
-    if device not in _DEFAULT:
-        _DEFAULT[device] = Sampler(device)
-    return _DEFAULT[device]
+    """Process-wide sampler of a device.  Shared between threads: take ``sampler.lock`` around a load + draw pair."""
+    with _DEFAULT_LOCK:
+        if device not in _DEFAULT:
+            _DEFAULT[device] = Sampler(device)
+        return _DEFAULT[device]
 
 
 def apply_temperature(probs, t: float = 1.0, device: int = 0) -> np.ndarray:
@@ -140,7 +148,9 @@ def apply_temperature(probs, t: float = 1.0, device: int = 0) -> np.ndarray:
     p = _as_probs(probs)
     if p.shape[0] == 0:
         return np.empty_like(p)
-    return default_sampler(device).load(p, t, apply_temperature=True, return_q=True)
+    sm = default_sampler(device)
+    with sm.lock:
+        return sm.load(p, t, apply_temperature=True, return_q=True)
 
 
 def sample_indices(probs, n_samples: int, temperature: float = 1.0, uniforms: Optional[np.ndarray] = None,
@@ -168,9 +178,10 @@ def sample_indices(probs, n_samples: int, temperature: float = 1.0, uniforms: Op
             res.append(np.empty((n_samples, n_res), "S1"))
         return res[0] if len(res) == 1 else tuple(res)
     sm = default_sampler(device)
-    sm.load(p, temperature, cum_dtype=cum_dtype)
-    d = sm.draw([0, n_res], n_samples, uniforms=uniforms, rng=rng, seed=seed, rng_offset=rng_offset, letters=letters,
-                want_uniforms=return_uniforms)
+    with sm.lock:       # another thread's load must not slip in between this load and its draw
+        sm.load(p, temperature, cum_dtype=cum_dtype)
+        d = sm.draw([0, n_res], n_samples, uniforms=uniforms, rng=rng, seed=seed, rng_offset=rng_offset, letters=letters,
+                    want_uniforms=return_uniforms)
     res = [d["idx"].reshape(n_samples, n_res)]
     if return_uniforms:
         res.append(d["uniforms"].reshape(n_samples, n_res))

@@ -155,6 +155,9 @@ def voxelise_pdb(path, voxels_per_side: int = 21, frame_edge_length: float = 21.
     return X, np.asarray(labels, dtype=np.uint8).reshape(-1, 20), flat
 
 
+PROVENANCE = "timed_hip.voxeliser (in-house GPU voxeliser; parity with aposteriori 2.4.0 NOT pinned by a golden file)"
+
+
 def write_frame_pack(stem, frames: np.ndarray, labels: np.ndarray, flat_map, gaussian: bool, source: str = ""):
     """Store voxelised frames as a frame pack that predict.py accepts wherever it accepts an .hdf5 path."""
     import json
@@ -164,7 +167,8 @@ def write_frame_pack(stem, frames: np.ndarray, labels: np.ndarray, flat_map, gau
     np.savetxt(stem + ".map.txt", np.asarray(flat_map), delimiter=",", fmt="%s")
     with open(stem + ".meta.json", "w") as f:
         json.dump(dict(frame_dims=list(frames.shape[1:]), voxels_as_gaussian=bool(gaussian), n_frames=int(frames.shape[0]),
-                       source=source, make_frame_dataset_ver="timed_hip.voxeliser (unpinned vs aposteriori 2.4.0)"), f)
+                       source=source, make_frame_dataset_ver="timed_hip.voxeliser (unpinned vs aposteriori 2.4.0)",
+                       frame_provenance=PROVENANCE), f)
 
 
 def write_hdf5(path, frames: np.ndarray, labels: np.ndarray, flat_map, gaussian: bool, atom_encoder: Sequence[str] = DEFAULT_ENCODER,
@@ -177,6 +181,8 @@ def write_hdf5(path, frames: np.ndarray, labels: np.ndarray, flat_map, gaussian:
     from . import h5write
     with h5write.File(path) as f:
         f.attrs["make_frame_dataset_ver"] = "2.4.0"        # the layout version the reference's checks accept (utils.py:271-280)
+        # ... but these frames did NOT come from aposteriori: a separate attribute lets any downstream tool tell them apart
+        f.attrs["frame_provenance"] = PROVENANCE
         f.attrs["frame_dims"] = np.asarray(frames.shape[1:], dtype=np.int64)
         f.attrs["atom_encoder"] = list(atom_encoder)
         f.attrs["encode_cb"] = bool(encode_cb)
