@@ -10,8 +10,9 @@ A *step* is one pass of the hot path over the whole per-GPU job: BASELINE.json c
 (generated on the device, 22.2 GB), through th_predict_device (include/timed_hip.h), probabilities
 left in HBM.  With N > 1 every rank runs the same job on its own GPU (weak scaling, frames are
 independent) and each step ends with the one real exchange of the path: an RCCL gather of the
-[100k, n_classes] fp32 shards to rank 0 (th_comm_gather_rows).  torch is used only for the
-process-group barrier / max-reduce the driver contract asks for (gloo, CPU tensors).
+[100k, n_classes] fp32 shards to rank 0 (th_comm_gather_rows).  No PyTorch: the barrier / max-reduce
+of the driver contract and the RCCL id broadcast run over the product's own TCP rendezvous
+(timed_hip/rendezvous.py) on the RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT the launcher sets.
 
 The JSON line carries, besides the contract fields:
   roofline      the dominant kernel (largest share of device time), timed live with HIP events on the
@@ -137,16 +138,15 @@ def main():
         sys.exit("no HIP device visible; bench.py measures the GPU path only")
     device = local_rank % ndev
 
-    dist = None
+    rdzv = None
     if world > 1:
-        import torch
-        import torch.distributed as dist
+        from timed_hip.rendezvous import HostRendezvous
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        rdzv = HostRendezvous(rank, world)
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        if rdzv is not None:
+            rdzv.barrier()
 
     cfg, weights = synth.TOPOLOGIES[args.topology]()
     model = engine.HipFrameModel.from_keras(cfg, weights, device=device, name=args.topology)
@@ -163,47 +163,33 @@ def main():
     d_gather = None
     host_gather = None
     exchange = "rccl gather to rank 0 (grouped send/recv over xGMI)" if world > 1 else "none"
-    counts = (C.c_int64 * world)(*([n] * world))
     if world > 1:
-        import torch
-        idbuf = C.create_string_buffer(_lib.TH_COMM_ID_BYTES)
-        if rank == 0 and lib.th_comm_unique_id(idbuf) != 0:
-            idbuf = C.create_string_buffer(_lib.TH_COMM_ID_BYTES)  # all zeros = "no id": every rank falls back together
-        t = torch.frombuffer(bytearray(idbuf.raw), dtype=torch.uint8).clone()
-        dist.broadcast(t, src=0)
-        idbytes = bytes(t.numpy().tobytes())
-        h = C.c_void_p()
-        rc = lib.th_comm_init(idbytes, world, rank, device, C.byref(h)) if any(idbytes) else -6
-        ok = torch.tensor([1 if rc == 0 else 0])
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 1:
-            comm = h
+        from timed_hip import distributed as td
+        why = ""
+        try:
+            comm = td.RcclGather.from_environment(rank, world, device, rendezvous=rdzv)   # raises on EVERY rank if any fails
             if rank == 0:
                 d_gather = engine.DeviceBuffer(world * n * model.n_classes * 4, device)
-        else:
-            if rc == 0:
-                lib.th_comm_free(h)
-            why = lib.th_last_error().decode(errors="replace")
+        except RuntimeError as e:
+            why = str(e)
             if ndev >= world:
                 # every rank has its own GPU: RCCL must work here, and a silent host exchange would be measured as if
                 # it were the xGMI gather — refuse
                 sys.exit(f"[bench] rank {rank}: RCCL communicator could not be created although {ndev} devices are "
                          f"visible for {world} ranks: {why}")
             # ranks share a GPU (fewer devices than ranks): RCCL cannot span them; measure with the exchange done on the
-            # host (device->host copy + gloo gather) and say so in the JSON line
-            exchange = f"HOST FALLBACK (gloo gather of downloaded rows): {world} ranks on {ndev} device(s): " + why
+            # host (device->host copy + TCP gather) and say so in the JSON line
+            exchange = f"HOST FALLBACK (TCP gather of downloaded rows): {world} ranks on {ndev} device(s): " + why
             if rank == 0:
                 print("[bench] " + exchange, file=sys.stderr)
-            from timed_hip import distributed as td
-            host_gather = td.GlooGather()
+            host_gather = rdzv
 
     def step():
         model.predict_device(d_frames.ptr, n, d_probs.ptr)
         if comm is not None:
-            _lib.check(lib.th_comm_gather_rows(comm, C.c_void_p(d_probs.ptr), counts, model.n_classes, 0,
-                                               C.c_void_p(d_gather.ptr if d_gather else 0)))
+            comm.gather_rows_device(d_probs.ptr, [n] * world, model.n_classes, 0, d_gather.ptr if d_gather else 0)
         elif host_gather is not None:
-            host_gather.gather_rows(d_probs.download((n, model.n_classes), np.float32), [n] * world, 0)
+            host_gather.allgather(d_probs.download((n, model.n_classes), np.float32).tobytes())
 
     # warm-up steps run with every plan step bracketed by HIP events (the per-layer table); the timed steps
     # bracket only the dominant kernel (2 events per chunk), which is what `roofline` is computed from
@@ -223,11 +209,8 @@ def main():
     _lib.check(lib.th_dev_sync(device))
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        tt = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    if rdzv is not None:
+        elapsed = rdzv.all_max_float(elapsed)
 
     # sanity: EVERY row the timed work produced is a probability vector (all n rows are brought back: 8 MB at 20 classes)
     out_rows = d_probs.download((n, model.n_classes), np.float32)
@@ -240,24 +223,22 @@ def main():
     # and tail rows of its own shard over gloo (host) and rank 0 compares them with the same rows of the RCCL result.
     gather_verified = None
     if world > 1 and comm is not None:
-        import torch
         k = min(n, 64)
         mine = np.concatenate([d_probs.download((k, model.n_classes), np.float32),
                                d_probs.download((k, model.n_classes), np.float32, offset=(n - k) * model.n_classes * 4)])
-        parts = [torch.empty(mine.shape, dtype=torch.float32) for _ in range(world)] if rank == 0 else None
-        dist.gather(torch.from_numpy(mine), parts, dst=0)
+        parts = [np.frombuffer(b, dtype=np.float32).reshape(mine.shape) for b in rdzv.allgather(mine.tobytes())]
         if rank == 0:
             gather_verified = True
             for r in range(world):
                 base = r * n * model.n_classes * 4
                 got = np.concatenate([d_gather.download((k, model.n_classes), np.float32, offset=base),
                                       d_gather.download((k, model.n_classes), np.float32, offset=base + (n - k) * model.n_classes * 4)])
-                if not np.array_equal(got, parts[r].numpy()):
+                if not np.array_equal(got, parts[r]):
                     gather_verified = False
             if not gather_verified:
                 sys.exit("[bench] RCCL gather delivered rows that differ from the ranks' own shards")
             # distinct seeds per rank: two blocks holding the same rows would mean a misrouted transfer
-            assert not np.array_equal(parts[0].numpy(), parts[1].numpy()), "ranks produced identical shards"
+            assert not np.array_equal(parts[0], parts[1]), "ranks produced identical shards"
 
     if rank == 0:
         cost = model.cost()
@@ -320,9 +301,10 @@ def main():
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if comm is not None:
-        lib.th_comm_free(comm)
-    if dist is not None:
-        dist.destroy_process_group()
+        comm.close()
+    if rdzv is not None:
+        rdzv.barrier()
+        rdzv.close()
 
 
 if __name__ == "__main__":

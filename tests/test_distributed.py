@@ -143,6 +143,138 @@ def test_two_rank_predict_writes_the_same_bytes_as_one_rank(tmp_path, bs, fpc, s
         assert (one / fn).read_bytes() == (two / fn).read_bytes(), fn
 
 
+@pytest.mark.parametrize("bs,start,expect", [(4, 0, [3, 3, 3, 4, 3, 3, 3, 4]), (5, 4, [0, 1, 1, 1, 0, 1, 1, 1])])
+def test_eight_rank_predict_uneven_and_empty_shards(tmp_path, bs, start, expect):
+    """BASELINE config 4's rank count on CPU: eight gloo ranks through the real predict.py control flow — uneven shard
+    sizes (26 rows: 3/4), and a resumed run that leaves 6 rows for 8 ranks (two ranks hold NO row: empty shard, empty
+    text part, zero-row gather block).  Files byte for byte as the 1-rank run."""
+    import warnings
+    from pathlib import Path
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import predict
+    import _oracle_model
+    assert td.shard_counts(26 - start * bs, 8) == expect
+    G = os.path.join(ROOT, "tests", "golden")
+    model, data = os.path.join(G, "keras_tiny.h5"), os.path.join(G, "frames_tiny.hdf5")
+    one, two = tmp_path / "one", tmp_path / "two"
+    one.mkdir(); two.mkdir()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        if start:
+            for d in (one, two):
+                predict.load_dataset_and_predict([Path(model)], data, batch_size=bs, dataset_map_path=d / "datasetmap.txt",
+                                                 path_to_output=d, model_loader=_oracle_model.load_model)
+                for fn in ("keras_tiny.csv", "encoded_labels.csv"):
+                    lines = (d / fn).read_text().splitlines(True)
+                    (d / fn).write_text("".join(lines[: start * bs]))
+        predict.load_dataset_and_predict([Path(model)], data, batch_size=bs, start_batch=start, dataset_map_path=one / "datasetmap.txt",
+                                         path_to_output=one, frames_per_call=2, model_loader=_oracle_model.load_model)
+    script = tmp_path / "worker.py"
+    worker = PREDICT_WORKER.replace("td.shard_bounds(26 - {start} * {bs}, 2)", "td.shard_bounds(26 - {start} * {bs}, 8)")
+    script.write_text(worker.format(root=ROOT, out=str(two), model=model, data=data, bs=bs, fpc=2, start=start))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    names = sorted(p.name for p in one.iterdir())
+    assert names == sorted(p.name for p in two.iterdir())
+    for fn in names:
+        assert (one / fn).read_bytes() == (two / fn).read_bytes(), fn
+
+
+RDZV_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, os.path.join({root!r}, "timed-design_amd"))
+    from timed_hip.rendezvous import HostRendezvous
+    assert "torch" not in sys.modules
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    r = HostRendezvous(rank, world, timeout=60)
+    ident = r.broadcast(bytes(range(128)) if rank == 0 else None)
+    assert ident == bytes(range(128))
+    table = r.allgather_ints([rank, rank * rank, -rank])
+    assert table == [[q, q * q, -q] for q in range(world)], table
+    parts = r.allgather(b"x" * (rank * 1000))                  # ragged payloads, an empty one from rank 0
+    assert [len(p) for p in parts] == [q * 1000 for q in range(world)]
+    assert r.all_min(1 if rank != world - 1 else 0) == 0 and r.all_min(7) == 7
+    assert r.all_max_float(0.5 + rank) == world - 0.5
+    for _ in range(20):
+        r.barrier()
+    r.close()
+    assert "torch" not in sys.modules, "the rendezvous must not pull PyTorch in"
+    sys.stdout.write("RDZV_OK %d\\n" % rank)
+""")
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_tcp_rendezvous_under_torchrun_without_torch(tmp_path, world):
+    """timed_hip.rendezvous (the product's N > 1 control plane: RCCL id broadcast, status reduce, text sizes) inside a
+    torch.distributed.run job — whose agent owns MASTER_PORT itself — without importing torch in the workers."""
+    script = tmp_path / "rdzv_worker.py"
+    script.write_text(RDZV_WORKER.format(root=ROOT))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    import re       # (the ranks' lines may interleave on the shared pipe)
+    assert sorted(int(x) for x in re.findall(r"RDZV_OK (\d+)", r.stdout)) == list(range(world))
+
+
+def test_tcp_rendezvous_skips_a_foreign_listener(tmp_path):
+    """a service that is not this job sits on the first candidate port: ranks recognise it by the failed handshake"""
+    import threading
+    from timed_hip.rendezvous import HostRendezvous
+    with socket.socket() as probe:
+        probe.bind(("127.0.0.1", 0))
+        base = probe.getsockname()[1]
+    foreign = socket.socket()
+    foreign.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    try:
+        foreign.bind(("", base + 1))
+    except OSError:
+        pytest.skip("candidate port already taken")
+    foreign.listen(4)
+    stop = threading.Event()
+
+    def chatter():          # accepts and answers garbage
+        foreign.settimeout(0.2)
+        while not stop.is_set():
+            try:
+                c, _ = foreign.accept()
+                c.sendall(b"HTTP/1.1 400 Bad Request\r\n\r\n")
+                c.close()
+            except OSError:
+                pass
+    th = threading.Thread(target=chatter)
+    th.start()
+    old = {k: os.environ.get(k) for k in ("MASTER_ADDR", "MASTER_PORT")}
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(base))
+    out = {}
+    try:
+        def run(rank):
+            r = HostRendezvous(rank, 2, timeout=30)
+            out[rank] = r.allgather_ints([rank + 10])
+            r.close()
+        ts = [threading.Thread(target=run, args=(k,)) for k in (0, 1)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+    finally:
+        stop.set()
+        th.join()
+        foreign.close()
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert out == {0: [[10], [11]], 1: [[10], [11]]}
+
+
 def test_in_process_multi_device_round_robin(tmp_path):
     """devices=[...]: one handle per device in this process, call groups dealt round-robin, files unchanged"""
     import warnings

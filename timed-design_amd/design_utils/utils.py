@@ -397,18 +397,21 @@ def save_outputs_to_file(
 
 
 def append_outputs(y_true: np.ndarray, predictions_f16: np.ndarray, flat_dataset_map, model: int, model_name: str,
-                   path_to_output: Path = Path.cwd()):
+                   path_to_output: Path = Path.cwd(), opener=None, write_map: bool = True):
     """The file appends of save_outputs_to_file on arrays (no list round trip): ``y_true`` [n, 20] labels,
-    ``predictions_f16`` [n, n_classes] float16 — what ``np.array(y_pred[model], dtype=np.float16)`` yields there."""
+    ``predictions_f16`` [n, n_classes] float16 — what ``np.array(y_pred[model], dtype=np.float16)`` yields there.
+    ``opener(path)`` returns the append handle of a file (default: the file itself, binary append); the sharded
+    predict path passes an in-memory sink and writes the dataset map on rank 0 only (``write_map=False``)."""
     path_to_output = Path(path_to_output)
+    opener = opener or (lambda p: open(p, "ab"))
     if model == 0:
-        with open(path_to_output / "encoded_labels.csv", "ab") as f:
+        with opener(path_to_output / "encoded_labels.csv") as f:
             _savetxt_small_ints(f, np.asarray(y_true))
     path_to_datasetmap = path_to_output / "datasetmap.txt"
-    if not path_to_datasetmap.exists():
+    if write_map and not path_to_datasetmap.exists():
         with open(path_to_datasetmap, "a") as f:
             _savetxt_strings(f, flat_dataset_map)
-    with open(path_to_output / f"{model_name}.csv", "ab") as f:
+    with opener(path_to_output / f"{model_name}.csv") as f:
         textio.savetxt_csv(f, np.asarray(predictions_f16, dtype=np.float16))   # same bytes as np.savetxt(f, predictions, delimiter=",")
 
 

@@ -17,9 +17,11 @@ How a run is organised (all of it invisible in the files, which are byte-identic
   * a loader thread builds group g+1 (reference load_batch, utils.py:487-530) while the GPU computes group g and the
     main thread formats and appends the outputs of group g-1 (th_predict_async / th_predict_wait);
   * ``devices=[0, 1, ...]`` (``--devices 0,1``): one model handle per GPU in this process, groups dealt round-robin;
-  * under ``torch.distributed.run`` (WORLD_SIZE > 1, one process per GPU): the flat dataset map is cut into contiguous
-    per-rank shards, every rank predicts its shard into device memory, ONE gather (RCCL over xGMI, th_comm_gather_rows)
-    assembles the [N, n_classes] matrix on rank 0, which writes every file; other ranks return only the dataset map.
+  * one process per GPU (WORLD_SIZE > 1: ``torch.distributed.run`` or any launcher that sets RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT; the product itself needs no PyTorch): the flat dataset map is cut into contiguous per-rank
+    shards, every rank predicts its shard into device memory AND formats the text of its own rows, ONE gather (RCCL over
+    xGMI, th_comm_gather_rows) assembles the [N, n_classes] matrix on rank 0 for the per-chain sequences, every rank
+    writes its text at its byte offset of the shared files; other ranks return only the dataset map.
 
 Deliberate differences from the reference: the raw rotamer probabilities go to
 ``<model_name>_rot.csv`` (the reference's missing f-string writes a file literally called "{model_name}_rot.csv",
@@ -42,30 +44,76 @@ N_RESIDUE_CLASSES, N_ROTAMER_CLASSES = 20, 338
 
 
 # ---- one model over one dataset --------------------------------------------------------------------------------
+class _TextSink:
+    """Append-only files held in memory: what one rank of a sharded run formats for ITS rows (put into the real files,
+    at this rank's byte offset, by _assemble_shard_files)."""
+
+    class _Handle:
+        def __init__(self, blocks):
+            self._blocks = blocks
+
+        def write(self, data):
+            # textio hands out views of a scratch buffer it reuses: keep a copy
+            self._blocks.append(data.encode("ascii") if isinstance(data, str) else bytes(data))
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *exc):
+            return False
+
+    def __init__(self):
+        self.blocks = {}
+
+    def opener(self, path):
+        return self._Handle(self.blocks.setdefault(str(path), []))
+
+    def size(self, path) -> int:
+        return sum(len(b) for b in self.blocks.get(str(path), ()))
+
+
 class _OutputFiles:
     """The per-model files of reference predict.py:123,145-155 / utils.save_outputs_to_file, appended group by group in
-    row order, and the float16 matrix the reference re-reads from the CSV afterwards (predict.py:163)."""
+    row order, and the float16 matrix the reference re-reads from the CSV afterwards (predict.py:163).  With a ``sink``
+    (sharded runs) the text of this rank's rows is collected in memory instead of being appended to the files."""
 
-    def __init__(self, model_index, model_name, flat_dataset_map, path_to_output, predict_rotamers, codec, resume):
+    def __init__(self, model_index, model_name, flat_dataset_map, path_to_output, predict_rotamers, codec, resume, sink=None):
         self.model_index, self.model_name = model_index, model_name
         self.flat_dataset_map, self.path_to_output = flat_dataset_map, path_to_output
         self.codec = codec
+        self.sink = sink
         self.matrix_path = path_to_output / (f"{model_name}_rot.csv" if predict_rotamers else f"{model_name}.csv")
         # rows already in the file (an earlier, interrupted or repeated run) are part of what the reference reads back
         self.must_reread = resume or (self.matrix_path.exists() and self.matrix_path.stat().st_size > 0)
         self._f16_rows = []
         self._codec_matrix = (np.array([codec[k] for k in range(len(codec))], dtype=np.float16) if codec is not None else None)
 
+    def paths(self):
+        """the files ``append`` writes, in a fixed order (the dataset map is not one of them)"""
+        out = [self.path_to_output / "encoded_labels.csv"] if self.model_index == 0 else []
+        if self.codec is not None:
+            out.append(self.matrix_path)
+        return out + [self.path_to_output / f"{self.model_name}.csv"]
+
+    def _open(self, path):
+        return self.sink.opener(path) if self.sink is not None else open(path, "ab")
+
     def append(self, probs: np.ndarray, labels: np.ndarray):
         f16 = probs.astype(np.float16)
-        self._f16_rows.append(f16)
+        if self.sink is None:
+            self._f16_rows.append(f16)      # (sharded runs take the matrix from the gather instead)
         if self.codec is not None:
-            with open(self.matrix_path, "ab") as f:
+            with self._open(self.matrix_path) as f:
                 textio.savetxt_csv(f, probs)            # = np.savetxt(f, y_pred_batch, delimiter=","), full precision
             f16 = self._codec_matrix[np.argmax(probs, axis=1)]      # one-hot residue of the arg-max rotamer
         # the appends of utils.save_outputs_to_file, on arrays: no list-of-lists round trip under the GIL while the
         # submitter thread is waiting to launch the next group
-        du.append_outputs(labels, f16, self.flat_dataset_map, self.model_index, self.model_name, self.path_to_output)
+        du.append_outputs(labels, f16, self.flat_dataset_map, self.model_index, self.model_name, self.path_to_output,
+                          opener=self._open, write_map=self.sink is None)
+
+    def set_gathered(self, probs: np.ndarray):
+        """sharded runs, rank 0: the [N, n_classes] float32 rows of every rank in map order (the RCCL gather)"""
+        self._f16_rows = [probs.astype(np.float16)]
 
     def prediction_matrix(self) -> np.ndarray:
         """what np.genfromtxt(matrix_path, delimiter=",", dtype=np.float16) would return: '%.18e' text round-trips every
@@ -74,6 +122,38 @@ class _OutputFiles:
         if self.must_reread or not self._f16_rows:
             return textio.loadtxt_f16(self.matrix_path)
         return np.concatenate(self._f16_rows, axis=0)
+
+
+def _assemble_shard_files(files, gather, rank, world):
+    """Sharded runs: every rank formatted the text of its OWN rows (rows are independent, so the files of the 1-rank run
+    are the concatenation of the ranks' texts in rank order).  The ranks tell each other how many bytes each file part
+    has, and every rank writes its part at its byte offset — no text travels through rank 0 (config 4's _rot.csv is
+    8.5 GB of '%.18e' text; formatted and written by one core it would idle eight GPUs).  One node, one file system."""
+    paths = files.paths()
+    mine = [files.sink.size(p) for p in paths]
+    # rank 0 also reports what the files hold already (append semantics of utils.py:758,770: a resumed or repeated run)
+    bases = [(p.stat().st_size if p.exists() else 0) if rank == 0 else 0 for p in paths]
+    table = gather.allgather_ints(mine + bases)             # doubles as the barrier between "stat" and "write"
+    if rank == 0 and not (files.path_to_output / "datasetmap.txt").exists():
+        with open(files.path_to_output / "datasetmap.txt", "a") as f:
+            du._savetxt_strings(f, files.flat_dataset_map)
+    for j, p in enumerate(paths):
+        offset = table[0][len(paths) + j] + sum(table[r][j] for r in range(rank))
+        blocks = files.sink.blocks.get(str(p), [])
+        if not blocks and rank != 0:
+            continue                                        # (rank 0 always creates the file, even an empty one)
+        fd = os.open(p, os.O_WRONLY | os.O_CREAT, 0o666)
+        try:
+            for b in blocks:
+                view = memoryview(b)
+                while len(view):
+                    done = os.pwrite(fd, view, offset)
+                    offset += done
+                    view = view[done:]
+        finally:
+            os.close(fd)
+    files.sink.blocks.clear()
+    gather.barrier()                                        # rank 0 reads the assembled files from here on
 
 
 def _row_groups(n_rows, batch_size, start_batch, frames_per_call):
@@ -263,15 +343,13 @@ def load_dataset_and_predict(
                     # <model>.txt depends on the map only: written on the side thread while the GPU works
                     srb = side.submit(du.convert_dataset_map_for_srb, flat_dataset_map, model_name, path_to_output)
                 if sharded:
-                    done = _predict_sharded(handles[0], gather, rank, world, dataset_path, flat_dataset_map, batch_size,
-                                            start_batch, frames_per_call)
+                    files = _OutputFiles(index, model_name, flat_dataset_map, path_to_output, predict_rotamers, codec,
+                                         resume=start_batch > 0, sink=_TextSink())
+                    gathered = _predict_sharded(handles[0], gather, rank, world, dataset_path, flat_dataset_map, batch_size,
+                                                start_batch, frames_per_call, files)
                     if rank != 0:
                         continue
-                    files = _OutputFiles(index, model_name, flat_dataset_map, path_to_output, predict_rotamers, codec,
-                                         resume=start_batch > 0)
-                    probs, labels, row0 = done
-                    for lo, hi in _row_groups(len(flat_dataset_map), batch_size, start_batch, frames_per_call):
-                        files.append(probs[lo - row0:hi - row0], labels[lo - row0:hi - row0])
+                    files.set_gathered(gathered)
                 else:
                     files = _OutputFiles(index, model_name, flat_dataset_map, path_to_output, predict_rotamers, codec,
                                          resume=start_batch > 0)
@@ -302,11 +380,14 @@ def load_dataset_and_predict(
     return (flat_dataset_map, *outputs)
 
 
-def _predict_sharded(model, gather, rank, world, dataset_path, flat_dataset_map, batch_size, start_batch, frames_per_call):
-    """One process per GPU: rows [row0, N) are cut into ``world`` contiguous shards (timed_hip.distributed.shard_bounds),
-    this rank predicts its shard and the shards are gathered to rank 0 in rank order = map order.
-    With the default transport the probabilities never leave the GPUs before the gather: predict_async writes them
-    into a device buffer and th_comm_gather_rows moves them over xGMI.  Returns (probs, labels, row0) on rank 0."""
+def _predict_sharded(model, gather, rank, world, dataset_path, flat_dataset_map, batch_size, start_batch, frames_per_call, files):
+    """One process per GPU: rows [row0, N) are cut into ``world`` contiguous shards (timed_hip.distributed.shard_bounds);
+    this rank predicts its shard, formats the text of its own rows (``files``, an in-memory sink) while the GPU works,
+    the probability shards are gathered to rank 0 in rank order = map order and the file parts are put
+    together by _assemble_shard_files.  With the default transport the probabilities stay on the GPUs for the gather:
+    predict_async writes them into a device shard buffer, th_comm_gather_rows moves them over xGMI, and the writer
+    thread fetches each group's rows from the shard buffer for formatting.  Returns the [n, n_classes] float32 matrix
+    on rank 0, None elsewhere."""
     from timed_hip import distributed as td
     row0 = min(start_batch * batch_size, len(flat_dataset_map))
     n = len(flat_dataset_map) - row0
@@ -314,51 +395,49 @@ def _predict_sharded(model, gather, rank, world, dataset_path, flat_dataset_map,
     lo, hi = td.shard_bounds(n, world)[rank]
     shard = flat_dataset_map[row0 + lo: row0 + hi]
     groups = [(a, min(a + max(1, int(frames_per_call)), len(shard))) for a in range(0, len(shard), max(1, int(frames_per_call)))]
-    labels = np.zeros((len(shard), N_RESIDUE_CLASSES), dtype=np.float32)
     own_transport = gather is None
     if own_transport:
         gather = td.RcclGather.from_environment(rank, world, model.device)     # raises when RCCL cannot be brought up
     try:
         if isinstance(gather, td.RcclGather):
-            d_local = engine.DeviceBuffer(max(1, len(shard) * model.n_classes * 4), model.device)
-            cursor = [0]
+            width = model.n_classes
+            d_local = engine.DeviceBuffer(max(1, len(shard) * width * 4), model.device)
 
-            def keep(_none, y):
-                labels[cursor[0]:cursor[0] + len(y)] = y
-                cursor[0] += len(y)
+            class _RowsOnDevice:      # a ticket whose rows sit in d_local: result() brings them to the host for formatting
+                def __init__(self, ticket, row, rows):
+                    self.ticket, self.row, self.rows = ticket, row, rows
 
-            class _ToDevice:      # the model facade _run_groups drives: outputs land in d_local at the shard row
+                def result(self):
+                    self.ticket.result()
+                    return d_local.download((self.rows, width), np.float32, offset=self.row * width * 4)
+
+            class _ToDevice:          # the model facade _run_groups drives: outputs land in d_local at the shard row
                 def __init__(self):
                     self.row = 0
 
                 def predict_async(self, X):
-                    t = model.predict_async_device(X, d_local.ptr + self.row * model.n_classes * 4)
+                    t = _RowsOnDevice(model.predict_async_device(X, d_local.ptr + self.row * width * 4), self.row, len(X))
                     self.row += len(X)
                     return t
-            _run_groups([_ToDevice()], dataset_path, shard, groups, keep)
-            d_all = engine.DeviceBuffer(max(1, n * model.n_classes * 4), model.device) if rank == 0 else None
-            gather.gather_rows_device(d_local.ptr, counts, model.n_classes, 0, d_all.ptr if d_all else 0)
-            probs = d_all.download((n, model.n_classes), np.float32) if rank == 0 else None
-            d_lab = engine.DeviceBuffer(max(1, labels.nbytes), model.device)
-            d_lab.upload(labels)
-            d_lab_all = engine.DeviceBuffer(max(1, n * N_RESIDUE_CLASSES * 4), model.device) if rank == 0 else None
-            gather.gather_rows_device(d_lab.ptr, counts, N_RESIDUE_CLASSES, 0, d_lab_all.ptr if d_lab_all else 0)
-            all_labels = d_lab_all.download((n, N_RESIDUE_CLASSES), np.float32) if rank == 0 else None
-        else:                     # host transport (GlooGather): the probabilities are wanted on the host anyway
+            _run_groups([_ToDevice()], dataset_path, shard, groups, files.append)
+            d_all = engine.DeviceBuffer(max(1, n * width * 4), model.device) if rank == 0 else None
+            gather.gather_rows_device(d_local.ptr, counts, width, 0, d_all.ptr if d_all else 0)
+            probs = d_all.download((n, width), np.float32) if rank == 0 else None
+        else:                     # host transport (GlooGather, the CPU tests): rows are on the host already
             local = np.zeros((len(shard), model.n_classes), dtype=np.float32)
             cursor = [0]
 
             def keep(p, y):
                 local[cursor[0]:cursor[0] + len(y)] = p
-                labels[cursor[0]:cursor[0] + len(y)] = y
                 cursor[0] += len(y)
+                files.append(p, y)
             _run_groups([model], dataset_path, shard, groups, keep)
             probs = gather.gather_rows(local, counts, 0)
-            all_labels = gather.gather_rows(labels, counts, 0)
+        _assemble_shard_files(files, gather, rank, world)
     finally:
         if own_transport:
             gather.close()
-    return (probs, all_labels.astype(float), row0) if rank == 0 else None
+    return probs if rank == 0 else None
 
 
 # ---- command line ----------------------------------------------------------------------------------------------

@@ -14,10 +14,13 @@ RANK/LOCAL_RANK/WORLD_SIZE).
 
 Two transports for the single exchange step:
   * ``RcclGather``  device buffers, RCCL grouped send/recv over xGMI through the C ABI
-                    (th_comm_gather_rows) — the production path on a GPU node;
-  * ``GlooGather``  host arrays through torch.distributed's gloo backend — used by the CPU tests
-                    (world_size 2) and usable when the probabilities are wanted on the host anyway.
-Both present ``gather_rows(local, counts, root) -> ndarray | None``.
+                    (th_comm_gather_rows) — the production path on a GPU node.  Its control plane (the
+                    128-byte RCCL id, "did every rank come up", text sizes) is ``timed_hip.rendezvous``:
+                    plain TCP sockets, NO PyTorch anywhere in the product's N > 1 path;
+  * ``GlooGather``  host arrays through torch.distributed's gloo backend — TEST transport: the CPU
+                    suite drives the real predict.py control flow on 2 and 8 gloo ranks with it.
+Both present ``gather_rows(local, counts, root) -> ndarray | None`` plus the small control-plane calls
+``allgather_ints(values) -> [[...] per rank]`` and ``barrier()``.
 """
 from __future__ import annotations
 
@@ -72,6 +75,13 @@ class GlooGather:
         self.dist.gather(buf, None, dst=root, group=self.group)
         return None
 
+    def allgather_ints(self, values: Sequence[int]) -> List[List[int]]:
+        import torch
+        mine = torch.tensor([int(v) for v in values], dtype=torch.int64)
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(parts, mine, group=self.group)
+        return [[int(x) for x in p.tolist()] for p in parts]
+
     def barrier(self):
         self.dist.barrier(group=self.group)
 
@@ -81,44 +91,45 @@ class RcclGather:
     rank 0 with ``RcclGather.new_unique_id()`` and shipped to the other ranks out of band (e.g. a gloo
     broadcast, see bench.py)."""
 
-    def __init__(self, unique_id: bytes, world: int, rank: int, device: int):
+    def __init__(self, unique_id: bytes, world: int, rank: int, device: int, rendezvous=None):
         self._lib = _lib.load()
         self.rank, self.world, self.device = rank, world, device
+        if world > 1 and rendezvous is None:
+            raise ValueError("an RcclGather over more than one rank needs its HostRendezvous (use from_environment)")
+        self.rendezvous = rendezvous
         self._h = C.c_void_p()
         _lib.check(self._lib.th_comm_init(unique_id, world, rank, device, C.byref(self._h)))
 
     @classmethod
-    def from_environment(cls, rank: int, world: int, device: int) -> "RcclGather":
-        """Bring the communicator up inside a ``torch.distributed.run`` job: rank 0 creates the RCCL unique id and it
-        travels to the other ranks through a gloo broadcast (CPU tensors; torch is rendezvous plumbing only).  Raises
-        on every rank when any rank fails — a GPU job never degrades silently to a host exchange."""
-        import torch
-        import torch.distributed as dist
-        if not dist.is_initialized():
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-        ident = bytearray(_lib.TH_COMM_ID_BYTES)
-        err = ""
+    def from_environment(cls, rank: int, world: int, device: int, rendezvous=None) -> "RcclGather":
+        """Bring the communicator up inside a one-process-per-GPU job (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as
+        ``torch.distributed.run`` or any other launcher sets them): rank 0 creates the RCCL unique id and it travels
+        to the other ranks over ``timed_hip.rendezvous`` (TCP; no PyTorch).  Raises on every rank when any rank fails
+        — a GPU job never degrades silently to a host exchange."""
+        from .rendezvous import HostRendezvous
+        own = rendezvous is None
+        rdzv = rendezvous or HostRendezvous(rank, world)
+        ident, err = bytes(_lib.TH_COMM_ID_BYTES), ""
         if rank == 0:
             try:
-                ident = bytearray(cls.new_unique_id())
+                ident = cls.new_unique_id()
             except _lib.TimedHipError as e:
                 err = str(e)
-        t = torch.frombuffer(ident, dtype=torch.uint8).clone()
-        dist.broadcast(t, src=0)
-        ident = bytes(t.numpy().tobytes())
+        ident = rdzv.broadcast(ident)
         comm = None
         if any(ident):
             try:
-                comm = cls(ident, world, rank, device)
+                comm = cls(ident, world, rank, device, rendezvous=rdzv)
             except _lib.TimedHipError as e:
                 err = str(e)
-        ok = torch.tensor([1 if comm is not None else 0])
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) != 1:
+        if rdzv.all_min(1 if comm is not None else 0) != 1:
             if comm is not None:
+                comm.rendezvous = None
                 comm.close()
+            if own:
+                rdzv.close()
             raise RuntimeError(f"RCCL communicator could not be created on every rank (rank {rank}: {err or 'ok'})")
+        comm._owns_rendezvous = own
         return comm
 
     @staticmethod
@@ -132,6 +143,11 @@ class RcclGather:
         _lib.check(self._lib.th_comm_gather_rows(self._h, C.c_void_p(d_local), arr, int(width), int(root),
                                                  C.c_void_p(d_out)))
 
+    def allgather_ints(self, values: Sequence[int]) -> List[List[int]]:
+        if self.world == 1:
+            return [[int(v) for v in values]]
+        return self.rendezvous.allgather_ints(values)
+
     def barrier(self):
         _lib.check(self._lib.th_comm_barrier(self._h))
 
@@ -139,6 +155,9 @@ class RcclGather:
         if self._h:
             self._lib.th_comm_free(self._h)
             self._h = C.c_void_p()
+        if getattr(self, "_owns_rendezvous", False) and self.rendezvous is not None:
+            self.rendezvous.close()
+            self.rendezvous = None
 
     def __del__(self):
         try:
