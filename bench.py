@@ -41,7 +41,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense 
 PEAK_HBM_GBS = 8000.0           # HBM3E spec
 
 
-def cpu_baseline(cfg, weights, topology: str, budget_s: float = 15.0):
+def cpu_baseline(cfg, weights, topology: str, budget_s: float = 15.0, min_s: float = 10.0):
     """Time the oracle (NumPy + multithreaded BLAS) on a bounded sample of the same workload."""
     from oracle import cnn_oracle
     from timed_hip import _lib, synth
@@ -63,7 +63,7 @@ def cpu_baseline(cfg, weights, topology: str, budget_s: float = 15.0):
         t0 = time.perf_counter()
         cnn_oracle.forward(cfg, weights, frames)
         dt = time.perf_counter() - t0
-        if dt >= 10.0 or n >= 8192:
+        if dt >= min_s or n >= 8192:
             break
         n = int(min(8192, max(2 * n, n * budget_s / max(dt, 1e-3))))
     # threads actually used: the BLAS pool NumPy's matmul runs on (im2col gather and elementwise ops are 1 thread)
@@ -81,25 +81,6 @@ def cpu_baseline(cfg, weights, topology: str, budget_s: float = 15.0):
                        f"quota; fp32), {dt:.1f} s wall")
 
 
-def pmc_traffic(label: str, avg_ms: float):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/pmc_latest.json, written by tools/rocpd_summary.py --json from separate --pmc FETCH_SIZE /
-    --pmc WRITE_SIZE runs of this same command; FETCH x2 per the gfx950 correction).  Matched on the
-    kernel instantiation and launch duration (same chunk size); None when nothing matches."""
-    import re
-    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    m = re.search(r"\[(k_conv_[a-z0-9]+<[^>]*>)\]", label)
-    if not m or not os.path.exists(path):
-        return None
-    best = None
-    for k in json.load(open(path))["kernels"]:
-        if k["kernel"] == m.group(1) and "FETCH_SIZE_bytes" in k and "WRITE_SIZE_bytes" in k and "avg_us" in k:
-            err = abs(k["avg_us"] / 1e3 - avg_ms) / avg_ms
-            if err < 0.15 and (best is None or err < best[0]):
-                best = (err, k["FETCH_SIZE_bytes"] + k["WRITE_SIZE_bytes"])
-    return best[1] if best else None
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -113,6 +94,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the e2e / sampler / other-topology legs (N=1 only)")
     ap.add_argument("--e2e-frames", type=int, default=20000, help="frames in the synthetic frame packs of the predict.py leg")
     ap.add_argument("--e2e-hdf5-frames", type=int, default=2000, help="frames in the synthetic gzip .hdf5 of the predict.py leg")
+    ap.add_argument("--e2e-rotamer-frames", type=int, default=125000,
+                    help="uint8 frames in the predict.py --predict_rotamers leg (config 4's per-GPU share: 1 M / 8)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 --pmc child passes (roofline.traffic stays null)")
     ap.add_argument("--other-frames", type=int, default=40960, help="frames for the densecpd / timed_rotamer legs")
     args = ap.parse_args()
 
@@ -267,9 +251,7 @@ def main():
             frames_per_launch = n * args.steps / dom["launches"]
             achieved = dom["flops"] * frames_per_launch / (avg_ms * 1e-3) / 1e12
             line["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(dom["label"], avg_ms),
-                                "traffic_source": "profiles/pmc_latest.json: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                                                  "this command (looked up by kernel name and launch duration, not measured in this run)",
+                                "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
                                 "kernel": dom["label"], "avg_launch_ms": avg_ms, "launches": dom["launches"],
                                 "measured": "HIP events around every launch of this kernel inside the timed region",
                                 "exec_tflops": dom["exec_flops"] * frames_per_launch / (avg_ms * 1e-3) / 1e12}
@@ -290,13 +272,30 @@ def main():
             import bench_legs
             model.profile(0)
             t_legs = time.perf_counter()
+            others = [t for t in ("densecpd", "timed_rotamer") if t != args.topology]
+            # HBM bytes of every kernel of every topology, measured now (two rocprofv3 --pmc child passes on this build)
+            pmc = bench_legs.pmc_traffic_inrun([args.topology] + others, args.chunk) if not args.no_pmc else {"error": "--no-pmc"}
+            line["pmc"] = {k: v for k, v in pmc.items() if k in ("error", "source")}
+            mine = pmc.get(args.topology, {})
+            if "roofline" in line and mine:
+                rl = line["roofline"]
+                rl["traffic"] = mine.get("steps", {}).get(rl["kernel"])
+                rl["traffic_frames"] = args.chunk
+                rl["traffic_source"] = pmc.get("source")
+                dom_step = next(s for s in model.steps() if s["label"] == rl["kernel"])
+                rl["algorithmic_bytes"] = dom_step["bytes"] * args.chunk
+                line["hbm"]["model_traffic_per_chunk"] = mine.get("model")
+                line["hbm"]["model_algorithmic_bytes_per_chunk"] = algo_bytes * args.chunk
+                for k in line.get("kernels", []):
+                    k["traffic_per_chunk"] = mine.get("steps", {}).get(k["label"])
             e2e = bench_legs.host_resident(model, d_frames.ptr, n, fps)
-            e2e.update(bench_legs.predict_py_e2e(cfg, weights, n_pack=args.e2e_frames, n_hdf5=args.e2e_hdf5_frames))
+            e2e.update(bench_legs.predict_py_e2e(cfg, weights, n_pack=args.e2e_frames, n_hdf5=args.e2e_hdf5_frames,
+                                                 n_rotamer=args.e2e_rotamer_frames))
             line["e2e"] = e2e
             line["sampler"] = bench_legs.sampler_config5(device)
-            others = [t for t in ("densecpd", "timed_rotamer") if t != args.topology]
-            line["other_configs"] = [bench_legs.topology_rate(t, device, d_frames.ptr, min(n, args.other_frames), args.chunk)
-                                     for t in others]
+            base = None if args.no_cpu_baseline else (lambda c, w, t: cpu_baseline(c, w, t, budget_s=8.0, min_s=5.0))
+            line["other_configs"] = [bench_legs.topology_rate(t, device, d_frames.ptr, min(n, args.other_frames), args.chunk,
+                                                              traffic=pmc.get(t), cpu_baseline=base) for t in others]
             line["extras_wall_s"] = time.perf_counter() - t_legs
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())

@@ -196,6 +196,20 @@ int th_sampler_draw(th_sampler* s, int64_t n_keys, const int64_t* row_off, int64
  * 'nan') into out; dtype is TH_F16 (preformatted table), TH_F32 or TH_F64.  Returns the number of bytes written,
  * or a negative TH_E* code (cap too small: 28 bytes per value always suffice). */
 int64_t th_format_csv(const void* data, int dtype, int64_t n, int64_t k, char* out, int64_t cap);
+/* argmax + residue letter per row: replaces max_idx = np.argmax(prediction_matrix, axis=1) and the per-residue string
+ * appends of extract_sequence_from_pred_matrix — design_utils/utils.py:659, :689-692.  matrix [n, k] of dtype TH_F16 /
+ * TH_F32 / TH_F64; np.argmax rules (first maximum; the first NaN of a row wins).  letters_out[i] = col_letters[argmax_i]
+ * (col_letters: k bytes, the one-letter code of every probability column); idx_out (int32[n]) optional; either output
+ * may be NULL.  Host code, rows split over host threads. */
+/* dataset-map text -> string table: replaces np.genfromtxt(dataset_map_path, delimiter=",", dtype="str") — predict.py:99.
+ * th_csv_shape validates plain ASCII text with the same number of `delim`-separated, non-empty fields on every line and
+ * reports (rows, cols, longest field); TH_EUNSUP for anything NumPy treats specially (comments, quotes, '\r', non-ASCII,
+ * ragged or blank lines, blank-padded fields): the caller then falls back to NumPy.  th_csv_fill writes the fields as
+ * UCS-4 code units into out[rows][cols][width], zero padded — the memory of a NumPy '<U{width}' array.  Host code. */
+int th_csv_shape(const char* text, int64_t len, char delim, int64_t* rows_out, int* cols_out, int* width_out);
+int th_csv_fill(const char* text, int64_t len, char delim, int64_t rows, int cols, int width, uint32_t* out);
+int th_argmax_letters(const void* matrix, int dtype, int64_t n, int64_t k, const char* col_letters, char* letters_out,
+                      int32_t* idx_out);
 
 /* ---- frame ingest: replaces the per-residue h5py reads of load_batch — design_utils/utils.py:514-529.  Host code
  * only.  `file` is the whole HDF5 file in memory (an mmap), `base` its superblock offset.  For n_datasets chunked

@@ -66,3 +66,66 @@ def test_loadtxt_f16_equals_genfromtxt(tmp_path):
     one = tmp_path / "one.csv"
     one.write_bytes(textio.format_csv(p16[:1]))
     assert textio.loadtxt_f16(one).shape == (1, 20)              # np.atleast_2d of the reference's re-read
+
+
+# ---- native argmax -> letters and the dataset-map tokenizer (host code: run without a GPU) ------------------------------
+def test_argmax_letters_follows_numpy_rules():
+    """reference design_utils/utils.py:659 (np.argmax: first maximum, a NaN is the maximum) + :689-692"""
+    rng = np.random.default_rng(0)
+    letters = "ACDEFGHIKLMNPQRSTVWY"
+    for dt in (np.float16, np.float32, np.float64):
+        m = rng.random((5000, 20)).astype(dt)
+        m[::7, 3] = m[::7].max(1)                    # ties: the first maximum wins
+        m[5, 11] = np.nan
+        m[6, [2, 9]] = np.nan                        # the first NaN wins
+        m[7] = 0
+        m[8, 0] = np.inf
+        m[9] = -np.inf
+        got = textio.argmax_letters(m, letters)
+        want = np.array(list(letters))[np.argmax(m, axis=1)]
+        assert got.dtype == np.dtype("S1") and np.array_equal(got.astype(str), want), dt
+    wide = rng.random((300, 338)).astype(np.float32)
+    cats = [letters[i % 20] for i in range(338)]
+    assert np.array_equal(textio.argmax_letters(wide, cats).astype(str), np.array(cats)[wide.argmax(1)])
+    assert textio.argmax_letters(np.empty((0, 20), np.float32), letters).shape == (0,)
+    with pytest.raises(ValueError):
+        textio.argmax_letters(wide, letters)
+
+
+def test_string_table_reader_equals_genfromtxt(tmp_path):
+    rows = [("1ubq", "A", str(i), "MET") for i in range(1, 77)] + [("2xyz_0", "B", "-5", "GLY"), ("7long_name", "AA", "1000", "TRP")]
+    p = tmp_path / "datasetmap.txt"
+    np.savetxt(p, np.array(rows), delimiter=",", fmt="%s")
+    got = textio.read_string_table(p)
+    want = np.atleast_2d(np.genfromtxt(p, delimiter=",", dtype="str"))
+    assert got.dtype == want.dtype and np.array_equal(got, want)
+    p.write_text("a,b,c,d")                                           # one row, no final newline
+    assert np.array_equal(textio.read_string_table(p), np.atleast_2d(np.genfromtxt(p, delimiter=",", dtype="str")))
+    # anything NumPy treats specially is declined (the caller falls back to NumPy)
+    for text in ("a,b\n#c,d\n", "a,b\nc\n", "a,,b\n", "a,b\r\nc,d\r\n", "a, b\nc,d\n", "a,b\n\nc,d\n", "é,b\n", ""):
+        p.write_text(text)
+        assert textio.read_string_table(p) is None, repr(text)
+
+
+def test_extract_sequences_plan_and_lazy_probabilities():
+    """the vectorised / native extract_sequence_from_pred_matrix against a literal transcription of the reference's loop
+    semantics (utils.py:660-692) on a map with a key that comes back later, and the lazy probability mapping"""
+    from design_utils import utils
+    rng = np.random.default_rng(3)
+    fmap = np.array([("1abc", "A", str(i), "ALA") for i in range(4)] + [("1abc", "B", str(i), "GLY") for i in range(3)] +
+                    [("1abc", "A", str(i), "TRP") for i in range(10, 12)])
+    pm = rng.random((9, 20)).astype(np.float16)
+    seq, prob, real, _, _ = utils.extract_sequence_from_pred_matrix(fmap, pm, None)
+    letters = np.array(list("ACDEFGHIKLMNPQRSTVWY"))
+    pick = letters[pm.argmax(1)]
+    assert list(seq) == ["1abcA", "1abcB"] and seq["1abcA"] == "".join(pick[[0, 1, 2, 3, 7, 8]]) and seq["1abcB"] == "".join(pick[4:7])
+    assert real == {"1abcA": "AAAAWW", "1abcB": "GGG"}
+    assert list(prob) == ["1abcA", "1abcB"] and len(prob) == 2 and "1abcB" in prob and "zzz" not in prob
+    assert prob["1abcB"] == [list(r) for r in pm[4:7]] and isinstance(prob["1abcB"][0], list)
+    assert np.array_equal(prob.matrix("1abcA"), pm[[0, 1, 2, 3, 7, 8]])
+    assert dict(prob.items()) == {"1abcA": [list(r) for r in pm[[0, 1, 2, 3, 7, 8]]], "1abcB": [list(r) for r in pm[4:7]]}
+    with pytest.raises(KeyError):
+        prob["nope"]
+    # "<pdb> <count>" maps
+    s2, p2, r2, _, _ = utils.extract_sequence_from_pred_matrix(np.array([("k1", "4"), ("k2", "3"), ("k1", "2")]), pm, None)
+    assert s2 == {"k1": "".join(pick[[0, 1, 2, 3, 7, 8]]), "k2": "".join(pick[4:7])} and r2 == {"k1": "", "k2": ""}

@@ -105,7 +105,9 @@ def _sample_keys(keys, sample_n: int, pdb_to_probability: dict, rotamer_categori
     keys = list(keys)
     if not keys:
         return {}
-    mats = [np.array(pdb_to_probability[k]) for k in keys]          # what the reference builds per sample (:125)
+    # what the reference builds per sample (:125); a LazyProbabilities mapping hands the rows out as an array directly
+    as_matrix = getattr(pdb_to_probability, "matrix", None)
+    mats = [np.array(as_matrix(k) if as_matrix else pdb_to_probability[k]) for k in keys]
     for k, m in zip(keys, mats):
         if m.ndim != 2 or m.shape[0] == 0:
             raise ValueError(f"{k}: expected a non-empty (n_residues, n_categories) probability matrix, got shape {m.shape}")

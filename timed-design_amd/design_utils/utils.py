@@ -14,6 +14,7 @@ from __future__ import annotations
 import os
 import typing as t
 import warnings
+from collections.abc import Mapping
 from itertools import product
 from pathlib import Path
 
@@ -120,6 +121,26 @@ def create_flat_dataset_map(
                     flat_dataset_map.append((pdb_code, chain_id, str(residue_id), residue_label))
                     training_set_pdbs.add(pdb_code)
     return flat_dataset_map, training_set_pdbs
+
+
+def read_flat_dataset_map(dataset_map_path) -> np.ndarray:
+    """``np.genfromtxt(dataset_map_path, delimiter=",", dtype="str")`` of reference predict.py:99 as a 2-D array: plain
+    files through the native tokenizer (th_csv_shape / th_csv_fill: 100 k rows in milliseconds instead of 0.2 s),
+    anything else through NumPy itself."""
+    table = textio.read_string_table(dataset_map_path, ",")
+    if table is None:
+        table = np.atleast_2d(np.genfromtxt(dataset_map_path, delimiter=",", dtype="str"))
+    return table
+
+
+def flat_dataset_map_array(frame_dataset: Path, filter_list: t.Sequence[str] = ()) -> np.ndarray:
+    """create_flat_dataset_map as a 2-D string array (what predict.py slices): a frame pack's map is handed out as the
+    array the pack was loaded with — no detour through 100 k tuples."""
+    from timed_hip import framepack
+    if framepack.is_pack(frame_dataset) and not filter_list:
+        return _frame_pack(frame_dataset).flat_map
+    flat, _ = create_flat_dataset_map(frame_dataset, list(filter_list))
+    return np.array(flat)
 
 
 def _chain_labels(dataset_file, chain_group, residue_n):
@@ -319,31 +340,81 @@ def _column_letters(rotamers_categories) -> np.ndarray:
     return np.array([one_letter[name.split("_")[0]] for name in rotamers_categories])
 
 
-def _row_groups_of_map(flat_dataset_map) -> t.List[t.Tuple[str, np.ndarray, t.Optional[np.ndarray]]]:
-    """(key, matrix rows, three-letter labels or None) per key, keys in first-seen order, rows in map order.
-    4-column maps: one matrix row per map row, key = pdb + chain, repeated keys are merged.  "<pdb> <count>" maps: every
-    map row takes the next ``count`` matrix rows; a key that appears again continues its entry."""
-    fmap = np.asarray(flat_dataset_map)
-    groups: t.Dict[str, t.List] = {}
-    if fmap.shape[1] == 4:
-        keys = np.char.add(fmap[:, 0].astype(str), fmap[:, 1].astype(str))
-        uniq, first_seen, inverse = np.unique(keys, return_index=True, return_inverse=True)
-        by_key = np.argsort(inverse, kind="stable")                    # matrix rows grouped by key, map order inside
-        bounds = np.concatenate([[0], np.cumsum(np.bincount(inverse))])
-        for u in np.argsort(first_seen, kind="stable"):
-            rows = by_key[bounds[u]:bounds[u + 1]]
-            groups[str(uniq[u])] = [rows, fmap[rows, 3]]
-        return [(k, v[0], v[1]) for k, v in groups.items()]
-    cursor = 0
-    for key, count in fmap:
-        key, count = str(key), int(count)
-        rows = np.arange(cursor, cursor + count)
-        cursor += count
-        if key in groups:
-            groups[key][0] = np.concatenate([groups[key][0], rows])
+class SequencePlan:
+    """Everything extract_sequence_from_pred_matrix derives from the dataset map ALONE: the keys in first-seen order,
+    the matrix rows of every key (map order) and the true sequences.  predict.py builds it on a side thread while the
+    GPU works, so that only the arg-max and the string joins remain once the probabilities exist."""
+
+    def __init__(self, flat_dataset_map):
+        fmap = np.asarray(flat_dataset_map)
+        if fmap.ndim != 2:
+            fmap = np.atleast_2d(fmap)
+        self.old_datasetmap = fmap.shape[1] == 4                     # re-derived from the map width (reference :662)
+        self.n_rows = 0
+        self.keys: t.List[str] = []
+        self.runs: t.Dict[str, t.List[t.Tuple[int, int]]] = {}       # key -> [(lo, hi), ...] matrix row ranges, in order
+        self.real: t.Dict[str, str] = {}
+        if self.old_datasetmap:
+            n = fmap.shape[0]
+            self.n_rows = n
+            pdb, chain = fmap[:, 0], fmap[:, 1]
+            # consecutive rows of one pdb + chain are one run; a key that comes back later continues its entry
+            change = np.flatnonzero((pdb[1:] != pdb[:-1]) | (chain[1:] != chain[:-1])) + 1
+            starts = np.concatenate([[0], change]).astype(np.int64)
+            ends = np.concatenate([change, [n]]).astype(np.int64)
+            run_keys = np.char.add(pdb[starts].astype(str), chain[starts].astype(str))
+            one_letter = {three: one for one, three in standard_amino_acids.items()}
+            uniq, inverse = np.unique(fmap[:, 3], return_inverse=True)
+            real_letters = np.array([one_letter[str(u)] for u in uniq], dtype="S1")[inverse] if n else np.empty(0, "S1")
+            real_parts: t.Dict[str, t.List[bytes]] = {}
+            for key, lo, hi in zip(run_keys.tolist(), starts.tolist(), ends.tolist()):
+                self.runs.setdefault(key, []).append((lo, hi))
+                real_parts.setdefault(key, []).append(real_letters[lo:hi].tobytes())
+            self.keys = list(self.runs)
+            self.real = {k: b"".join(v).decode("ascii") for k, v in real_parts.items()}
         else:
-            groups[key] = [rows, None]
-    return [(k, v[0], None) for k, v in groups.items()]
+            cursor = 0
+            for key, count in fmap:
+                key, count = str(key), int(count)
+                self.runs.setdefault(key, []).append((cursor, cursor + count))
+                cursor += count
+            self.n_rows = cursor
+            self.keys = list(self.runs)
+            self.real = {k: "" for k in self.keys}                   # "<pdb> <count>" maps carry no true sequence
+
+    def rows(self, key) -> t.Union[slice, np.ndarray]:
+        runs = self.runs[key]
+        if len(runs) == 1:
+            return slice(runs[0][0], runs[0][1])
+        return np.concatenate([np.arange(lo, hi) for lo, hi in runs])
+
+
+class LazyProbabilities(Mapping):
+    """``pdb_to_probability`` of the reference — {key: [list(row), ...]} (utils.py:646,688-690) — with the lists built on
+    first access of a key: a 100 k-residue run holds 2 M Python floats that predict.py's caller rarely looks at.
+    ``matrix(key)`` gives the same rows as an array without the list round trip (sample.py uses it)."""
+
+    def __init__(self, prediction_matrix: np.ndarray, plan: SequencePlan):
+        self._matrix, self._plan, self._lists = prediction_matrix, plan, {}
+
+    def matrix(self, key) -> np.ndarray:
+        return self._matrix[self._plan.rows(key)]
+
+    def __getitem__(self, key):
+        if key not in self._lists:
+            if key not in self._plan.runs:
+                raise KeyError(key)
+            self._lists[key] = [list(r) for r in self.matrix(key)]
+        return self._lists[key]
+
+    def __iter__(self):
+        return iter(self._plan.keys)
+
+    def __len__(self):
+        return len(self._plan.keys)
+
+    def __contains__(self, key):
+        return key in self._plan.runs
 
 
 def extract_sequence_from_pred_matrix(
@@ -352,21 +423,31 @@ def extract_sequence_from_pred_matrix(
     rotamers_categories: t.Optional[t.List[str]],
     old_datasetmap: bool = False,
     is_consensus: bool = False,
+    plan: t.Optional[SequencePlan] = None,
 ) -> (dict, dict, dict, dict, dict):
     """reference utils.py:616-723.  argmax (first maximum) -> one-letter sequence per key; key = pdb+chain for 4-column
     maps, the map's own key for "<pdb> <count>" maps (which carry no true sequence: it stays "").  ``old_datasetmap`` is
     re-derived from the map width exactly as the reference does (:662).  With ``is_consensus`` the states
     "<pdb>_<n>..." of an NMR ensemble are merged by the reference's RUNNING PAIRWISE average (acc+new)/2 (:699-705) —
-    not an arithmetic mean."""
-    one_letter = {three: one for one, three in standard_amino_acids.items()}
+    not an arithmetic mean.
+
+    The arg-max and the residue letters come from one native pass (th_argmax_letters); ``pdb_to_probability`` is a
+    Mapping whose list-of-lists values are built when a key is first read (LazyProbabilities).  ``plan`` (opt-in): a
+    SequencePlan of the same map prepared earlier."""
     letters = _column_letters(rotamers_categories)
     prediction_matrix = np.asarray(prediction_matrix)
-    predicted = letters[np.argmax(prediction_matrix, axis=1)]
-    pdb_to_sequence, pdb_to_probability, pdb_to_real_sequence = {}, {}, {}
-    for key, rows, labels in _row_groups_of_map(flat_dataset_map):
-        pdb_to_sequence[key] = "".join(predicted[rows])
-        pdb_to_probability[key] = [list(r) for r in prediction_matrix[rows]]
-        pdb_to_real_sequence[key] = "".join(one_letter[str(lab)] for lab in labels) if labels is not None else ""
+    if plan is None:
+        plan = SequencePlan(flat_dataset_map)
+    if prediction_matrix.ndim == 2 and prediction_matrix.dtype in (np.float16, np.float32, np.float64) and \
+            all(len(str(c)) == 1 and ord(str(c)) < 128 for c in letters):
+        predicted = textio.argmax_letters(prediction_matrix, letters)
+        join = lambda rows: predicted[rows].tobytes().decode("ascii")      # noqa: E731
+    else:       # multi-character column names or an unusual matrix dtype: NumPy
+        chosen = letters[np.argmax(prediction_matrix, axis=1)]
+        join = lambda rows: "".join(chosen[rows])                          # noqa: E731
+    pdb_to_sequence = {key: join(plan.rows(key)) for key in plan.keys}
+    pdb_to_probability = LazyProbabilities(prediction_matrix, plan)
+    pdb_to_real_sequence = dict(plan.real)
     if not is_consensus:
         return pdb_to_sequence, pdb_to_probability, pdb_to_real_sequence, None, None
     # consecutive keys with the same prefix before the first "_" are states of one structure
@@ -374,7 +455,7 @@ def extract_sequence_from_pred_matrix(
     previous = None
     for key in pdb_to_sequence:
         structure = key.split("_")[0]
-        state = np.array(pdb_to_probability[key])
+        state = np.array(pdb_to_probability.matrix(key))
         pdb_to_consensus_prob[structure] = state if structure != previous else (pdb_to_consensus_prob[structure] + state) / 2
         previous = structure
     pdb_to_consensus = {structure: "".join(letters[np.argmax(prob, axis=1)]) for structure, prob in pdb_to_consensus_prob.items()}
@@ -445,13 +526,23 @@ def convert_dataset_map_for_srb(flat_dataset_map: list, model_name: str, path_to
     """reference utils.py:533-566: PDBench map "<pdb> <count>" (chain appended to 4-letter codes,
     "_0..." state suffix stripped) after three header lines."""
     count_dict: dict = {}
-    for pdb, chain, _res_idx, _ in flat_dataset_map:
+    fmap = np.asarray(flat_dataset_map)
+    if fmap.ndim == 2 and fmap.shape[1] == 4 and fmap.shape[0] and fmap.dtype.kind == "U":
+        # the same counts from runs of equal (pdb, chain): one dictionary update per run instead of per residue
+        pdb, chain = fmap[:, 0], fmap[:, 1]
+        change = np.flatnonzero((pdb[1:] != pdb[:-1]) | (chain[1:] != chain[:-1])) + 1
+        starts = np.concatenate([[0], change])
+        lengths = np.diff(np.concatenate([starts, [fmap.shape[0]]]))
+        runs = zip(pdb[starts].tolist(), chain[starts].tolist(), lengths.tolist())
+    else:
+        runs = ((pdb, chain, 1) for pdb, chain, _res_idx, _ in flat_dataset_map)
+    for pdb, chain, count in runs:
         pdb, chain = str(pdb), str(chain)
         if "_0" in pdb:
             pdb = pdb.split("_0")[0]
         if len(pdb) == 4:
             pdb += chain
-        count_dict[pdb] = count_dict.get(pdb, 0) + 1
+        count_dict[pdb] = count_dict.get(pdb, 0) + count
     with open(Path(path_to_output) / f"{model_name}.txt", "w") as d:
         d.write("ignore_uncommon False\ninclude_pdbs\n##########\n")
         for pdb, count in count_dict.items():

@@ -318,11 +318,13 @@ def load_dataset_and_predict(
     side = ThreadPoolExecutor(max_workers=1, thread_name_prefix="predict_side")
     pending_handles = side.submit(lambda m=models[0]: [loader(Path(m), device=d) for d in device_ids]) if models else None
     if Path(dataset_map_path).exists():
-        flat_dataset_map = np.atleast_2d(np.genfromtxt(dataset_map_path, delimiter=",", dtype="str"))
+        flat_dataset_map = du.read_flat_dataset_map(dataset_map_path)
     else:
         excluded = du.get_pdb_keys_to_filter(blacklist) if blacklist else []
-        flat_dataset_map, _ = du.create_flat_dataset_map(dataset_path, excluded)
-    flat_dataset_map = np.array(flat_dataset_map)       # (the reference converts after the first model; rows slice as arrays)
+        flat_dataset_map = du.flat_dataset_map_array(dataset_path, excluded)
+    # (the reference converts to an array after the first model; rows slice as arrays)
+    # what the sequence extraction needs from the map alone is prepared on the side thread, under the GPU's work
+    plan = side.submit(du.SequencePlan, flat_dataset_map) if rank == 0 else None
     old_datasetmap = len(flat_dataset_map[0]) == 4
     codec, flat_categories = du.get_rotamer_codec() if predict_rotamers else (None, None)
     outputs = (None,) * 5
@@ -362,7 +364,7 @@ def load_dataset_and_predict(
                     srb.result()
             outputs = du.extract_sequence_from_pred_matrix(
                 flat_dataset_map, files.prediction_matrix(), rotamers_categories=flat_categories if predict_rotamers else None,
-                old_datasetmap=old_datasetmap, is_consensus=is_consensus)
+                old_datasetmap=old_datasetmap, is_consensus=is_consensus, plan=plan.result())
             pdb_to_sequence, _prob, pdb_to_real_sequence, pdb_to_consensus, pdb_to_consensus_prob = outputs
             du.save_dict_to_fasta(pdb_to_sequence, model_name, path_to_output)
             du.save_dict_to_fasta(pdb_to_real_sequence, "dataset", path_to_output)

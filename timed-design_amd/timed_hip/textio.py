@@ -66,3 +66,38 @@ def loadtxt_f16(path) -> np.ndarray:
         return np.loadtxt(path, delimiter=",", dtype=np.float64, ndmin=2).astype(np.float16)
     except ValueError:      # ragged / missing fields: let genfromtxt apply its own rules
         return np.atleast_2d(np.genfromtxt(path, delimiter=",", dtype=np.float16))
+
+
+def read_string_table(path, delimiter: str = ",") -> "np.ndarray | None":
+    """The rows of a plain delimiter-separated text file as a 2-D NumPy string array — what
+    ``np.atleast_2d(np.genfromtxt(path, delimiter=delimiter, dtype=str))`` returns (reference predict.py:99 reads
+    datasetmap.txt that way) — parsed natively (th_csv_shape / th_csv_fill).  None when the file is anything but plain
+    (comments, quotes, blank or ragged lines, non-ASCII …): the caller then lets NumPy apply its own rules."""
+    with open(path, "rb") as f:
+        text = f.read()
+    lib = _lib.load()
+    rows, cols, width = C.c_int64(), C.c_int(), C.c_int()
+    d = delimiter.encode("ascii")
+    if lib.th_csv_shape(text, len(text), d, C.byref(rows), C.byref(cols), C.byref(width)) != 0:
+        return None
+    out = np.empty((rows.value, cols.value), dtype=f"<U{width.value}")
+    if lib.th_csv_fill(text, len(text), d, rows.value, cols.value, width.value, out.ctypes.data_as(C.c_void_p)) != 0:
+        return None
+    return out
+
+
+def argmax_letters(matrix: np.ndarray, column_letters) -> np.ndarray:
+    """'S1' array: the one-letter code of each row's arg-max column (np.argmax rules: first maximum, first NaN wins) —
+    reference design_utils/utils.py:659,689-692 — in one native pass over the float16/32/64 matrix."""
+    a = np.asarray(matrix)
+    if a.ndim != 2 or a.dtype not in _DTYPES:
+        raise TypeError("argmax_letters takes a 2-D float16/float32/float64 matrix")
+    a = np.ascontiguousarray(a)
+    letters = "".join(str(c) for c in column_letters).encode("ascii")
+    if len(letters) != a.shape[1]:
+        raise ValueError(f"need one letter per column ({a.shape[1]}), got {len(letters)}")
+    out = np.empty(a.shape[0], dtype="S1")
+    if a.shape[0]:
+        _lib.check(_lib.load().th_argmax_letters(a.ctypes.data_as(C.c_void_p), _DTYPES[a.dtype], a.shape[0], a.shape[1], letters,
+                                                 out.ctypes.data_as(C.c_void_p), None))
+    return out

@@ -103,7 +103,7 @@ def make_frame_pack(stem, n, gaussian=True, seed=1):
                    make_frame_dataset_ver=""), open(stem + ".meta.json", "w"))
 
 
-def predict_py_e2e(cfg, weights, n_pack=20000, n_hdf5=2000, batch_size=500, workdir=None):
+def predict_py_e2e(cfg, weights, n_pack=20000, n_hdf5=2000, batch_size=500, workdir=None, n_rotamer=0):
     """predict.load_dataset_and_predict wall clock (model load, dataset map, load_batch, H2D, kernels, every output file,
     FASTA extraction) on (a) a float32 frame pack, (b) a uint8 (boolean) frame pack, (c) an aposteriori-style gzip
     .hdf5 written by real h5py when the image's conda interpreter is present."""
@@ -141,6 +141,35 @@ def predict_py_e2e(cfg, weights, n_pack=20000, n_hdf5=2000, batch_size=500, work
             make_frame_pack(stem, n_pack, gaussian=False)
             run(stem + ".framepack", "predict_py_framepack_u8", n_pack)
             os.remove(stem + ".frames.npy")
+        if n_rotamer > 0:
+            # BASELINE config 4's per-GPU share (1 M frames / 8 GPUs = 125 k) through `predict.py --predict_rotamers` on
+            # ONE GPU, every file written: the 338-class model, the full-precision _rot.csv (125 k x 338 '%.18e' values,
+            # ~1 GB of text), the codec one-hot <model>.csv, labels, map, FASTA.  uint8 (boolean) frames keep the
+            # synthetic pack at 7 GB; in the 8-GPU run every rank formats and writes its own shard like this.
+            from timed_hip import synth
+            cfg_r, w_r = synth.TOPOLOGIES["timed_rotamer"]()
+            mpr = Path(td) / "TIMED_rotamer.pack"
+            mpr.write_bytes(pack.keras_to_pack(cfg_r, w_r))
+            stem = os.path.join(td, "synth_rot_u8")
+            t0 = time.perf_counter()
+            make_frame_pack(stem, n_rotamer, gaussian=False)
+            res["predict_py_rotamer_pack_write_s"] = time.perf_counter() - t0
+            out = Path(td) / "out_rotamer"
+            out.mkdir()
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                t0 = time.perf_counter()
+                predict.load_dataset_and_predict([mpr], stem + ".framepack", batch_size=batch_size, dataset_map_path=out / "datasetmap.txt",
+                                                 predict_rotamers=True, path_to_output=out)
+                dt = time.perf_counter() - t0
+            assert sum(1 for _ in open(out / "TIMED_rotamer.csv")) == n_rotamer
+            res["predict_py_rotamer_frames"] = n_rotamer
+            res["predict_py_rotamer_fps"] = n_rotamer / dt
+            res["predict_py_rotamer_s"] = dt
+            res["predict_py_rotamer_rot_csv_MB"] = os.path.getsize(out / "TIMED_rotamer_rot.csv") / 1e6
+            os.remove(stem + ".frames.npy")
+            for f in out.iterdir():
+                f.unlink()
         # BASELINE config 1 (the reference's own CPU-runnable case: predict.py on the 1ubq structure of its tests
         # directory, tests/testing_files/1ubq.pdb1.gz): here the structure file is voxelised on the GPU (row f-4, parity
         # unpinned against aposteriori) and predicted with a 5-channel TIMED-synth; beside it the CPU oracle on the very
@@ -184,6 +213,19 @@ def predict_py_e2e(cfg, weights, n_pack=20000, n_hdf5=2000, batch_size=500, work
             res["predict_py_hdf5_gzip_f64_fps"] = None
             res["hdf5_note"] = "no h5py in this image to write the synthetic .hdf5"
     return res
+
+
+def _sampler_pool_baseline(n_res, n_samples, seed, usable):
+    """BASELINE.md B3 under multiprocessing.Pool: tools/sampler_pool_baseline.py in a child process of its own (no HIP
+    context to fork, bounded by a timeout)."""
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sampler_pool_baseline.py"), str(n_res), str(n_samples),
+                            str(seed), str(usable)], capture_output=True, text=True, timeout=180)
+        if r.returncode != 0:
+            return {"error": r.stderr[-300:]}
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:        # a baseline leg never takes the bench line down
+        return {"error": repr(e)}
 
 
 # ---- BASELINE config 5: the sampler ----------------------------------------------------------------------------------
@@ -243,14 +285,106 @@ def sampler_config5(device=0, n_res=300, n_samples=1000, temps=(0.1, 0.5, 1.0), 
         assert exact, f"sampler indices differ from the oracle at T={t}"
     sm.close()
     out["cpu_cores"] = 1
+    from timed_hip import _lib
+    out["cpu_pool"] = _sampler_pool_baseline(n_res, n_samples, seed, max(1, int(_lib.load().th_host_cpus())))
     out["note"] = "launch-latency bound (a few microseconds of device work per run): no roofline fraction is meaningful"
     return out
 
 
+# ---- HBM traffic of every kernel, measured in THIS run -------------------------------------------------------------
+def pmc_traffic_inrun(topologies, chunk, timeout=240):
+    """Two rocprofv3 child runs of tools/pmc_child.py (`--kernel-trace --pmc FETCH_SIZE`, then `--pmc WRITE_SIZE`: separate
+    passes, as /opt/skills/guides/MI355X_MICROARCH.md prescribes) on the library this process has loaded: one chunk of every
+    topology, every plan step dispatched once in plan order.  FETCH_SIZE x2 (the guide's gfx950 correction; calibrated on
+    k_convert_frames), WRITE_SIZE x1, both counted in KiB.  Returns {topology: {"steps": {label: bytes}, "model": bytes}}
+    per launch of `chunk` frames, or {"error": ...} — nothing is looked up by kernel name or duration in committed files."""
+    import re
+    import shutil
+    import sqlite3
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return {"error": "rocprofv3 not found"}
+    child = os.path.join(ROOT, "tools", "pmc_child.py")
+    env = dict(os.environ, TMPDIR="/tmp")
+    result = {}
+    labels = None
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        for counter, corr in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+            out_dir = os.path.join(td, counter)
+            cmd = [rocprof, "--kernel-trace", "--pmc", counter, "-d", out_dir, "-o", counter, "--",
+                   sys.executable, child, str(chunk), *topologies]
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd="/tmp", env=env)
+            except subprocess.TimeoutExpired:
+                return {"error": f"rocprofv3 --pmc {counter} timed out"}
+            line = next((l for l in r.stdout.splitlines() if l.startswith("{")), None)
+            dbs = [os.path.join(dp, f) for dp, _dn, fn in os.walk(out_dir) for f in fn if f.endswith(".db")]
+            if r.returncode != 0 or line is None or not dbs:
+                return {"error": f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): " + (r.stderr or r.stdout)[-300:]}
+            labels = json.loads(line)
+            c = sqlite3.connect(dbs[0])
+            disp = c.execute("select d.event_id, coalesce(s.display_name, s.kernel_name) from rocpd_kernel_dispatch d "
+                             "join rocpd_info_kernel_symbol s on d.kernel_id = s.id order by d.start").fetchall()
+            vals = dict(c.execute("select e.event_id, sum(e.value) from rocpd_pmc_event e join rocpd_info_pmc p on e.pmc_id = p.id "
+                                  "where p.name = ? group by e.event_id", (counter,)).fetchall())
+            c.close()
+            # split the dispatch stream on the k_synth_frames markers: segment t belongs to topologies[t]
+            segments, cur = [], None
+            for ev, name in disp:
+                if "k_synth_frames" in name:
+                    cur = []
+                    segments.append(cur)
+                elif cur is not None:
+                    cur.append((re.sub(r"\(anonymous namespace\)::", "", name), vals.get(ev, 0.0) * 1024.0 * corr))
+            if len(segments) != len(topologies):
+                return {"error": f"expected {len(topologies)} marker launches in the {counter} trace, found {len(segments)}"}
+            for topo, seg in zip(topologies, segments):
+                rec = result.setdefault(topo, {"steps": {}, "model": 0.0})
+                rec["model"] += sum(b for _n, b in seg)
+                pos = 0
+                for label in labels[topo]:                     # greedy in-order match of the tagged steps
+                    m = re.search(r"\[(k_[a-z0-9_]+)(<[^>]*>)?\]", label)
+                    if not m:
+                        continue
+                    want = m.group(1) + (m.group(2) or "")
+                    for j in range(pos, len(seg)):
+                        if want.replace(" ", "") in seg[j][0].replace(" ", ""):
+                            rec["steps"][label] = rec["steps"].get(label, 0.0) + seg[j][1]
+                            pos = j + 1
+                            break
+    for topo in result:
+        result[topo]["chunk"] = chunk
+    result["source"] = ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE child passes of "
+                        "tools/pmc_child.py on the loaded library (FETCH x2 gfx950 correction, WRITE x1), one chunk per topology")
+    return result
+
+
+def step_roofline(step, frames, traffic_bytes=None, chunk=None):
+    """roofline record of one plan step from its HIP-event time over `frames` frames: bound 'mfma' for convolutions
+    whose arithmetic intensity is above the ridge (157.3 TFLOP/s / 8 TB/s = 19.7 FLOP/B), 'hbm' otherwise"""
+    ms = step["ms"]
+    if not ms:
+        return None
+    tf = step["flops"] * frames / (ms * 1e-3) / 1e12
+    gbs = step["bytes"] * frames / (ms * 1e-3) / 1e9
+    intensity = step["flops"] / step["bytes"] if step["bytes"] else float("inf")
+    if intensity >= 157.3e12 / 8.0e12 and step["flops"]:
+        rec = {"bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3}
+    else:
+        rec = {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0}
+    rec.update(kernel=step["label"], flop_per_byte=intensity if step["bytes"] else None,
+               avg_launch_ms=ms / max(1, step["launches"]), launches=step["launches"], traffic=traffic_bytes)
+    if traffic_bytes is not None and chunk:
+        rec["traffic_over_algorithmic"] = traffic_bytes / (step["bytes"] * chunk) if step["bytes"] else None
+    return rec
+
+
 # ---- other BASELINE topologies ---------------------------------------------------------------------------------------
-def topology_rate(name, device, d_frames_ptr, n, chunk, steps=2):
+def topology_rate(name, device, d_frames_ptr, n, chunk, steps=2, traffic=None, cpu_baseline=None):
     """device-resident frames/s of another BASELINE topology on the same frames (config 3: densecpd, config 4's model:
-    timed_rotamer), with the per-kernel table from HIP events"""
+    timed_rotamer) with its own roofline records: the whole model against the fp32-MFMA peak, the dominant kernel
+    (largest share of device time) and every kernel's bound / fraction / measured HBM traffic; all n output rows are
+    checked.  ``traffic``: this topology's record from pmc_traffic_inrun; ``cpu_baseline``: callable(cfg, weights, name)."""
     from timed_hip import _lib, engine, synth
     cfg, weights = synth.TOPOLOGIES[name]()
     model = engine.HipFrameModel.from_keras(cfg, weights, device=device, name=name)
@@ -268,14 +402,32 @@ def topology_rate(name, device, d_frames_ptr, n, chunk, steps=2):
     _lib.check(lib.th_dev_sync(device))
     dt = (time.perf_counter() - t0) / steps
     cost = model.cost()
-    probe = d_probs.download((min(n, 64), model.n_classes), np.float32)
-    assert np.all(np.isfinite(probe)) and np.allclose(probe.sum(1), 1.0, atol=1e-4)
+    rows = d_probs.download((n, model.n_classes), np.float32)
+    bad = int(np.count_nonzero(~np.isfinite(rows).all(1) | (np.abs(rows.sum(1, dtype=np.float64) - 1.0) > 1e-4)))
+    assert bad == 0, f"{name}: {bad} of {n} output rows are not probability vectors"
     tot = sum(s["ms"] for s in table)
-    res = {"topology": name, "frames": n, "n_classes": model.n_classes, "frames_per_s": n / dt,
-           "algo_mflop_per_frame": cost["algo_flops"] / 1e6, "model_tflops": n / dt * cost["algo_flops"] / 1e12,
-           "kernels": [{"label": s["label"], "share": s["ms"] / tot,
-                        "tflops_algo": (s["flops"] * n / (s["ms"] * 1e-3) / 1e12) if s["ms"] and s["flops"] else 0.0,
-                        "GBps_algo": (s["bytes"] * n / (s["ms"] * 1e-3) / 1e9) if s["ms"] else 0.0} for s in table]}
+    per_step = (traffic or {}).get("steps", {})
+    D, H, W, Cc = model.input_shape
+    algo_bytes = D * H * W * Cc * 4 + 4 * model.n_classes
+    fps = n / dt
+    dom = max(table, key=lambda s: s["ms"])
+    res = {"topology": name, "frames": n, "chunk": chunk, "n_classes": model.n_classes, "frames_per_s": fps, "rows_verified": n,
+           "algo_mflop_per_frame": cost["algo_flops"] / 1e6, "model_tflops": fps * cost["algo_flops"] / 1e12,
+           "model_roofline": {"bound": "mfma", "achieved": fps * cost["algo_flops"] / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                              "frac": fps * cost["algo_flops"] / 1e12 / 157.3,
+                              "traffic": (traffic or {}).get("model"), "traffic_frames": (traffic or {}).get("chunk"),
+                              "algorithmic_bytes": algo_bytes * ((traffic or {}).get("chunk") or 0) or None},
+           "hbm": {"algo_bytes_per_frame": algo_bytes, "achieved_GBps": fps * algo_bytes / 1e9, "frac": fps * algo_bytes / 1e9 / 8000.0},
+           "roofline": dict(step_roofline(dom, n, per_step.get(dom["label"]), (traffic or {}).get("chunk")),
+                            share_of_device_time=dom["ms"] / tot),
+           "kernels": [dict(step_roofline(s, n, per_step.get(s["label"]), (traffic or {}).get("chunk")) or {}, label=s["label"],
+                            share=s["ms"] / tot,
+                            tflops_algo=(s["flops"] * n / (s["ms"] * 1e-3) / 1e12) if s["ms"] and s["flops"] else 0.0,
+                            GBps_algo=(s["bytes"] * n / (s["ms"] * 1e-3) / 1e9) if s["ms"] else 0.0) for s in table]}
+    for k in res["kernels"]:
+        k.pop("kernel", None)
     model.close()
     d_probs.free()
+    if cpu_baseline is not None:
+        res["cpu_baseline"] = cpu_baseline(cfg, weights, f"{name}-synth")
     return res
