@@ -1,4 +1,5 @@
 """Host logic without a GPU: Keras-config normalisation, pack round trip, C-ABI surface."""
+import json
 import os
 import re
 
@@ -109,3 +110,124 @@ def test_per_channel_ops_and_pooling_are_pushed_through_branch_concats():
     layers = kc.parse_keras_model(cfg, w)
     assert not any("__b" in l.name for l in layers)
     assert sum(l.op == kc.OP_CONCAT for l in layers) == 12
+
+
+# ---- Keras 2.13-style serialisation details the synthetic builder does not emit -------------------
+def _k213(class_name, name, inbound, **cfg):
+    """a layer record as tf.keras 2.13 writes it into a legacy .h5 model_config"""
+    base = dict(name=name, trainable=True, dtype="float32")
+    base.update(cfg)
+    return {"class_name": class_name, "config": base, "name": name, "inbound_nodes": [[[n, 0, 0, {}] for n in inbound]] if inbound else []}
+
+
+def _keras213_config(policy="float32"):
+    init = {"class_name": "GlorotUniform", "config": {"seed": None}}
+    zeros = {"class_name": "Zeros", "config": {}}
+    conv_common = dict(strides=[1, 1, 1], padding="same", data_format="channels_last", dilation_rate=[1, 1, 1], groups=1, use_bias=True,
+                       kernel_initializer=init, bias_initializer=zeros, kernel_regularizer=None, bias_regularizer=None,
+                       activity_regularizer=None, kernel_constraint=None, bias_constraint=None)
+    layers = [
+        {"class_name": "InputLayer", "config": {"batch_input_shape": [None, 5, 5, 5, 2], "dtype": "float32", "sparse": False,
+                                                  "ragged": False, "name": "input_1"}, "name": "input_1", "inbound_nodes": []},
+        _k213("Conv3D", "conv3d", ["input_1"], filters=4, kernel_size=[3, 3, 3], activation="linear",
+              **dict(conv_common, dtype={"class_name": "Policy", "config": {"name": policy}})),
+        _k213("ELU", "elu", ["conv3d"], alpha=1.0),
+        _k213("BatchNormalization", "batch_normalization", ["elu"], axis=[4], momentum=0.99, epsilon=0.001, center=True, scale=True,
+              beta_initializer=zeros, gamma_initializer={"class_name": "Ones", "config": {}},
+              moving_mean_initializer=zeros, moving_variance_initializer={"class_name": "Ones", "config": {}},
+              beta_regularizer=None, gamma_regularizer=None, beta_constraint=None, gamma_constraint=None),
+        _k213("SpatialDropout3D", "spatial_dropout3d", ["batch_normalization"], rate=0.2, noise_shape=None, seed=None),
+        # activation given as a serialized layer object (Conv3D(..., activation=tf.keras.layers.LeakyReLU(0.1)))
+        _k213("Conv3D", "conv3d_1", ["spatial_dropout3d"], filters=3, kernel_size=[1, 1, 1],
+              activation={"class_name": "LeakyReLU", "config": {"name": "leaky_re_lu", "trainable": True, "dtype": "float32", "alpha": 0.1}},
+              **conv_common),
+        _k213("Activation", "activation", ["conv3d_1"], activation="relu"),
+        _k213("GlobalAveragePooling3D", "global_average_pooling3d", ["activation"], data_format="channels_last", keepdims=False),
+        _k213("Softmax", "softmax", ["global_average_pooling3d"], axis=-1),
+    ]
+    return {"class_name": "Functional",
+            "config": {"name": "model", "trainable": True, "layers": layers, "input_layers": [["input_1", 0, 0]],
+                       "output_layers": [["softmax", 0, 0]]},
+            "keras_version": "2.13.1", "backend": "tensorflow"}
+
+
+def _keras213_weights(rng):
+    return {"conv3d": [rng.normal(size=(3, 3, 3, 2, 4)).astype(np.float32), rng.normal(size=4).astype(np.float32)],
+            "batch_normalization": [rng.uniform(0.5, 1.5, 4).astype(np.float32), rng.normal(size=4).astype(np.float32),
+                                    rng.normal(size=4).astype(np.float32), rng.uniform(0.5, 1.5, 4).astype(np.float32)],
+            "conv3d_1": [rng.normal(size=(1, 1, 1, 4, 3)).astype(np.float32), rng.normal(size=3).astype(np.float32)]}
+
+
+def test_keras_2_13_style_config_roundtrips():
+    """dtype policy dicts, groups: 1, keras_version/backend keys, initializer/regularizer objects, an activation given as
+    a serialized layer, list-valued BN axis: parsed, packed and read back; the oracle (which walks the same JSON on its own)
+    evaluates it too"""
+    from oracle import cnn_oracle
+    cfg = _keras213_config()
+    w = _keras213_weights(np.random.default_rng(0))
+    layers = kc.parse_keras_model(json.dumps(cfg), w)
+    assert [l.name for l in layers] == ["input_1", "conv3d", "elu", "batch_normalization", "conv3d_1", "activation",
+                                        "global_average_pooling3d", "softmax"]
+    c1 = next(l for l in layers if l.name == "conv3d_1")
+    assert c1.ip["act"] == kc.ACT_LEAKY and abs(c1.fp["alpha"] - 0.1) < 1e-7 and c1.inputs == ["batch_normalization"]
+    blob = pack.keras_to_pack(cfg, w)
+    assert blob[:8] == pack.MAGIC
+    probs = cnn_oracle.forward(cfg, w, np.random.default_rng(1).random((2, 5, 5, 5, 2)).astype(np.float32))
+    assert probs.shape == (2, 3) and np.allclose(probs.sum(1), 1, atol=1e-6)
+
+
+@pytest.mark.parametrize("policy", ["mixed_float16", "float16", "bfloat16", "float64"])
+def test_non_float32_policy_is_refused(policy):
+    with pytest.raises(kc.UnsupportedLayer, match="float32"):
+        kc.parse_keras_model(_keras213_config(policy), _keras213_weights(np.random.default_rng(0)))
+    cfg = _keras213_config()
+    cfg["config"]["layers"][1]["config"]["groups"] = 2
+    with pytest.raises(kc.UnsupportedLayer, match="grouped"):
+        kc.parse_keras_model(cfg, _keras213_weights(np.random.default_rng(0)))
+
+
+def test_nested_functional_and_sequential_models_are_inlined():
+    """a Model / Sequential used as a layer is spliced into the graph: same ops, same weights as the flat model"""
+    flat = _keras213_config()
+    w = _keras213_weights(np.random.default_rng(0))
+    L = flat["config"]["layers"]
+    inner_in = {"class_name": "InputLayer", "config": {"batch_input_shape": [None, 5, 5, 5, 2], "dtype": "float32", "name": "input_2"},
+                "name": "input_2", "inbound_nodes": []}
+    body = [dict(l) for l in L[1:5]]                                   # conv3d, elu, batch_normalization, spatial_dropout3d
+    body[0] = dict(body[0], inbound_nodes=[[["input_2", 0, 0, {}]]])
+    nested = {"class_name": "Functional", "name": "trunk", "inbound_nodes": [[["input_1", 0, 0, {}]]],
+              "config": {"name": "trunk", "trainable": True, "layers": [inner_in] + body, "input_layers": [["input_2", 0, 0]],
+                         "output_layers": [["spatial_dropout3d", 0, 0]]}}
+    head = {"class_name": "Sequential", "name": "head", "inbound_nodes": [[["trunk", 0, 0, {}]]],
+            "config": {"name": "head", "layers": [dict(l, inbound_nodes=[]) for l in L[5:8]]}}
+    sm = dict(L[8], inbound_nodes=[[["head", 0, 0, {}]]])
+    outer = {"class_name": "Functional", "keras_version": "2.13.1", "backend": "tensorflow",
+             "config": {"name": "outer", "layers": [L[0], nested, head, sm], "input_layers": [["input_1", 0, 0]],
+                        "output_layers": [["softmax", 0, 0]]}}
+    # weights as timed_hip.h5model hands them out for nested groups: under the inner layer names
+    a = kc.parse_keras_model(flat, w)
+    b = kc.parse_keras_model(outer, w)
+    assert [l.op for l in a] == [l.op for l in b] and [l.out_shape for l in a] == [l.out_shape for l in b]
+    assert [l.name for l in b] == ["input_1", "trunk/conv3d", "trunk/elu", "trunk/batch_normalization", "head/conv3d_1", "head/activation",
+                                   "head/global_average_pooling3d", "softmax"]
+    for la, lb in zip(a, b):
+        assert la.ip == lb.ip and la.fp == lb.fp and set(la.weights) == set(lb.weights)
+        for k in la.weights:
+            assert np.array_equal(la.weights[k], lb.weights[k])
+    assert b[4].inputs == ["trunk/batch_normalization"] and b[-1].inputs == ["head/global_average_pooling3d"]
+    assert pack.keras_to_pack(outer, w)[:8] == pack.MAGIC
+
+
+def test_keras_pinning_tool_dry_runs_without_tensorflow():
+    """tools/validate_against_keras.py (the hook that pins the CNN oracle to TensorFlow the day it is available): --help and
+    the TensorFlow-free part of `--synth NAME --emit-fixture` work in this image"""
+    import subprocess
+    import sys
+    tool = os.path.join(ROOT, "tools", "validate_against_keras.py")
+    r = subprocess.run([sys.executable, tool, "--help"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "--synth" in r.stdout and "--emit-fixture" in r.stdout
+    r = subprocess.run([sys.executable, tool, "--synth", "densecpd", "--dry-run", "--emit-fixture"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1000:]
+    assert "391.0 MFLOP/frame" in r.stdout and "keras_real_" in r.stdout
+    r = subprocess.run([sys.executable, tool, "--dry-run"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "exactly one of" in r.stderr

@@ -51,4 +51,13 @@ def read_keras_h5(path) -> Tuple[dict, Dict[str, List[np.ndarray]]]:
             lg = g[lname]
             wn = _names(lg.attrs["weight_names"]) if "weight_names" in lg.attrs else []
             weights[lname] = [np.asarray(lg[w][()], dtype=np.float32) for w in wn]
+            # a nested model used as a layer keeps its layers' weights in ITS group as "<inner layer>/kernel:0" ... in
+            # `layer.weights` order (trainable first): expose them under "<outer>/<inner>" and "<inner>" as well, each in
+            # Keras' per-layer order (kernel, bias / gamma, beta, moving_mean, moving_variance — which that order keeps)
+            for w, arr in zip(wn, weights[lname]):
+                parts = w.split("/")
+                if len(parts) >= 2 and parts[0] != lname:
+                    inner = "/".join(parts[:-1])
+                    weights.setdefault(f"{lname}/{inner}", []).append(arr)
+                    weights.setdefault(parts[-2], []).append(arr)
     return cfg, weights

@@ -88,6 +88,19 @@ def _act_code(name):
     return code, alpha
 
 
+def _check_compute_dtype(name: str, dtype) -> None:
+    """A layer's ``dtype`` entry is a string ("float32") or, since TF 2.4, a serialized policy
+    ({"class_name": "Policy", "config": {"name": "mixed_float16"}}).  The engine evaluates in float32 — what every
+    model of the reference does; a float16 / bfloat16 / mixed-precision / float64 layer would give other numbers than
+    Keras, so it is refused instead of being computed silently at another precision."""
+    if dtype is None:
+        return
+    if isinstance(dtype, dict):
+        dtype = (dtype.get("config") or {}).get("name", dtype.get("class_name"))
+    if str(dtype) != "float32":
+        raise UnsupportedLayer(f"{name}: dtype policy {dtype!r} — the engine computes in float32 only")
+
+
 def _triple(v) -> tuple:
     if isinstance(v, int):
         return (v, v, v)
@@ -143,10 +156,14 @@ def parse_keras_model(model_config, weights: Dict[str, Sequence[np.ndarray]]) ->
     raw_layers = cfg["layers"] if isinstance(cfg, dict) else cfg  # very old Sequential: bare list
     if cls not in ("Sequential", "Functional", "Model"):
         raise UnsupportedLayer(f"model class {cls!r} is not supported")
+    if cls != "Sequential":
+        raw_layers, nested_alias = _inline_nested_models(raw_layers)
+    else:
+        nested_alias = {}
 
     layers: List[Layer] = []
     shapes: Dict[str, tuple] = {}
-    alias: Dict[str, str] = {}
+    alias: Dict[str, str] = dict(nested_alias)
     prev_name = None
 
     def resolve(n: str) -> str:
@@ -176,7 +193,10 @@ def parse_keras_model(model_config, weights: Dict[str, Sequence[np.ndarray]]) ->
             ins = [resolve(n) for n in _inbound_names(lc)]
         if c.get("data_format", "channels_last") != "channels_last":
             raise UnsupportedLayer(f"{name}: only channels_last is supported")
-        w = list(weights.get(name, []))
+        _check_compute_dtype(name, c.get("dtype"))
+        # layers of an inlined nested model are called "<outer>/<inner>"; a Keras .h5 stores their weights under the
+        # inner name inside the outer layer's group (timed_hip.h5model exposes both spellings)
+        w = list(weights.get(name, weights.get(name.rsplit("/", 1)[-1], [])))
 
         if cname == "InputLayer":
             bis = c.get("batch_input_shape") or c.get("batch_shape")
@@ -318,6 +338,57 @@ def parse_keras_model(model_config, weights: Dict[str, Sequence[np.ndarray]]) ->
     if sum(1 for l in layers if l.op == OP_INPUT) != 1:
         raise UnsupportedLayer("exactly one model input is supported")
     return push_through_concat(layers)
+
+
+def _inline_nested_models(raw_layers: list):
+    """A Functional model may use another Model / Sequential as a layer (``class_name`` "Functional" / "Model" /
+    "Sequential" with its own ``config.layers``).  At inference that is just a sub-graph: its layers are spliced into the
+    outer list as "<outer>/<inner>", its InputLayer becomes an alias of the tensor the outer graph feeds it, and the outer
+    layer's name an alias of the sub-graph's output.  Returns (flat layer list, alias map); nesting may be deeper than one."""
+    flat, alias = [], {}
+    for lc in raw_layers:
+        if lc.get("class_name") not in ("Functional", "Model", "Sequential") or not isinstance(lc.get("config"), dict) \
+                or "layers" not in lc["config"]:
+            flat.append(lc)
+            continue
+        outer = lc.get("name") or lc["config"]["name"]
+        fed = _inbound_names(lc)
+        if len(fed) != 1:
+            raise UnsupportedLayer(f"{outer}: a nested model with {len(fed)} inputs is not supported")
+        inner_cfg = lc["config"]
+        sequential = lc["class_name"] == "Sequential"
+        inner_layers, inner_alias = (inner_cfg["layers"], {}) if sequential else _inline_nested_models(inner_cfg["layers"])
+        prev = fed[0]
+        last = None
+        for il in inner_layers:
+            iname = il.get("name") or il["config"]["name"]
+            full = f"{outer}/{iname}"
+            if il["class_name"] == "InputLayer":
+                alias[full] = fed[0]
+                prev = full
+                continue
+            new = dict(il)
+            new["name"] = full
+            new["config"] = dict(il["config"], name=full)
+            if sequential:
+                new["inbound_nodes"] = [[[prev, 0, 0, {}]]]
+            else:
+                new["inbound_nodes"] = [[[f"{outer}/{n}", 0, 0, {}] for n in _inbound_names(il)]]
+            flat.append(new)
+            prev = last = full
+        for k, v in inner_alias.items():
+            alias[f"{outer}/{k}"] = f"{outer}/{v}"
+        if sequential:
+            out_name = last
+        else:
+            outs = inner_cfg.get("output_layers")
+            if not outs or len(outs) != 1:
+                raise UnsupportedLayer(f"{outer}: a nested model needs exactly one output")
+            out_name = f"{outer}/{outs[0][0]}"
+        if out_name is None:
+            raise UnsupportedLayer(f"{outer}: empty nested model")
+        alias[outer] = out_name
+    return flat, alias
 
 
 def push_through_concat(layers: List[Layer]) -> List[Layer]:

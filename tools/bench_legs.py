@@ -295,7 +295,7 @@ def sampler_config5(device=0, n_res=300, n_samples=1000, temps=(0.1, 0.5, 1.0), 
 def pmc_traffic_inrun(topologies, chunk, timeout=240):
     """Two rocprofv3 child runs of tools/pmc_child.py (`--kernel-trace --pmc FETCH_SIZE`, then `--pmc WRITE_SIZE`: separate
     passes, as /opt/skills/guides/MI355X_MICROARCH.md prescribes) on the library this process has loaded: one chunk of every
-    topology, every plan step dispatched once in plan order.  FETCH_SIZE x2 (the guide's gfx950 correction; calibrated on
+    topology after a warm-up pass, every plan step dispatched once in plan order.  FETCH_SIZE x2 (the guide's gfx950 correction; calibrated on
     k_convert_frames), WRITE_SIZE x1, both counted in KiB.  Returns {topology: {"steps": {label: bytes}, "model": bytes}}
     per launch of `chunk` frames, or {"error": ...} — nothing is looked up by kernel name or duration in committed files."""
     import re
@@ -336,9 +336,9 @@ def pmc_traffic_inrun(topologies, chunk, timeout=240):
                     segments.append(cur)
                 elif cur is not None:
                     cur.append((re.sub(r"\(anonymous namespace\)::", "", name), vals.get(ev, 0.0) * 1024.0 * corr))
-            if len(segments) != len(topologies):
-                return {"error": f"expected {len(topologies)} marker launches in the {counter} trace, found {len(segments)}"}
-            for topo, seg in zip(topologies, segments):
+            if len(segments) != 2 * len(topologies):
+                return {"error": f"expected {2 * len(topologies)} marker launches in the {counter} trace, found {len(segments)}"}
+            for topo, seg in zip(topologies, segments[1::2]):          # [warm-up, measured] per topology
                 rec = result.setdefault(topo, {"steps": {}, "model": 0.0})
                 rec["model"] += sum(b for _n, b in seg)
                 pos = 0

@@ -8,6 +8,14 @@ NOT runnable in the build image (no TensorFlow, no released .h5 — SURVEY.md §
 
     pip install tensorflow==2.13.0 h5py
     python tools/validate_against_keras.py --model TIMED.h5 [--frames data.hdf5 | --synthetic 64] [--emit-fixture]
+    python tools/validate_against_keras.py --synth timed|timed_rotamer|densecpd|prodconn --emit-fixture
+
+`--synth NAME` needs no released file: the benchmark topology of that name (timed_hip/synth.py — the very configs and
+weights bench.py and the golden fixtures use) is instantiated IN KERAS from its model_config
+(`tf.keras.Model.from_config` + `layer.set_weights`), saved as a legacy .h5 with Keras' own writer and then treated exactly
+like a released model — so one command on any machine with TensorFlow pins the oracle, the .h5 reader, the converter and
+the HIP engine to TensorFlow's arithmetic.  `--dry-run` does everything that needs no TensorFlow (builds the config,
+parses and packs it, evaluates the oracle on two frames, prints the plan) and exits.
 
 Exit status 0 when max |p_keras - p_oracle| <= 1e-4 and the argmax agrees on every frame whose top-2 margin
 exceeds 1e-4 (the north-star tolerance), for the oracle and, if available, for the HIP engine.
@@ -28,26 +36,65 @@ sys.path.insert(0, os.path.join(ROOT, "timed-design_amd"))
 
 def main():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
-    ap.add_argument("--model", required=True, help="Keras legacy .h5 (e.g. a released TIMED model)")
+    ap.add_argument("--model", help="Keras legacy .h5 (e.g. a released TIMED model)")
+    ap.add_argument("--synth", choices=["timed", "timed_rotamer", "densecpd", "prodconn"],
+                    help="build this benchmark topology in Keras from timed_hip/synth.py instead of loading a released .h5")
+    ap.add_argument("--dry-run", action="store_true", help="do what needs no TensorFlow (config, pack, oracle on 2 frames) and exit")
     ap.add_argument("--frames", help="aposteriori .hdf5 frame dataset; default: synthetic frames")
     ap.add_argument("--synthetic", type=int, default=64, help="number of synthetic frames when --frames is not given")
     ap.add_argument("--save-golden", help="write inputs and Keras probabilities to this .npz")
     ap.add_argument("--emit-fixture", action="store_true", help="write tests/golden/keras_real_<model>.npz + .h5 (see above)")
     ap.add_argument("--tol", type=float, default=1e-4)
     args = ap.parse_args()
+    if bool(args.model) == bool(args.synth):
+        ap.error("give exactly one of --model FILE.h5 and --synth NAME")
+
+    from timed_hip import h5model, synth
+    from oracle import cnn_oracle
+
+    synth_cfg = synth_weights = None
+    if args.synth:
+        synth_cfg, synth_weights = synth.TOPOLOGIES[args.synth]()
+    if args.dry_run:
+        from timed_hip import keras_config, pack
+        if args.synth:
+            cfg, weights = synth_cfg, synth_weights
+        else:
+            cfg, weights = h5model.read_keras_h5(args.model)
+        layers = keras_config.parse_keras_model(cfg, weights)
+        blob = pack.keras_to_pack(cfg, weights)
+        shape = layers[0].out_shape
+        X = synth.synthetic_frames(2, seed=1234, side=shape[0], channels=shape[-1])
+        p = cnn_oracle.forward(cfg, weights, X, np.float32)
+        print(f"[dry-run] {args.synth or args.model}: {len(cfg['config']['layers'])} Keras layers -> {len(layers)} engine nodes, "
+              f"{keras_config.flops_per_frame(layers) / 1e6:.1f} MFLOP/frame, pack {len(blob) / 1e6:.2f} MB, input {shape}, "
+              f"{p.shape[1]} classes; oracle rows sum to {p.sum(1)}")
+        print("[dry-run] with TensorFlow this run would: " +
+              ("tf.keras.Model.from_config(config) + set_weights per layer, save keras_real_<name>.h5; " if args.synth else "") +
+              "tf.keras.models.load_model(.h5).predict(X); compare with the oracle (and the HIP engine when a GPU is visible)"
+              + ("; write tests/golden/keras_real_<name>.npz/.h5" if args.emit_fixture else ""))
+        sys.exit(0)
 
     try:
         import tensorflow as tf
     except ImportError:
-        sys.exit("TensorFlow is not installed: this tool needs the reference's own stack (tensorflow==2.13.0)")
-
-    from timed_hip import h5model, synth
-    from oracle import cnn_oracle
+        sys.exit("TensorFlow is not installed: this tool needs the reference's own stack (tensorflow==2.13.0); "
+                 "--dry-run shows what it would do")
 
     def top_3_cat_acc(y_true, y_pred):   # the custom metric the reference registers (predict.py:24-25, :88)
         return tf.keras.metrics.top_k_categorical_accuracy(y_true, y_pred, k=3)
 
     tf.keras.utils.get_custom_objects()["top_3_cat_acc"] = top_3_cat_acc
+    if args.synth:
+        # the benchmark topology, built by Keras itself from the same model_config the engine packs, written with Keras'
+        # own legacy-HDF5 writer: from here on it is handled exactly like a released model file
+        import tempfile
+        built = tf.keras.Model.from_config(synth_cfg["config"])
+        for layer in built.layers:
+            if layer.name in synth_weights and synth_weights[layer.name]:
+                layer.set_weights([np.asarray(a) for a in synth_weights[layer.name]])
+        args.model = os.path.join(tempfile.mkdtemp(), f"{args.synth}_synth.h5")
+        built.save(args.model, save_format="h5")
     keras_model = tf.keras.models.load_model(args.model)                 # predict.py:121
     cfg, weights = h5model.read_keras_h5(args.model)                     # our reader of the same file
     in_shape = tuple(int(d) for d in keras_model.input_shape[1:])
