@@ -249,3 +249,42 @@ def test_compile_time_geometry_kernels_with_preactivation(gpu, side, cmid, cout,
     labels = _check(cfg, weights, frames)
     assert any(l.endswith(tag) and "conv_" in l for l in labels), labels
     _check(cfg, weights, frames, chunk=3)
+
+
+# (shape, cin, cout, pool, post, n, kernels the label must name)
+TAIL = [
+    ((5, 5, 5), 64, 338, None, "elu_bn", 5, ("k_conv_mfma<4,4,2,4,16,2,0,7>", "k_conv_mfma<4,2,3,3,16,2,0,7>")),   # the rotamer head: 128 + 128 + 96
+    ((5, 5, 5), 48, 300, None, "bn_relu", 3, ("k_conv_mfma<4,4,2,4,16,2,0,7>", "k_conv_mfma<4,4,2,2,16,2,0,7>")),  # 128 + 128 + 64
+    ((5, 5, 5), 32, 280, None, "leaky", 4, ("k_conv_mfma<4,4,2,4,16,2,0,7>", "k_conv_mfma<4,2,1,1,16,2,0")),       # 128 + 128 + 32
+    ((5, 5, 5), 40, 200, None, "elu_bn", 3, ("k_conv_mfma<4,4,2,4,16,2,0,7>", "k_conv_mfma<4,2,3,3,16,2,0,7>")),   # 128 + 96, Cin % 16 != 0
+    ((4, 4, 4), 32, 210, "max", "elu_bn", 5, ("k_conv_mfma<4,4,2,4,16,2,1", "k_conv_mfma<4,2,3,3,16,2,1")),        # pooled, runtime geometry
+]
+
+
+@pytest.mark.parametrize("shape,cin,cout,pool,post,n,kernels", TAIL)
+def test_heterogeneous_cout_blocks(gpu, shape, cin, cout, pool, post, n, kernels, monkeypatch):
+    """the last Cout block of a wide layer on a narrower instantiation (conv_mfma_plan_tail): weights, bias and the
+    per-channel BatchNorm vectors of the tail start at its first channel; per-element against the oracle, and
+    bit-identical to the run with the tail switched off (same fmaf chains per output)"""
+    def build(b, x):
+        x = b.conv3d(x, cout, 3, padding="same")
+        if post == "elu_bn":
+            x = b.batchnorm(b.elu(x))
+        elif post == "bn_relu":
+            x = b.relu(b.batchnorm(x))
+        else:
+            x = b.leaky_relu(x, 0.2)
+        return b.maxpool(x, 2) if pool == "max" else x
+
+    cfg, weights = _net(shape, cin, build, seed=cout)
+    frames = _frames(n, shape, cin, seed=n)
+    labels = _check(cfg, weights, frames)
+    conv = next(l for l in labels if "conv_mfma" in l)
+    assert all(k in conv for k in kernels) and " + " in conv, conv
+    _check(cfg, weights, frames, chunk=2)
+    with_tail = engine.HipFrameModel.from_keras(cfg, weights).predict(frames)
+    monkeypatch.setenv("TH_CONV_NOTAIL", "1")
+    m = engine.HipFrameModel.from_keras(cfg, weights)
+    assert not any(" + " in s["label"] for s in m.steps())
+    assert np.array_equal(m.predict(frames), with_tail)
+    m.close()

@@ -114,6 +114,10 @@ struct ConvMfmaPlan {
 // (stride/dilation != 1, nothing fits in LDS, ...)
 bool conv_mfma_plan(const TView& in, const TView& out_conv, const ConvGeom& g, int Cin, int Cout, int pool,
                     ConvMfmaPlan* plan);
+// a narrower instantiation for the last Cout block of a layer planned on 128-column blocks (see conv_mfma.hip); on success
+// the main launch covers output channels [0, *cout_main) and `tail` the rest
+bool conv_mfma_plan_tail(const TView& in, const TView& out_conv, const ConvGeom& g, int Cin, int Cout, int pool,
+                         const ConvMfmaPlan& main, ConvMfmaPlan* tail, int* cout_main);
 // host-side weight re-layout: Keras [kd,kh,kw,Cin,Cout] -> [nb][chunk][tap][BN][CS]
 void conv_mfma_pack_weights(const ConvMfmaPlan& p, const ConvGeom& g, int Cin, int Cout, const float* w_keras,
                             float* dst);

@@ -1272,6 +1272,7 @@ const CfgDesc kCfgs[] = {
     {4, 2, 1, 1, 16, 2},  // 10
     {8, 2, 1, 1, 8, 2},   // 11: Cin<=8 with weights streamed (large kernels on the input, e.g. 5^3: 125 taps do not fit LDS)
     {8, 2, 2, 2, 8, 2},   // 12: same, BN=64
+    {4, 2, 3, 3, 16, 2},  // 13: BN=96 — the last Cout block of a wide layer (338 = 128 + 128 + 82: 352 columns instead of 384)
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -1284,6 +1285,7 @@ const ConvKernel kKernels[kNumCfgs][3] = {
     CFG_ROW(8, 4, 2, 2, 16, 2), CFG_ROW(8, 4, 2, 4, 16, 2), CFG_ROW(8, 2, 1, 1, 16, 2),
     CFG_ROW(4, 4, 2, 2, 16, 2), CFG_ROW(4, 4, 2, 4, 16, 2), CFG_ROW(4, 2, 1, 1, 16, 2),
     CFG_ROW(8, 2, 1, 1, 8, 2), CFG_ROW(8, 2, 2, 2, 8, 2),
+    CFG_ROW(4, 2, 3, 3, 16, 2),
 };
 
 // compile-time staged row geometry (Hp = Wp) for the TIMED layers after the first: 3x3x3, stride 1
@@ -1291,6 +1293,8 @@ struct MfmaGeo { int cfg, pool, geo; ConvKernel k; };
 const MfmaGeo kMfmaGeo[] = {
     {9, 0, 7, k_conv_mfma<4, 4, 2, 4, 16, 2, 0, 7>},     // 5^3 volumes, two frames per workgroup
     {5, 1, 12, k_conv_mfma<8, 4, 2, 2, 16, 2, 1, 12>},   // 10^3 + 2^3 max-pool
+    {13, 0, 7, k_conv_mfma<4, 2, 3, 3, 16, 2, 0, 7>},    // 5^3, 96-column tail block
+    {8, 0, 7, k_conv_mfma<4, 4, 2, 2, 16, 2, 0, 7>},     // 5^3, 64-column tail block
 };
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -1486,6 +1490,24 @@ bool conv_mfma_plan(const TView& in, const TView& oc, const ConvGeom& g, int Cin
     // Cin <= 8 with a kernel too large for LDS-resident weights: stream them
     if (cfg == 0 || cfg == 4) return plan_with_cfg(cfg == 0 ? 11 : 12, kLdsLimit, false, in, oc, g, Cin, Cout, pool, p);
     return false;
+}
+
+// Heterogeneous Cout blocks: a layer planned on the two-per-CU 128-column kernel (cfg 9) whose LAST block would be mostly
+// zero columns gets that block from a narrower instantiation instead — 96 (cfg 13), 64 (cfg 8) or 32 (cfg 10) columns —
+// launched right after the 128-column blocks on the same input.  Every block stages the input once either way (a block
+// is a workgroup), so unlike a split over different kernels nothing is staged more often than before.  TIMED-rotamer's
+// head (256 -> 338 at 5^3, half of that model's time): 128 + 128 + 96 = 352 columns instead of 3 x 128 = 384.
+bool conv_mfma_plan_tail(const TView& in, const TView& oc, const ConvGeom& g, int Cin, int Cout, int pool, const ConvMfmaPlan& main,
+                         ConvMfmaPlan* tail, int* cout_main) {
+    const bool off = getenv("TH_CONV_NOTAIL") != nullptr;     // A/B comparisons and tests (read at every model load)
+    if (off || main.cfg != 9 || main.nnb < 2) return false;
+    const int done = (main.nnb - 1) * main.BN, rest = Cout - done;
+    if (rest <= 0 || rest > 96) return false;
+    const int cfg = rest <= 32 ? 10 : (rest <= 64 ? 8 : 13);
+    if (!plan_with_cfg(cfg, kLdsLimit / 2, true, in, oc, g, Cin, rest, pool, tail)) return false;
+    if (tail->nnb != 1) return false;
+    *cout_main = done;
+    return true;
 }
 
 void conv_mfma_pack_weights(const ConvMfmaPlan& p, const ConvGeom& g, int Cin, int Cout, const float* w, float* dst) {

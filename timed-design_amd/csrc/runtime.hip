@@ -529,16 +529,54 @@ int plan(th_model* m) {
                             return launch_conv_pw(s, cnt, mp, M->view(src), M->view(dst), Cin, Cout, dw, dbias, pre, po);
                         };
                     } else if (mplans.count(i)) {
-                        const ConvMfmaPlan mp = mplans[i];
-                        std::vector<float> packed(mp.wpk_floats);
-                        conv_mfma_pack_weights(mp, g, Cin, Cout, hw, packed.data());
-                        float* dw;
-                        if ((rc = upload(M, packed.data(), packed.size(), &dw))) return rc;
-                        st.exec_flops = mp.exec_flops;
-                        st.label = n.name + ": " + mp.label;
-                        st.run = [=](hipStream_t s, int64_t cnt) {
-                            return launch_conv_mfma(s, cnt, mp, M->view(src), M->view(dst), g, Cin, Cout, dw, dbias, pre, po);
-                        };
+                        ConvMfmaPlan mp = mplans[i];
+                        // heterogeneous Cout blocks: the last, mostly empty 128-column block on a narrower instantiation
+                        ConvMfmaPlan tp;
+                        int cout_main = Cout;
+                        TView ivp; ivp.D = sn.D; ivp.H = sn.H; ivp.W = sn.W; ivp.C = sn.C;
+                        TView ovp; ovp.D = n.D; ovp.H = n.H; ovp.W = n.W; ovp.C = n.C; ovp.fs = (int64_t)n.D * n.H * n.W * n.C;
+                        const bool tailed = conv_mfma_plan_tail(ivp, ovp, g, Cin, Cout, mp.pool, mp, &tp, &cout_main);
+                        float *dw, *dwt = nullptr;
+                        if (tailed) {
+                            const int cout_tail = Cout - cout_main;
+                            const size_t ktaps = (size_t)g.kd * g.kh * g.kw * Cin;
+                            std::vector<float> wm(ktaps * cout_main), wt(ktaps * cout_tail);
+                            for (size_t r = 0; r < ktaps; ++r) {
+                                std::memcpy(&wm[r * cout_main], hw + r * Cout, (size_t)cout_main * sizeof(float));
+                                std::memcpy(&wt[r * cout_tail], hw + r * Cout + cout_main, (size_t)cout_tail * sizeof(float));
+                            }
+                            mp.nnb -= 1;
+                            mp.exec_flops *= (double)mp.nnb / (mp.nnb + 1);
+                            mp.wpk_floats = mp.wpk_floats / (mp.nnb + 1) * mp.nnb;
+                            std::vector<float> packed(mp.wpk_floats), packed_t(tp.wpk_floats);
+                            conv_mfma_pack_weights(mp, g, Cin, cout_main, wm.data(), packed.data());
+                            conv_mfma_pack_weights(tp, g, Cin, cout_tail, wt.data(), packed_t.data());
+                            if ((rc = upload(M, packed.data(), packed.size(), &dw)) || (rc = upload(M, packed_t.data(), packed_t.size(), &dwt))) return rc;
+                            PostOps pot = po;        // per-channel vectors of the tail block start at its first channel
+                            for (int k = 0; k < pot.n; ++k) {
+                                if (pot.scale[k]) pot.scale[k] += cout_main;
+                                if (pot.shift[k]) pot.shift[k] += cout_main;
+                            }
+                            const float* dbias_t = dbias ? dbias + cout_main : nullptr;
+                            st.exec_flops = mp.exec_flops + tp.exec_flops;
+                            st.label = n.name + ": " + mp.label + " x" + std::to_string(mp.nnb) + " + " + tp.label;
+                            st.run = [=](hipStream_t s, int64_t cnt) {
+                                int r1 = launch_conv_mfma(s, cnt, mp, M->view(src), M->view(dst), g, Cin, cout_main, dw, dbias, pre, po);
+                                if (r1) return r1;
+                                TView ot = M->view(dst);
+                                ot.coff += cout_main;
+                                return launch_conv_mfma(s, cnt, tp, M->view(src), ot, g, Cin, cout_tail, dwt, dbias_t, pre, pot);
+                            };
+                        } else {
+                            std::vector<float> packed(mp.wpk_floats);
+                            conv_mfma_pack_weights(mp, g, Cin, Cout, hw, packed.data());
+                            if ((rc = upload(M, packed.data(), packed.size(), &dw))) return rc;
+                            st.exec_flops = mp.exec_flops;
+                            st.label = n.name + ": " + mp.label;
+                            st.run = [=](hipStream_t s, int64_t cnt) {
+                                return launch_conv_mfma(s, cnt, mp, M->view(src), M->view(dst), g, Cin, Cout, dw, dbias, pre, po);
+                            };
+                        }
                     } else {
                         float* dw;
                         if ((rc = upload(M, hw, wcount, &dw))) return rc;
