@@ -334,7 +334,7 @@ def pmc_traffic_inrun(topologies, chunk, timeout=240):
                 if "k_synth_frames" in name:
                     cur = []
                     segments.append(cur)
-                elif cur is not None:
+                elif cur is not None and "k_clip01" not in name:        # (k_clip01 is the second half of the marker itself)
                     cur.append((re.sub(r"\(anonymous namespace\)::", "", name), vals.get(ev, 0.0) * 1024.0 * corr))
             if len(segments) != 2 * len(topologies):
                 return {"error": f"expected {2 * len(topologies)} marker launches in the {counter} trace, found {len(segments)}"}
