@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -41,6 +42,7 @@ struct ConvPwArgs {
     unsigned nrows;     // GEMM rows: frames*V, or frames*Vo*8 when pooled
     unsigned ntiles;
     unsigned in_bytes, out_bytes;   // k_conv_pw2: byte spans of the activation views (buffer descriptors, < 4 GiB)
+    int dbg;            // k_conv_pw2 timing knock-outs (TH_PW_DBG; results are WRONG when set): 1 no loads, 2 no stores
 };
 
 // this lane's input row for a tile: lane j supplies GEMM row tile*32 + j (POOL: pooled voxel tile*4 + j/8, mate j%8);
@@ -226,7 +228,9 @@ __global__ void __launch_bounds__(256, (NT == 4 || KMAX == 16) ? 2 : 3) k_conv_p
         }
     }
     __syncthreads();
-    const bool has_pre = a.pre.scale != nullptr || a.pre.act != ACT_LINEAR;
+    // psc / psh hold (1, 0) where there is no BatchNorm, so "affine" is always applicable; what matters is the activation
+    const int pre_kind = __builtin_amdgcn_readfirstlane(
+        a.pre.act == ACT_RELU ? (a.pre.scale ? 1 : 2) : (a.pre.act == ACT_LINEAR && !a.pre.scale ? 0 : 3));
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, (int)a.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)a.out_bytes, 0x00020000);
 
@@ -253,7 +257,7 @@ __global__ void __launch_bounds__(256, (NT == 4 || KMAX == 16) ? 2 : 3) k_conv_p
         const unsigned base = row_off(tile);
 #pragma unroll
         for (int u = 0; u < KMAX; ++u) {
-            const unsigned off = (u < K8 && base != OOB) ? base + (unsigned)u * 32u : OOB;
+            const unsigned off = (u < K8 && base != OOB && !(a.dbg & 1)) ? base + (unsigned)u * 32u : OOB;
             av[u] = __builtin_amdgcn_raw_buffer_load_b128(rin, off, 0, 0);
         }
     };
@@ -263,29 +267,44 @@ __global__ void __launch_bounds__(256, (NT == 4 || KMAX == 16) ? 2 : 3) k_conv_p
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+        // The BN -> activation prologue is decoded ONCE per tile, outside the MFMA loop: one specialised copy of the loop for
+        // "affine + ReLU" (every DenseNet/DenseCPD layer), one for "nothing", one generic.  With th_act's switch inlined per
+        // element the kernel spent ~60 VALU/SALU instructions per MFMA and ran at 44 % of the matrix pipe with every load and
+        // store knocked out (round 3, TH_PW_DBG=3).
+        auto gemm = [&](auto kind) {
+            constexpr int KIND = decltype(kind)::value;     // 0 none, 1 affine + ReLU, 2 ReLU, 3 generic
 #pragma unroll
-        for (int u = 0; u < KMAX; ++u) {
-            if (u < K8) {
-                const f32x4v vv = __builtin_bit_cast(f32x4v, av[u]);   // whole-vector cast (element-wise bit_cast of a vector lvalue reads .x four times)
-                float4 v = make_float4(vv.x, vv.y, vv.z, vv.w);
-                if (has_pre) {
-                    const float4 sc = *reinterpret_cast<const float4*>(psc + u * 8 + 4 * h);
-                    const float4 sh = *reinterpret_cast<const float4*>(psh + u * 8 + 4 * h);
-                    v.x = th_act(fmaf(v.x, sc.x, sh.x), a.pre.act, a.pre.alpha);
-                    v.y = th_act(fmaf(v.y, sc.y, sh.y), a.pre.act, a.pre.alpha);
-                    v.z = th_act(fmaf(v.z, sc.z, sh.z), a.pre.act, a.pre.alpha);
-                    v.w = th_act(fmaf(v.w, sc.w, sh.w), a.pre.act, a.pre.alpha);
-                }
+            for (int u = 0; u < KMAX; ++u) {
+                if (u < K8) {
+                    const f32x4v vv = __builtin_bit_cast(f32x4v, av[u]);   // whole-vector cast (element-wise bit_cast of a vector lvalue reads .x four times)
+                    float4 v = make_float4(vv.x, vv.y, vv.z, vv.w);
+                    if constexpr (KIND == 1 || KIND == 3) {
+                        const float4 sc = *reinterpret_cast<const float4*>(psc + u * 8 + 4 * h);
+                        const float4 sh = *reinterpret_cast<const float4*>(psh + u * 8 + 4 * h);
+                        v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+                    }
+                    if constexpr (KIND == 1 || KIND == 2) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    }
+                    if constexpr (KIND == 3) {
+                        v.x = th_act(v.x, a.pre.act, a.pre.alpha); v.y = th_act(v.y, a.pre.act, a.pre.alpha);
+                        v.z = th_act(v.z, a.pre.act, a.pre.alpha); v.w = th_act(v.w, a.pre.act, a.pre.alpha);
+                    }
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const float4 b = Bs[(u * NT + nt) * 64 + lane];
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, b.x, acc[nt], 0, 0, 0);
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, b.y, acc[nt], 0, 0, 0);
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.z, b.z, acc[nt], 0, 0, 0);
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.w, b.w, acc[nt], 0, 0, 0);
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const float4 b = Bs[(u * NT + nt) * 64 + lane];
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, b.x, acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, b.y, acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.z, b.z, acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.w, b.w, acc[nt], 0, 0, 0);
+                    }
                 }
             }
-        }
+        };
+        if (pre_kind == 1) gemm(std::integral_constant<int, 1>{});
+        else if (pre_kind == 0) gemm(std::integral_constant<int, 0>{});
+        else if (pre_kind == 2) gemm(std::integral_constant<int, 2>{});
+        else gemm(std::integral_constant<int, 3>{});
         // epilogue: lane holds output channel (nt*32 + j) of rows (r&3) + 8*(r>>2) + 4h; every store is issued, masked by offset
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -297,14 +316,24 @@ __global__ void __launch_bounds__(256, (NT == 4 || KMAX == 16) ? 2 : 3) k_conv_p
 #pragma unroll
             for (int r = 0; r < 16; ++r) x[r] = acc[nt][r] + bv;
             th_post16(x, cc, a.post);
-            if (POOL == 0) {
+            if (POOL == 0 && a.out_dense && tile * 32 + 32 <= a.nrows) {
+                // whole tile in range, rows at a constant byte stride: ONE vector offset per (tile, n-tile) and the row
+                // displacement as the instruction's scalar offset — no per-store address arithmetic (it was ~8 VALU
+                // instructions x 32 stores per tile, a third of this kernel's VALU issue)
+                const unsigned rs = (unsigned)a.out_cs * 4u;
+                const unsigned vbase = cok ? ((tile * 32u + 4u * h) * (unsigned)a.out_cs + (unsigned)a.out_coff + (unsigned)co) * 4u : OOB;
+                const unsigned vb = (a.dbg & 2) ? OOB : vbase;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x[r]), rout, vb, (unsigned)((r & 3) + 8 * (r >> 2)) * rs, 0);
+            } else if (POOL == 0) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const unsigned row = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                     unsigned e;
                     if (a.out_dense) e = row * (unsigned)a.out_cs;
                     else { const unsigned f = row / (unsigned)a.V; e = f * (unsigned)a.out_fs + (row - f * a.V) * (unsigned)a.out_cs; }
-                    const unsigned off = (cok && row < a.nrows) ? (e + (unsigned)a.out_coff + (unsigned)co) * 4u : OOB;
+                    const unsigned off = (cok && row < a.nrows && !(a.dbg & 2)) ? (e + (unsigned)a.out_coff + (unsigned)co) * 4u : OOB;
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x[r]), rout, off, 0, 0);
                 }
             } else {
@@ -449,6 +478,7 @@ int launch_conv_pw(hipStream_t s, int64_t n, const ConvMfmaPlan& p, TView in, TV
     if (nrows >= 0x7fffffffLL) TH_FAIL(TH_EINVAL, "conv_pw: %lld rows per launch exceed the 32-bit row index; lower the chunk size", (long long)nrows);
     a.nrows = (unsigned)nrows;
     a.ntiles = (unsigned)((nrows + 31) / 32);
+    { static const int dbg = getenv("TH_PW_DBG") ? atoi(getenv("TH_PW_DBG")) : 0; a.dbg = dbg; }
     const unsigned want = (a.ntiles + 3) / 4;
     const unsigned grid = std::min(want, 256u * 8u);   // persistent: up to 8 workgroups per CU queued, waves stride over tiles
     PwKernel k = kPw[kmi][nti][p.pool];

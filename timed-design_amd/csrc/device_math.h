@@ -15,6 +15,39 @@ __device__ __forceinline__ float th_act(float x, int act, float alpha) {
     }
 }
 
+// The same activation over N register values with the op decoded ONCE (op-outer, element-inner).  The scalar th_act above
+// inlines its whole switch — exp, the sigmoid division, tanhf's libdevice body — at every call site: in a kernel that applies
+// it to 48 prefetched values per tile (k_conv_pw2's BN -> ReLU prologue) that was 6 000 VALU + 3 500 SALU instructions per 96
+// MFMAs, ~160 KB of code thrashing the instruction cache, and the kernel ran at 44 % of the matrix pipe WITH ALL LOADS AND
+// STORES KNOCKED OUT (round 3, TH_PW_DBG=3).  Here only the taken case's N arithmetic instructions execute.
+template <int N>
+__device__ __forceinline__ void th_act_vec(float (&x)[N], int act, float alpha) {
+    switch (act) {
+        case ACT_RELU:
+#pragma unroll
+            for (int k = 0; k < N; ++k) x[k] = fmaxf(x[k], 0.f);
+            break;
+        case ACT_ELU:
+#pragma unroll
+            for (int k = 0; k < N; ++k) x[k] = x[k] > 0.f ? x[k] : alpha * (__expf(x[k]) - 1.f);
+            break;
+        case ACT_LEAKY:
+#pragma unroll
+            for (int k = 0; k < N; ++k) x[k] = x[k] > 0.f ? x[k] : alpha * x[k];
+            break;
+        case ACT_SIGMOID:
+#pragma unroll
+            for (int k = 0; k < N; ++k) x[k] = 1.f / (1.f + expf(-x[k]));
+            break;
+        case ACT_TANH:
+#pragma unroll
+            for (int k = 0; k < N; ++k) x[k] = tanhf(x[k]);
+            break;
+        default:
+            break;
+    }
+}
+
 // epilogue: ordered list of activation / per-channel affine (folded BatchNormalization:
 // scale = gamma*rsqrt(var+eps), shift = beta - mean*scale — the form tf.nn.batch_normalization uses)
 __device__ __forceinline__ float th_post(float x, int c, const PostOps& ops) {
@@ -30,25 +63,17 @@ __device__ __forceinline__ float th_post(float x, int c, const PostOps& ops) {
 
 // Two values of one channel (the pooled outputs a lane owns after a pool-first epilogue): op list decoded once.
 __device__ __forceinline__ void th_post2(float& x0, float& x1, int c, const PostOps& ops) {
+    float x[2] = {x0, x1};
     for (int i = 0; i < ops.n; ++i) {
         if (ops.type[i] == POP_AFFINE) {
             const float sc = ops.scale[i][c], sh = ops.shift[i][c];
-            x0 = fmaf(x0, sc, sh);
-            x1 = fmaf(x1, sc, sh);
+            x[0] = fmaf(x[0], sc, sh);
+            x[1] = fmaf(x[1], sc, sh);
         } else {
-            const float alpha = ops.alpha[i];
-            switch (ops.act[i]) {
-                case ACT_RELU: x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f); break;
-                case ACT_ELU:
-                    x0 = x0 > 0.f ? x0 : alpha * (__expf(x0) - 1.f);
-                    x1 = x1 > 0.f ? x1 : alpha * (__expf(x1) - 1.f);
-                    break;
-                case ACT_LEAKY: x0 = x0 > 0.f ? x0 : alpha * x0; x1 = x1 > 0.f ? x1 : alpha * x1; break;
-                case ACT_LINEAR: break;
-                default: x0 = th_act(x0, ops.act[i], alpha); x1 = th_act(x1, ops.act[i], alpha);
-            }
+            th_act_vec<2>(x, ops.act[i], ops.alpha[i]);
         }
     }
+    x0 = x[0]; x1 = x[1];
 }
 
 // Same epilogue for the 16 accumulator values a lane holds for ONE output channel c: the op list is
@@ -61,26 +86,7 @@ __device__ __forceinline__ void th_post16(float (&x)[16], int c, const PostOps& 
 #pragma unroll
             for (int k = 0; k < 16; ++k) x[k] = fmaf(x[k], sc, sh);
         } else {
-            const float alpha = ops.alpha[i];
-            switch (ops.act[i]) {
-                case ACT_RELU:
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) x[k] = fmaxf(x[k], 0.f);
-                    break;
-                case ACT_ELU:
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) x[k] = x[k] > 0.f ? x[k] : alpha * (__expf(x[k]) - 1.f);
-                    break;
-                case ACT_LEAKY:
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) x[k] = x[k] > 0.f ? x[k] : alpha * x[k];
-                    break;
-                case ACT_LINEAR:
-                    break;
-                default:
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) x[k] = th_act(x[k], ops.act[i], alpha);
-            }
+            th_act_vec<16>(x, ops.act[i], ops.alpha[i]);
         }
     }
 }

@@ -144,11 +144,22 @@ struct th_model {
     int cur_dtype = TH_F32;
     bool need_convert = true;      // some consumer of the input needs the fp32 arena copy
 
+    // ---- two lanes (TH_LANES=2 / th_model_set_lanes): a chunk is cut in two halves that travel through the plan on two
+    // streams, the second one a few steps behind the first, each in its own half of every arena.  Layers of different
+    // kind then overlap on the device: an HBM-bound 1x1x1 layer (<= 24 KB of LDS, 4-wave workgroups) of one half co-resides
+    // with the single 138 KB / 8-wave workgroup per CU of an MFMA-bound 10^3 growth convolution of the other half and runs
+    // in its barrier / LDS-write / epilogue gaps, and vice versa.
+    int lanes = 1;
+    int lane_lag = 1;                 // steps the second lane runs behind the first at issue time
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int64_t lane_off = 0;             // frame offset (inside the arenas) of the lane whose steps are being issued
+
     TView view(int node) const {
         const Node& nd = nodes[node];
         TView v;
         const Buffer& b = bufs[nd.buf];
-        v.p = b.dev;
+        v.p = b.dev + lane_off * b.floats_per_frame;
         v.D = nd.D; v.H = nd.H; v.W = nd.W; v.C = nd.C;
         v.cs = nd.cs; v.coff = nd.coff; v.fs = b.floats_per_frame;
         return v;
@@ -778,6 +789,33 @@ int run_device(th_model* m, const void* d_frames, int dtype, int64_t n, float* d
             rc = launch_convert_frames(m->stream, m->cur_in, dtype, cnt, Vin, in.C, m->view(m->input_node));
             if (rc) return rc;
         }
+        const bool two = m->lanes == 2 && !m->profiling && cnt >= 256 && m->stream2;
+        if (two) {
+            // halves of the chunk on two streams; lane 1 issues `lane_lag` steps behind lane 0
+            const int64_t h0 = (cnt / 2 + 63) / 64 * 64, h1 = cnt - h0;
+            const char* in0 = (const char*)m->cur_in;
+            HIP_TRY(hipEventRecord(m->ev_fork, m->stream));
+            HIP_TRY(hipStreamWaitEvent(m->stream2, m->ev_fork, 0));
+            std::vector<size_t> order;
+            for (size_t si = 0; si < m->steps.size(); ++si)
+                if (!(logits && m->steps[si].is_final_softmax)) order.push_back(si);
+            const int L = std::max(0, m->lane_lag);
+            for (size_t k = 0; k < order.size() + (size_t)L; ++k) {
+                if (k < order.size()) {
+                    m->lane_off = 0; m->cur_in = in0;
+                    if ((rc = m->steps[order[k]].run(m->stream, h0))) { m->lane_off = 0; return rc; }
+                }
+                if (k >= (size_t)L) {
+                    m->lane_off = h0; m->cur_in = in0 + (size_t)h0 * frame_bytes;
+                    rc = m->steps[order[k - L]].run(m->stream2, h1);
+                    m->lane_off = 0; m->cur_in = in0;
+                    if (rc) return rc;
+                }
+            }
+            m->lane_off = 0; m->cur_in = in0;
+            HIP_TRY(hipEventRecord(m->ev_join, m->stream2));
+            HIP_TRY(hipStreamWaitEvent(m->stream, m->ev_join, 0));
+        } else
         for (size_t si = 0; si < m->steps.size(); ++si) {
             Step& st = m->steps[si];
             if (logits && st.is_final_softmax) continue;
@@ -825,6 +863,11 @@ int load_common(th_model* m) {
     HIP_TRY(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&m->d2h_stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&m->stream2, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+    if (const char* e = getenv("TH_LANES")) m->lanes = atoi(e) == 2 ? 2 : 1;
+    if (const char* e = getenv("TH_LANE_LAG")) m->lane_lag = std::max(0, atoi(e));
     for (int r = 0; r < th_model::kRing; ++r) {
         HIP_TRY(hipEventCreateWithFlags(&m->ev_h2d[r], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&m->ev_free[r], hipEventDisableTiming));
@@ -897,6 +940,7 @@ void th_model_free(th_model* m) {
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     if (m->copy_stream) (void)hipStreamSynchronize(m->copy_stream);
     if (m->d2h_stream) (void)hipStreamSynchronize(m->d2h_stream);
+    if (m->stream2) (void)hipStreamSynchronize(m->stream2);
     for (float* p : m->dev_allocs) (void)hipFree(p);
     for (Buffer& b : m->bufs) if (b.dev) (void)hipFree(b.dev);
     for (int r = 0; r < th_model::kRing; ++r) {
@@ -910,6 +954,9 @@ void th_model_free(th_model* m) {
         if (t.computed) (void)hipEventDestroy(t.computed);
         if (t.done) (void)hipEventDestroy(t.done);
     }
+    if (m->stream2) (void)hipStreamDestroy(m->stream2);
+    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+    if (m->ev_join) (void)hipEventDestroy(m->ev_join);
     if (m->copy_stream) (void)hipStreamDestroy(m->copy_stream);
     if (m->d2h_stream) (void)hipStreamDestroy(m->d2h_stream);
     for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
