@@ -262,12 +262,11 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
                             if (has_pre) {
                                 const int c0 = ch * CI + (dst[u] % CS4) * 4;
                                 float e[4] = {val[u].x, val[u].y, val[u].z, val[u].w};
+                                if (a.pre.scale) {
 #pragma unroll
-                                for (int k = 0; k < 4; ++k) {
-                                    float x = e[k];
-                                    if (a.pre.scale) x = fmaf(x, a.pre.scale[c0 + k], a.pre.shift[c0 + k]);
-                                    e[k] = th_act(x, a.pre.act, a.pre.alpha);
+                                    for (int k = 0; k < 4; ++k) e[k] = fmaf(e[k], a.pre.scale[c0 + k], a.pre.shift[c0 + k]);
                                 }
+                                th_act_vec<4>(e, a.pre.act, a.pre.alpha);   // decoded once per vector (see device_math.h)
                                 val[u] = make_float4(e[0], e[1], e[2], e[3]);
                             }
                             A4[dst[u]] = val[u];
@@ -307,15 +306,16 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_mfma(co
                         const int v = i / CI4, g = i % CI4;
                         if (has_pre && off[u] >= 0) {
                             const int c0 = ch * CI + g * 4;
-                            float e[4] = {val[u].x, val[u].y, val[u].z, val[u].w};
+                            float e[4] = {val[u].x, val[u].y, val[u].z, val[u].w}, y[4];
 #pragma unroll
                             for (int k = 0; k < 4; ++k) {
-                                if (c0 + k < a.Cin) {
-                                    float x = e[k];
-                                    if (a.pre.scale) x = fmaf(x, a.pre.scale[c0 + k], a.pre.shift[c0 + k]);
-                                    e[k] = th_act(x, a.pre.act, a.pre.alpha);
-                                }
+                                const int c = min(c0 + k, a.Cin - 1);
+                                y[k] = a.pre.scale ? fmaf(e[k], a.pre.scale[c], a.pre.shift[c]) : e[k];
                             }
+                            th_act_vec<4>(y, a.pre.act, a.pre.alpha);   // decoded once per vector (see device_math.h)
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+                                if (c0 + k < a.Cin) e[k] = y[k];
                             val[u] = make_float4(e[0], e[1], e[2], e[3]);
                         }
                         A4[(size_t)v * CS4 + g] = val[u];
@@ -909,15 +909,16 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
         const int v = i / CI4, g = i % CI4;
         if (has_pre && ok) {
             const int c0 = ch * CI + g * 4;
-            float e[4] = {val.x, val.y, val.z, val.w};
+            float e[4] = {val.x, val.y, val.z, val.w}, y[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                if (c0 + k < a.Cin) {
-                    float x = e[k];
-                    if (a.pre.scale) x = fmaf(x, a.pre.scale[c0 + k], a.pre.shift[c0 + k]);
-                    e[k] = th_act(x, a.pre.act, a.pre.alpha);
-                }
+                const int c = min(c0 + k, a.Cin - 1);
+                y[k] = a.pre.scale ? fmaf(e[k], a.pre.scale[c], a.pre.shift[c]) : e[k];
             }
+            th_act_vec<4>(y, a.pre.act, a.pre.alpha);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (c0 + k < a.Cin) e[k] = y[k];
             val = make_float4(e[0], e[1], e[2], e[3]);
         }
         A4[(size_t)v * CS4 + g] = val;
@@ -1155,19 +1156,25 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) k_conv_n16(con
                 long long prof_c = clock64();
 #endif
                 if (do_pf) {
-                    // BN -> activation prologue in registers BEFORE the barrier (overlaps the other waves' last MFMAs)
+                    // BN -> activation prologue in registers BEFORE the barrier (overlaps the other waves' last MFMAs).  The
+                    // activation is decoded ONCE for all 4 PF values (th_act_vec): th_act's switch inlined per element
+                    // cost ~10 scalar + vector instructions per value in this serial phase of the chunk.
+                    if (has_pre && pch * CI + (tid % CI4) * 4 < a.Cin) {   // (a thread's vectors all cover the same 4 channels)
+                        float xv[4 * PF];
 #pragma unroll
-                    for (int u = 0; u < PF; ++u) {
-                        float4 v = pfv[u];   // zeros where nothing was fetched
-                        if (has_pre && pf_boff[u] != OOB && pch * CI + (tid % CI4) * 4 < a.Cin) {
-                            if (a.pre.scale) {
-                                v.x = fmaf(v.x, psc.x, psh.x); v.y = fmaf(v.y, psc.y, psh.y);
-                                v.z = fmaf(v.z, psc.z, psh.z); v.w = fmaf(v.w, psc.w, psh.w);
-                            }
-                            v.x = th_act(v.x, a.pre.act, a.pre.alpha); v.y = th_act(v.y, a.pre.act, a.pre.alpha);
-                            v.z = th_act(v.z, a.pre.act, a.pre.alpha); v.w = th_act(v.w, a.pre.act, a.pre.alpha);
+                        for (int u = 0; u < PF; ++u) {
+                            xv[4 * u] = pfv[u].x; xv[4 * u + 1] = pfv[u].y; xv[4 * u + 2] = pfv[u].z; xv[4 * u + 3] = pfv[u].w;
                         }
-                        pfv[u] = v;
+                        if (a.pre.scale) {
+#pragma unroll
+                            for (int u = 0; u < PF; ++u) {
+                                xv[4 * u] = fmaf(xv[4 * u], psc.x, psh.x); xv[4 * u + 1] = fmaf(xv[4 * u + 1], psc.y, psh.y);
+                                xv[4 * u + 2] = fmaf(xv[4 * u + 2], psc.z, psh.z); xv[4 * u + 3] = fmaf(xv[4 * u + 3], psc.w, psh.w);
+                            }
+                        }
+                        th_act_vec<4 * PF>(xv, a.pre.act, a.pre.alpha);
+#pragma unroll
+                        for (int u = 0; u < PF; ++u) pfv[u] = make_float4(xv[4 * u], xv[4 * u + 1], xv[4 * u + 2], xv[4 * u + 3]);   // slots that fetched nothing are never stored
                     }
                     __syncthreads();   // every wave is done reading chunk ch
 #pragma unroll

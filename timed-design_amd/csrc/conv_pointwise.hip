@@ -171,10 +171,9 @@ __global__ void __launch_bounds__(256, NT == 4 ? 2 : (KMAX == 16 && NT == 2 ? 3 
                     if (has_pre) {
                         const float4 sc = *reinterpret_cast<const float4*>(psc + (k0 + u) * 8 + 4 * h);
                         const float4 sh = *reinterpret_cast<const float4*>(psh + (k0 + u) * 8 + 4 * h);
-                        v.x = th_act(fmaf(v.x, sc.x, sh.x), a.pre.act, a.pre.alpha);
-                        v.y = th_act(fmaf(v.y, sc.y, sh.y), a.pre.act, a.pre.alpha);
-                        v.z = th_act(fmaf(v.z, sc.z, sh.z), a.pre.act, a.pre.alpha);
-                        v.w = th_act(fmaf(v.w, sc.w, sh.w), a.pre.act, a.pre.alpha);
+                        float y[4] = {fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w)};
+                        th_act_vec<4>(y, a.pre.act, a.pre.alpha);     // the activation decoded once per vector, not per element
+                        v = make_float4(y[0], y[1], y[2], y[3]);
                     }
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
