@@ -215,8 +215,14 @@ __global__ void __launch_bounds__(WAVES * 64, 3) k_conv_first(const ConvFirstArg
         }
         // ---- epilogue in registers (see conv_mfma.hip for the row/lane layout) ----------------------
         float x[16];
+        if (POOL_FIRST) {
+            // (the bias is added to the 2 pooled values, not to all 16 sums: max commutes with "+ bv" bit for bit)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) x[i] = acc[i] + bv;
+            for (int i = 0; i < 16; ++i) x[i] = acc[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) x[i] = acc[i] + bv;
+        }
         if (POOL_FIRST) {
             // max-pooling commutes with a monotone non-decreasing chain (ELU/ReLU/BN with scale >= 0 ...): pool the raw
             // sums and evaluate the chain on the 4 pooled values of this lane instead of all 16 (TIMED block 1: 8x fewer
@@ -228,7 +234,7 @@ __global__ void __launch_bounds__(WAVES * 64, 3) k_conv_first(const ConvFirstArg
                 m4[q] = fmaxf(m, __shfl_xor(m, 32));
             }
             // lanes of half h own pooled voxels 2h and 2h+1 of the tile
-            float y0 = h ? m4[2] : m4[0], y1 = h ? m4[3] : m4[1];
+            float y0 = (h ? m4[2] : m4[0]) + bv, y1 = (h ? m4[3] : m4[1]) + bv;
             th_post2(y0, y1, cc, a.post);
             const int o0 = cok ? rowout[mt * 4 + 2 * h] : -1, o1 = cok ? rowout[mt * 4 + 2 * h + 1] : -1;
             if (o0 >= 0) outb[o0 + co] = y0;
