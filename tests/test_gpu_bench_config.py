@@ -88,3 +88,30 @@ def test_chunk4096_host_resident_async_equals_device_resident(gpu, lib):
     model.close()
     d_frames.free()
     d_p.free()
+
+
+def test_two_lanes_give_the_same_bits(gpu, lib, monkeypatch):
+    """TH_LANES=2 (the halves of a chunk on two streams, each in its own half of every arena, the second lane a few plan
+    steps behind): only the schedule changes — every row bit-identical to the one-lane run, for a ragged multi-chunk batch"""
+    cfg, weights = synth.densecpd_synth(20)
+    n = 2 * 1024 + 300
+    frame_bytes = 21 * 21 * 21 * 6 * 4
+    d_frames = engine.DeviceBuffer(n * frame_bytes, gpu)
+    d_p = engine.DeviceBuffer(n * 20 * 4, gpu)
+    _lib.check(lib.th_dev_synth_frames(gpu, C.c_void_p(d_frames.ptr), n, 21, 6, 200, 11))
+    one = engine.HipFrameModel.from_keras(cfg, weights, device=gpu)
+    one.set_chunk(1024)
+    one.predict_device(d_frames.ptr, n, d_p.ptr)
+    ref = d_p.download((n, 20), np.float32)
+    one.close()
+    for lag in ("0", "1", "4"):
+        monkeypatch.setenv("TH_LANES", "2")
+        monkeypatch.setenv("TH_LANE_LAG", lag)
+        two = engine.HipFrameModel.from_keras(cfg, weights, device=gpu)
+        two.set_chunk(1024)
+        two.predict_device(d_frames.ptr, n, d_p.ptr)
+        got = d_p.download((n, 20), np.float32)
+        two.close()
+        assert np.array_equal(got, ref), f"two lanes (lag {lag}) changed {np.count_nonzero((got != ref).any(1))} rows"
+    d_frames.free()
+    d_p.free()

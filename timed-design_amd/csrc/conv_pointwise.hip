@@ -260,6 +260,16 @@ __global__ void __launch_bounds__(256, (NT == 4 || KMAX == 16) ? 2 : 3) k_conv_p
             av[u] = __builtin_amdgcn_raw_buffer_load_b128(rin, off, 0, 0);
         }
     };
+    // this lane's bias values, fetched ONCE: a global load inside the tile loop is the YOUNGEST memory operation of the wave,
+    // so waiting for it is s_waitcnt vmcnt(0) — it would drain the next tile's prefetch in front of every epilogue (the
+    // compiler cannot hoist it itself: the stores to `out` might alias)
+    float bias_r[NT];
+    const int npost = __builtin_amdgcn_readfirstlane(a.post.n);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int co = nt * 32 + j;
+        bias_r[nt] = a.bias ? a.bias[co < a.Cout ? co : 0] : 0.f;
+    }
     auto compute_store = [&](const u32x4 (&av)[KMAX], unsigned tile) {
         f32x16 acc[NT];
 #pragma unroll
@@ -311,10 +321,10 @@ __global__ void __launch_bounds__(256, (NT == 4 || KMAX == 16) ? 2 : 3) k_conv_p
             const bool cok = co < a.Cout;
             const int cc = cok ? co : 0;
             float x[16];
-            const float bv = a.bias ? a.bias[cc] : 0.f;
+            const float bv = bias_r[nt];
 #pragma unroll
             for (int r = 0; r < 16; ++r) x[r] = acc[nt][r] + bv;
-            th_post16(x, cc, a.post);
+            if (npost) th_post16(x, cc, a.post);    // (its BatchNorm constants are loaded in the loop: layers with an epilogue chain pay the drain)
             if (POOL == 0 && a.out_dense && tile * 32 + 32 <= a.nrows) {
                 // whole tile in range, rows at a constant byte stride: ONE vector offset per (tile, n-tile) and the row
                 // displacement as the instruction's scalar offset — no per-store address arithmetic (it was ~8 VALU
