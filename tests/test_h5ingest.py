@@ -205,3 +205,63 @@ def test_bulk_reader_requires_matching_dtype_kind():
         assert h5lite.read_many_direct([ds], [np.empty(w.shape, np.int8)]) == [False]
         ok = np.empty(w.shape, bool)
         assert h5lite.read_many_direct([ds], [ok]) == [True] and np.array_equal(ok, w)
+
+
+def test_resolver_survives_truncated_and_corrupted_files():
+    """th_h5_resolve parses untrusted bytes.  The valid fixture is truncated at every 97th byte and corrupted with
+    random byte flips inside the object headers; the buffer handed to the library is EXACTLY file-sized and sits at the end of
+    a page-aligned allocation followed by a PROT_NONE guard page, so a read past the end is a SIGSEGV, not luck.  Every call
+    must return (status bits clear where it cannot parse) — the caller then falls back to the general reader."""
+    import ctypes as C
+    import mmap
+    from timed_hip import _lib, h5lite
+    lib = _lib.load()
+    path = os.path.join(G, "frames_tiny.hdf5")
+    data = open(path, "rb").read()
+    with h5lite.File(path) as f:
+        addrs = []
+        for pdb in f:
+            for chain in f[pdb]:
+                links = f[pdb][chain]._load()
+                addrs += [links[k] for k in links]
+        base = f._base
+    addrs = np.asarray(addrs, dtype=np.int64)
+    n = len(addrs)
+    libc = C.CDLL(None, use_errno=True)
+    libc.mprotect.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+    page = mmap.PAGESIZE
+
+    def run(buf: bytes):
+        size = len(buf)
+        if size == 0:
+            return None
+        npages = (size + page - 1) // page + 1
+        m = mmap.mmap(-1, npages * page)
+        start = (npages - 1) * page - size                   # the data ends exactly where the guard page begins
+        m[start:start + size] = buf
+        addr = C.addressof(C.c_char.from_buffer(m))
+        assert libc.mprotect(addr + (npages - 1) * page, page, 0) == 0
+        status = np.zeros(n, np.int32); btree = np.zeros(n, np.int64); geom = np.zeros(40, np.int64)
+        num = np.zeros((n, 20)); sbuf = np.zeros((n, 16), np.uint8)
+        rc = lib.th_h5_resolve(C.c_void_p(addr + start), size, base, n, addrs.ctypes.data_as(C.POINTER(C.c_int64)), b"encoded_residue",
+                               num.ctypes.data, 20, b"label", sbuf.ctypes.data, 16, btree.ctypes.data_as(C.POINTER(C.c_int64)),
+                               geom.ctypes.data_as(C.POINTER(C.c_int64)), status.ctypes.data_as(C.POINTER(C.c_int)), 1)
+        libc.mprotect(addr + (npages - 1) * page, page, 3)
+        del addr
+        m.close()
+        return rc, status
+
+    rc, status = run(data)
+    # the intact file resolves completely (bit 1 = "same geometry as the first dataset": the fixture mixes two dtypes)
+    assert rc == 0 and np.all(status & 2) and np.all(status & 4) and np.count_nonzero(status & 1) >= n // 2
+    for cut in range(len(data) - 1, 64, -97):                # truncations: headers, heaps, chunk data cut anywhere
+        rc, status = run(data[:cut])
+        assert rc == 0
+    rng = np.random.default_rng(0)
+    lo, hi = int(addrs.min()) + base, min(len(data), int(addrs.max()) + base + 2048)
+    for _ in range(300):                                     # random corruption inside the object-header region
+        b = bytearray(data)
+        for pos in rng.integers(lo, hi, size=int(rng.integers(1, 12))):
+            b[pos] = int(rng.integers(0, 256))
+        rc, status = run(bytes(b))
+        assert rc == 0
