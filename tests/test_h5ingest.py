@@ -265,3 +265,29 @@ def test_resolver_survives_truncated_and_corrupted_files():
             b[pos] = int(rng.integers(0, 256))
         rc, status = run(bytes(b))
         assert rc == 0
+
+
+def test_load_batch_on_corrupted_files_raises_or_returns(tmp_path):
+    """the whole ingest path (h5lite walk -> th_h5_resolve -> th_h5_read_chunked_as, general reader as fallback) on files with
+    random byte flips anywhere: a Python exception or a result, never a crash of the process"""
+    path = os.path.join(G, "frames_tiny.hdf5")
+    data = open(path, "rb").read()
+    rng = np.random.default_rng(1)
+    outcomes = {"ok": 0, "raised": 0}
+    for k in range(60):
+        b = bytearray(data)
+        for pos in rng.integers(8, len(b), size=int(rng.integers(1, 6))):
+            b[pos] = int(rng.integers(0, 256))
+        p = tmp_path / f"c{k}.hdf5"
+        p.write_bytes(bytes(b))
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                flat, _ = utils.create_flat_dataset_map(p)
+                X, y = utils.load_batch(p, flat)
+            assert X.shape[0] == len(flat)
+            outcomes["ok"] += 1
+        except Exception:
+            outcomes["raised"] += 1
+        p.unlink()
+    assert outcomes["ok"] + outcomes["raised"] == 60 and outcomes["ok"] > 0
