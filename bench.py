@@ -41,8 +41,45 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense 
 PEAK_HBM_GBS = 8000.0           # HBM3E spec
 
 
+def keras_cpu_baseline(cfg, weights, topology: str, budget_s: float = 15.0):
+    """The reference's own CPU path — tf.keras Model.predict (reference predict.py:142, TensorFlow 2.13 on the host cores) —
+    on the same topology, when TensorFlow is importable on the measuring host (BASELINE.md B1').  It is not
+    in this image, so this normally returns None and the NumPy/BLAS port below is reported instead."""
+    try:
+        import tensorflow as tf      # noqa: F401
+    except Exception:
+        return None
+    from timed_hip import synth
+    try:
+        tf.config.set_visible_devices([], "GPU")
+        model = tf.keras.Model.from_config(cfg["config"])
+        for layer in model.layers:
+            if weights.get(layer.name):
+                layer.set_weights([np.asarray(a) for a in weights[layer.name]])
+        n, dt = 64, 0.0
+        model.predict(synth.synthetic_frames(8, seed=999), batch_size=500, verbose=0)
+        while True:
+            frames = synth.synthetic_frames(n, seed=1000)
+            t0 = time.perf_counter()
+            model.predict(frames, batch_size=500, verbose=0)          # batch size of scripts/run_benchmark_models.sh:1-6
+            dt = time.perf_counter() - t0
+            if dt >= 10.0 or n >= 16384:
+                break
+            n = int(min(16384, max(2 * n, n * budget_s / max(dt, 1e-3))))
+        return dict(value=n / dt, unit="frames/s", cores=os.cpu_count(), kind="reference",
+                    sample=f"{n} synthetic frames of {topology} through tf.keras Model.predict(batch_size=500) of TensorFlow "
+                           f"{tf.__version__} on the host CPUs, {dt:.1f} s wall")
+    except Exception as e:
+        print(f"[bench] TensorFlow is importable but the Keras baseline failed ({e!r}); using the NumPy port", file=sys.stderr)
+        return None
+
+
 def cpu_baseline(cfg, weights, topology: str, budget_s: float = 15.0, min_s: float = 10.0):
-    """Time the oracle (NumPy + multithreaded BLAS) on a bounded sample of the same workload."""
+    """Time the oracle (NumPy + multithreaded BLAS) on a bounded sample of the same workload — or, when TensorFlow is
+    importable on this host, the reference's own Keras CPU path."""
+    ref = keras_cpu_baseline(cfg, weights, topology, budget_s)
+    if ref is not None:
+        return ref
     from oracle import cnn_oracle
     from timed_hip import _lib, synth
     # the container may expose every host core but enforce a CPU quota (cgroup cpu.max): a BLAS pool wider than the
