@@ -231,6 +231,22 @@ int th_h5_read_chunked_as(const void* file, int64_t file_len, int64_t base, int6
  * written (zeros) */
 int th_h5_read_contiguous_as(const void* file, int64_t file_len, int64_t base, int64_t n_datasets, const int64_t* data_addrs,
                              void* const* dests, int64_t count, int esz, int conv);
+/* The same datasets decoded ON THE DEVICE (f-1: the host's inflate rate — 1.3 k frames/s per core — is what limits predict.py on
+ * real gzip .hdf5 datasets, reference design_utils/utils.py:514-529).  Only the chunk B-trees are walked on the host; the
+ * COMPRESSED chunk bytes are copied to the GPU as they lie in the file, inflated there one lane per chunk, and placed into d_out —
+ * device memory on `device`, [n_datasets][shape...] of float32 when conv = 1 (float64 data: the cast Keras applies) or of the
+ * stored element type when conv = 0.  Supports the pipeline aposteriori writes (n_filters = 1, filter id 1 = deflate, every chunk
+ * compressed); TH_EUNSUP for anything else (use th_h5_read_chunked_as).  Never-allocated chunks read as zeros.  Synchronous. */
+int th_h5_decode_device(const void* file, int64_t file_len, int64_t base, int64_t n_datasets, const int64_t* btree_addrs, int rank,
+                        const int64_t* shape, const int64_t* chunk, int esz, int n_filters, const int* filter_ids, int conv, int device,
+                        void* d_out);
+/* n independent zlib (wrapped = 1) or raw DEFLATE (wrapped = 0) streams inflated on `device`: stream i is
+ * comp[src_off[i] .. + src_len[i]) and decodes to exactly dst_len[i] bytes at out[dst_off[i]] (8-byte aligned).  comp / out are
+ * host buffers.  status_out[i] (optional): 0, or why stream i failed (1 input exhausted, 2 output overrun, 3 bad zlib header,
+ * 4 invalid code, 5 distance too far back, 6 bad code table, 7 bad stored block, 8 ended short of dst_len).  TH_EIO if any failed. */
+int th_inflate_many(int device, const void* comp, int64_t comp_len, int64_t n, const int64_t* src_off, const int64_t* src_len,
+                    const int64_t* dst_off, const int64_t* dst_len, void* out, int64_t out_len, int wrapped, int* status_out);
+
 /* Resolve MANY datasets' object headers in one call — the per-residue `dataset[pdb][chain][res]` header parse and the
  * two attribute reads of load_batch (`encoded_residue`, utils.py:529) and create_flat_dataset_map (`label`,
  * utils.py:375).  ohdr_addrs[n] are object-header addresses (from the chain groups' symbol tables).  Outputs:

