@@ -59,6 +59,8 @@ extern "C" {
 #define TH_PREDICT_LOGITS 1u    /* skip the final Softmax: return its input (parity on the logits) */
 #define TH_PREDICT_OUT_DEVICE 2u /* th_predict/_async: probs_out is memory of the model's DEVICE (frames still come from the
                                   * host); the rows stay in HBM, e.g. for th_comm_gather_rows */
+#define TH_PREDICT_IN_DEVICE 4u  /* th_predict/_async: `frames` is memory of the model's DEVICE already (e.g. frames that
+                                  * th_h5_decode_device inflated there): no host->device copy; it must stay valid until the wait */
 
 typedef struct th_model th_model;
 typedef struct th_comm th_comm;

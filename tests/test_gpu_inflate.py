@@ -115,3 +115,69 @@ def test_corrupt_streams_end_in_a_status(gpu, lib):
     assert rc == -2 and np.count_nonzero(status) > 200                # TH_EIO: most of them are rejected
     assert raw[-8:].tolist() == [0xAB] * 8
     assert lib.th_inflate_many(gpu, None, 0, 1, None, None, None, None, None, 0, 1, None) == -1
+
+
+def _write_dataset(path, n_res=40, gaussian=True, seed=0):
+    """an aposteriori-layout .hdf5 through timed_hip.h5write (gzip, one chunk per residue dataset)"""
+    from timed_hip import voxeliser
+    rng = np.random.default_rng(seed)
+    if gaussian:
+        frames = (rng.random((n_res, 21, 21, 21, 6)) * (rng.random((n_res, 21, 21, 21, 6)) < 0.08)).astype(np.float32)
+    else:
+        frames = (rng.random((n_res, 21, 21, 21, 6)) < 0.03).astype(np.float32)
+    three = ["ALA", "CYS", "ASP", "GLU", "PHE", "GLY", "HIS", "ILE", "LYS", "LEU", "MET", "ASN", "PRO", "GLN", "ARG", "SER", "THR", "VAL",
+             "TRP", "TYR"]
+    flat = [("1abc" if i < n_res // 2 else "2xyz", "A", str(i + 1), three[i % 20]) for i in range(n_res)]
+    labels = np.zeros((n_res, 20), np.uint8)
+    labels[np.arange(n_res), np.arange(n_res) % 20] = 1
+    voxeliser.write_hdf5(path, frames, labels, flat, gaussian=gaussian, atom_encoder=list("CNOQP") + ["CA"])
+    return frames, labels, flat
+
+
+@pytest.mark.parametrize("gaussian", [True, False])
+def test_hdf5_frames_decoded_on_the_gpu_equal_the_host_reader(gpu, tmp_path, gaussian):
+    """th_h5_decode_device (B-trees on the host, DEFLATE + placement + float64 -> float32 on the GPU) against load_batch"""
+    import warnings
+    from design_utils import utils
+    p = tmp_path / "d.hdf5"
+    frames, labels, flat = _write_dataset(p, gaussian=gaussian)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fmap, _ = utils.create_flat_dataset_map(p)
+        X, y = utils.load_batch(p, fmap, dtype=np.float32)
+        got = utils.load_batch_device(p, np.array(fmap), device=gpu)
+    assert got is not None, "the deflate-only dataset must take the device path"
+    dev, yd = got
+    assert dev.shape == X.shape and np.array_equal(yd, y)
+    host = dev.buffer.download(dev.shape, dev.dtype)
+    assert np.array_equal(host.astype(np.float32), X.astype(np.float32))
+    sub = np.array(fmap)[[5, 3, 30, 7]]                         # an arbitrary selection of residues, not a contiguous range
+    d2, y2 = utils.load_batch_device(p, sub, device=gpu)
+    X2, yy2 = utils.load_batch(p, sub, dtype=np.float32)
+    assert np.array_equal(d2.buffer.download(d2.shape, d2.dtype).astype(np.float32), X2.astype(np.float32)) and np.array_equal(y2, yy2)
+
+
+def test_predict_py_with_gpu_inflate_writes_the_same_files(gpu, tmp_path, monkeypatch):
+    import warnings
+    import predict
+    from timed_hip import pack, synth
+    p = tmp_path / "d.hdf5"
+    _write_dataset(p, n_res=50)
+    cfg, weights = synth.timed_synth(20, widths=(8, 16), side=21, in_channels=6, seed=3)
+    mp = tmp_path / "M.pack"
+    mp.write_bytes(pack.keras_to_pack(cfg, weights))
+    a, b = tmp_path / "a", tmp_path / "b"
+    a.mkdir(); b.mkdir()
+    calls = []
+    from design_utils import utils
+    real = utils.load_batch_device
+    monkeypatch.setattr(utils, "load_batch_device", lambda *x, **k: (calls.append(1), real(*x, **k))[1])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        predict.load_dataset_and_predict([mp], p, batch_size=7, dataset_map_path=a / "datasetmap.txt", path_to_output=a, frames_per_call=16)
+        assert len(calls) == 4                                   # 50 frames in groups of 14 (2 reference batches): every group on the GPU
+        monkeypatch.setenv("TIMED_GPU_INFLATE", "0")
+        predict.load_dataset_and_predict([mp], p, batch_size=7, dataset_map_path=b / "datasetmap.txt", path_to_output=b, frames_per_call=16)
+        assert len(calls) == 4
+    for fn in sorted(x.name for x in a.iterdir()):
+        assert (a / fn).read_bytes() == (b / fn).read_bytes(), fn

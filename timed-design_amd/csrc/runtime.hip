@@ -1037,7 +1037,7 @@ static int predict_async_locked(th_model* m, const void* frames, int dtype, int6
     // more than the overlap wins.  Overlap across small batches comes from submitting the next ticket early.
     const int64_t piece = std::min<int64_t>(m->chunk, std::max<int64_t>(n, 1));
     const size_t need_in = frame_bytes * (size_t)piece;
-    if (m->in_ring_bytes < need_in) {
+    if (!(flags & TH_PREDICT_IN_DEVICE) && m->in_ring_bytes < need_in) {
         // growing the ring: nothing may still be reading the old buffers
         HIP_TRY(hipStreamSynchronize(m->copy_stream));
         HIP_TRY(hipStreamSynchronize(m->stream));
@@ -1064,12 +1064,17 @@ static int predict_async_locked(th_model* m, const void* frames, int dtype, int6
         HIP_TRY(hipHostMalloc((void**)&t.h_out, std::max<size_t>(floats, 1024) * sizeof(float), hipHostMallocDefault));
         t.h_out_floats = std::max<size_t>(floats, 1024);
     }
-    const bool pinned = n > 0 && host_ptr_is_pinned(frames);
+    const bool in_device = (flags & TH_PREDICT_IN_DEVICE) != 0;         // frames are on the device already: no ring, no copies
+    const bool pinned = !in_device && n > 0 && host_ptr_is_pinned(frames);
     // (Shorter first pieces do not help: PCIe moves 252 k fp32 frames/s against 216 k computed, so a copy only stays
     // hidden behind the previous piece's kernels if pieces grow by <= 1.17x — measured, a 256/512/1024 ramp ends within
     // 0.5 % of equal pieces.  The one unhidden copy costs ~4 ms per call: 0.94x the device-resident rate at 16 k frames,
     // 0.97x at 32 k.)
-    for (int64_t off = 0; off < n; off += piece) {
+    if (in_device && n > 0) {
+        int rc = run_device(m, frames, dtype, n, (out_on_device ? probs_out : t.d_out), flags, /*sync=*/false);
+        if (rc) return rc;
+    }
+    for (int64_t off = 0; off < n && !in_device; off += piece) {
         const int64_t cnt = std::min<int64_t>(piece, n - off);
         const int r = (int)(m->piece_counter % th_model::kRing);
         if (m->ring_used[r]) {

@@ -266,6 +266,93 @@ def load_batch(dataset_path: Path, data_point_batch: t.List[t.Tuple], dtype=None
     return X, y
 
 
+class _DevicePool:
+    """A few reusable device buffers for batches decoded on the GPU (a fresh hipMalloc / hipFree per batch costs more than
+    the decode of a small batch)."""
+
+    def __init__(self, keep: int = 6):
+        import threading
+        self.free: t.List = []
+        self.keep = keep
+        self.lock = threading.Lock()
+
+    def acquire(self, nbytes: int, device: int):
+        from timed_hip import engine
+        with self.lock:
+            for i, b in enumerate(self.free):
+                if b.device == device and b.nbytes >= nbytes:
+                    return self.free.pop(i)
+        return engine.DeviceBuffer(nbytes, device)
+
+    def release(self, buf):
+        with self.lock:
+            if len(self.free) < self.keep:
+                self.free.append(buf)
+                return
+        buf.free()
+
+
+_DEVICE_POOL = _DevicePool()
+
+
+def load_batch_device(dataset_path: Path, data_point_batch, device: int = 0):
+    """load_batch (reference utils.py:487-530) with the frames left in HBM: (DeviceFrames [n, *frame_dims] float32 — or uint8
+    for boolean datasets —, y[n, 20]) — or None when this dataset cannot take the path (not an h5lite-readable .hdf5, a filter
+    pipeline other than deflate, mixed geometries ...; the caller then uses load_batch).  The gzip chunks are inflated ON THE
+    GPU (libtimedhip th_h5_decode_device, one lane per chunk): only the compressed bytes cross PCIe — 8.7x fewer than the float64
+    frames — and no host core spends a millisecond per frame in zlib."""
+    from timed_hip import engine, framepack, h5lite
+    if framepack.is_pack(dataset_path) or framepack.is_structure(dataset_path):
+        return None
+    n = len(data_point_batch)
+    if n == 0:
+        return None
+    with open_frame_dataset(dataset_path) as dataset:
+        if not _is_h5lite_file(dataset):
+            return None
+        dims = tuple(int(d) for d in np.asarray(dataset.attrs["frame_dims"]).ravel())
+        gaussian = bool(dataset.attrs["voxels_as_gaussian"])
+        addrs = np.full(n, -1, dtype=np.int64)
+        chain_links = {}
+        for i, (pdb_code, chain_id, residue_id, *_rest) in enumerate(data_point_batch):
+            key = (str(pdb_code), str(chain_id))
+            links = chain_links.get(key)
+            if links is None:
+                try:
+                    grp = dataset[key[0]][key[1]]
+                except KeyError:
+                    return None
+                links = chain_links[key] = grp._load() if isinstance(grp, h5lite.Group) else {}
+            addrs[i] = links.get(str(residue_id), -1)
+        if np.any(addrs < 0):
+            return None
+        res = h5lite.resolve_many(dataset, addrs, num_attr="encoded_residue", num_len=20)
+        if res is None or not np.all((res["status"] & 3) == 3):
+            return None
+        g = res["geom"]
+        rank = int(g[0])
+        if tuple(int(v) for v in g[1:1 + rank]) != dims:
+            return None
+        cls, esz = int(g[16]), int(g[15])
+        if gaussian and cls == 1 and esz == 8:
+            dtype, as_f32 = np.float32, True
+        elif not gaussian and esz == 1 and cls in (0, 8):
+            dtype, as_f32 = np.uint8, False
+        else:
+            return None
+        nbytes = n * int(np.prod(dims)) * np.dtype(dtype).itemsize
+        buf = _DEVICE_POOL.acquire(nbytes, device)
+        ok = False
+        try:
+            ok = h5lite.decode_resolved_device(dataset, res, buf.ptr, device, as_float32=as_f32)
+        finally:
+            if not ok:
+                _DEVICE_POOL.release(buf)
+        if not ok:
+            return None
+        return engine.DeviceFrames(buf, (n, *dims), dtype, on_release=_DEVICE_POOL.release), np.asarray(res["num"], dtype=float)
+
+
 def _is_h5lite(obj) -> bool:
     from timed_hip import h5lite
     return isinstance(obj, h5lite.Dataset)

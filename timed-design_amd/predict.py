@@ -162,7 +162,7 @@ def _row_groups(n_rows, batch_size, start_batch, frames_per_call):
     return [(lo, min(lo + per_call, n_rows)) for lo in range(start_batch * batch_size, n_rows, per_call)]
 
 
-def _run_groups(models, dataset_path, flat_dataset_map, groups, consume):
+def _run_groups(models, dataset_path, flat_dataset_map, groups, consume, gpu_decode=False):
     """Pipeline over the call groups, three stages on three threads:
          loader thread   load_batch of group g+1 (reference utils.py:487-530)
          this thread     th_predict_async of group g, round-robin over ``models`` (the host->device copy of pageable
@@ -195,8 +195,18 @@ def _run_groups(models, dataset_path, flat_dataset_map, groups, consume):
         finally:
             load_seconds[0] += time.perf_counter() - t0
 
+    decode_on_gpu = [bool(gpu_decode) and not framepack.is_pack(dataset_path) and not framepack.is_structure(dataset_path)]
+
     def _load(k):
         lo, hi = groups[k]
+        if decode_on_gpu[0]:
+            # gzip .hdf5: the chunks of this group are inflated ON the GPU that will predict it (th_h5_decode_device) — the
+            # frames never exist on the host; a dataset that cannot take the path (other filters, h5py in use ...) says so
+            # once and the host reader takes over
+            got = du.load_batch_device(dataset_path, flat_dataset_map[lo:hi], device=models[k % len(models)].device)
+            if got is not None:
+                return got
+            decode_on_gpu[0] = False
         slot = k % ring_size
         # float32 frames: the rounding Keras applies to load_batch's float64 anyway, done while the chunks are placed
         X, y = du.load_batch(dataset_path, flat_dataset_map[lo:hi], dtype=np.float32, out=ring[slot] if slot < len(ring) else None)
@@ -302,6 +312,8 @@ def load_dataset_and_predict(
     if rank == 0:
         print(f"Predicting {n_classes} classes per residue ({'rotamer' if predict_rotamers else 'residue'} mode)")
     loader = model_loader or engine.load_model
+    # gzip .hdf5 datasets are inflated on the GPU unless TIMED_GPU_INFLATE=0 (or a model double without a device is in use)
+    gpu_decode = model_loader is None and os.environ.get("TIMED_GPU_INFLATE", "1") != "0"
     if world > 1:
         device_ids = [local_rank if devices is None else list(devices)[local_rank % len(devices)]]
         if model_loader is None:
@@ -348,7 +360,7 @@ def load_dataset_and_predict(
                     files = _OutputFiles(index, model_name, flat_dataset_map, path_to_output, predict_rotamers, codec,
                                          resume=start_batch > 0, sink=_TextSink())
                     gathered = _predict_sharded(handles[0], gather, rank, world, dataset_path, flat_dataset_map, batch_size,
-                                                start_batch, frames_per_call, files)
+                                                start_batch, frames_per_call, files, gpu_decode=gpu_decode)
                     if rank != 0:
                         continue
                     files.set_gathered(gathered)
@@ -356,7 +368,8 @@ def load_dataset_and_predict(
                     files = _OutputFiles(index, model_name, flat_dataset_map, path_to_output, predict_rotamers, codec,
                                          resume=start_batch > 0)
                     _run_groups(handles, dataset_path, flat_dataset_map,
-                                _row_groups(len(flat_dataset_map), batch_size, start_batch, frames_per_call), files.append)
+                                _row_groups(len(flat_dataset_map), batch_size, start_batch, frames_per_call), files.append,
+                                gpu_decode=gpu_decode)
             finally:
                 for h in handles:
                     h.close()
@@ -382,7 +395,8 @@ def load_dataset_and_predict(
     return (flat_dataset_map, *outputs)
 
 
-def _predict_sharded(model, gather, rank, world, dataset_path, flat_dataset_map, batch_size, start_batch, frames_per_call, files):
+def _predict_sharded(model, gather, rank, world, dataset_path, flat_dataset_map, batch_size, start_batch, frames_per_call, files,
+                     gpu_decode=False):
     """One process per GPU: rows [row0, N) are cut into ``world`` contiguous shards (timed_hip.distributed.shard_bounds);
     this rank predicts its shard, formats the text of its own rows (``files``, an in-memory sink) while the GPU works,
     the probability shards are gathered to rank 0 in rank order = map order and the file parts are put
@@ -416,12 +430,13 @@ def _predict_sharded(model, gather, rank, world, dataset_path, flat_dataset_map,
             class _ToDevice:          # the model facade _run_groups drives: outputs land in d_local at the shard row
                 def __init__(self):
                     self.row = 0
+                    self.device = model.device
 
                 def predict_async(self, X):
                     t = _RowsOnDevice(model.predict_async_device(X, d_local.ptr + self.row * width * 4), self.row, len(X))
                     self.row += len(X)
                     return t
-            _run_groups([_ToDevice()], dataset_path, shard, groups, files.append)
+            _run_groups([_ToDevice()], dataset_path, shard, groups, files.append, gpu_decode=gpu_decode)
             d_all = engine.DeviceBuffer(max(1, n * width * 4), model.device) if rank == 0 else None
             gather.gather_rows_device(d_local.ptr, counts, width, 0, d_all.ptr if d_all else 0)
             probs = d_all.download((n, width), np.float32) if rank == 0 else None
@@ -433,7 +448,7 @@ def _predict_sharded(model, gather, rank, world, dataset_path, flat_dataset_map,
                 local[cursor[0]:cursor[0] + len(y)] = p
                 cursor[0] += len(y)
                 files.append(p, y)
-            _run_groups([model], dataset_path, shard, groups, keep)
+            _run_groups([model], dataset_path, shard, groups, keep, gpu_decode=gpu_decode)
             probs = gather.gather_rows(local, counts, 0)
         _assemble_shard_files(files, gather, rank, world)
     finally:

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("TIMED_HIP_LIB", os.path.join(_HERE, "libtimedhip.so")
 TH_OK = 0
 TH_F32, TH_F64, TH_U8, TH_BOOL, TH_F16 = 0, 1, 2, 3, 4
 TH_LOAD_DEFAULT, TH_LOAD_NO_FUSE, TH_LOAD_NO_MFMA, TH_LOAD_KEEP_ALL = 0, 1, 2, 4
-TH_PREDICT_DEFAULT, TH_PREDICT_LOGITS, TH_PREDICT_OUT_DEVICE = 0, 1, 2
+TH_PREDICT_DEFAULT, TH_PREDICT_LOGITS, TH_PREDICT_OUT_DEVICE, TH_PREDICT_IN_DEVICE = 0, 1, 2, 4
 TH_RNG_HOST, TH_RNG_PHILOX, TH_RNG_MT19937 = 0, 1, 2
 TH_TEMPER_NONE, TH_TEMPER_POW, TH_TEMPER_PREPOWERED = 0, 1, 2
 TH_COMM_ID_BYTES = 128

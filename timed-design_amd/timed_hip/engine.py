@@ -85,6 +85,11 @@ class HipFrameModel:
     __call__ = predict
 
     def predict_async(self, X, logits: bool = False) -> "PendingPrediction":
+        if isinstance(X, DeviceFrames):
+            return self.predict_async_frames_on_device(X, logits=logits)
+        return self._predict_async_host(X, logits=logits)
+
+    def _predict_async_host(self, X, logits: bool = False) -> "PendingPrediction":
         """Queue ``X`` (copy to the device, kernels, copy of the probabilities back) and return at once; the
         returned handle's ``result()`` blocks until that batch is done and gives the float32 [B, n_classes] array.
         Up to four batches may be in flight per model; they finish in submission order.  The caller's loop (load the
@@ -110,6 +115,13 @@ class HipFrameModel:
         """As predict_async, but the probability rows are left in device memory at address ``d_out`` (this model's
         device, room for len(X) * n_classes floats) — e.g. a shard buffer that th_comm_gather_rows sends over xGMI.
         ``result()`` returns None once the rows are there."""
+        if isinstance(X, DeviceFrames):          # frames on the device already (GPU-inflated .hdf5 batches): nothing is copied
+            if tuple(X.shape[1:]) != self.input_shape or X.device != self.device:
+                raise ValueError(f"device frames of shape {X.shape} on device {X.device} do not fit this model")
+            ticket = C.c_int(-1)
+            _lib.check(self._lib.th_predict_async(self._h, C.c_void_p(X.ptr), _DTYPES[np.dtype(X.dtype)], X.shape[0], C.c_void_p(d_out),
+                                                  _lib.TH_PREDICT_OUT_DEVICE | _lib.TH_PREDICT_IN_DEVICE, C.byref(ticket)))
+            return PendingPrediction(self, ticket.value, X, None)
         X = np.asarray(X)
         if X.ndim != 5 or tuple(X.shape[1:]) != self.input_shape:
             raise ValueError(f"expected frames of shape (B, {', '.join(map(str, self.input_shape))}), got {X.shape}")
@@ -122,6 +134,20 @@ class HipFrameModel:
         _lib.check(self._lib.th_predict_async(self._h, X.ctypes.data, dt, X.shape[0], C.c_void_p(d_out),
                                               _lib.TH_PREDICT_OUT_DEVICE, C.byref(ticket)))
         return PendingPrediction(self, ticket.value, X, None)
+
+    def predict_async_frames_on_device(self, frames: "DeviceFrames", logits: bool = False) -> "PendingPrediction":
+        """As predict_async for a batch that is in this device's memory already (DeviceFrames, e.g. from
+        design_utils.utils.load_batch_device: frames inflated on the GPU): no host->device copy at all."""
+        if tuple(frames.shape[1:]) != self.input_shape:
+            raise ValueError(f"expected frames of shape (B, {', '.join(map(str, self.input_shape))}), got {frames.shape}")
+        if frames.device != self.device:
+            raise ValueError(f"frames live on device {frames.device}, the model on {self.device}")
+        n = frames.shape[0]
+        out = np.empty((n, self.logits_width if logits else self.n_classes), dtype=np.float32)
+        ticket = C.c_int(-1)
+        _lib.check(self._lib.th_predict_async(self._h, C.c_void_p(frames.ptr), _DTYPES[np.dtype(frames.dtype)], n, out.ctypes.data,
+                                              _lib.TH_PREDICT_IN_DEVICE | (_lib.TH_PREDICT_LOGITS if logits else 0), C.byref(ticket)))
+        return PendingPrediction(self, ticket.value, frames, out)
 
     @property
     def logits_width(self) -> int:
@@ -236,6 +262,30 @@ def pinned_empty(shape, dtype=np.float32):
     dtype = np.dtype(dtype)
     buf = PinnedBuffer(max(1, int(np.prod(shape)) * dtype.itemsize))
     return buf.array(shape, dtype), buf
+
+
+class DeviceFrames:
+    """A batch of frames resident in device memory: [n, D, H, W, C] of ``dtype`` at ``ptr`` inside ``buffer`` (kept alive by
+    this object).  ``len()`` is the number of frames; a pool may hand the buffer out again once ``release`` was called."""
+
+    def __init__(self, buffer: "DeviceBuffer", shape, dtype, on_release=None):
+        self.buffer, self.shape, self.dtype = buffer, tuple(int(x) for x in shape), np.dtype(dtype)
+        self.ptr, self.device = buffer.ptr, buffer.device
+        self._on_release = on_release
+
+    def __len__(self):
+        return self.shape[0]
+
+    def release(self):
+        cb, self._on_release = self._on_release, None
+        if cb is not None:
+            cb(self.buffer)
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
 
 
 class DeviceBuffer:

@@ -808,3 +808,34 @@ def read_resolved(f: File, resolved: dict, rows, dests, as_float32: bool = False
     finally:
         del whole
     return rc == 0
+
+
+def decode_resolved_device(f: File, resolved: dict, d_out: int, device: int, as_float32: bool = False) -> bool:
+    """Every dataset of a resolve_many result (all with status bit 1: one shared chunked geometry) inflated ON THE GPU
+    straight into device memory at ``d_out`` — [n, *shape] float32 when ``as_float32`` (float64 data) or the stored element
+    type — by libtimedhip th_h5_decode_device: only the compressed bytes cross PCIe.  False when the file uses anything but
+    the deflate-only pipeline (the caller then reads through the host path)."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    g = resolved["geom"]
+    rank, esz, cls, nf = int(g[0]), int(g[15]), int(g[16]), int(g[18])
+    if int(g[27]) != 2 or rank < 1 or cls not in (0, 1, 8) or (as_float32 and not (cls == 1 and esz == 8)):
+        return False
+    filters = [int(x) for x in g[19:19 + nf]]
+    if filters != [1]:
+        return False
+    shape, chunk = [int(x) for x in g[1:1 + rank]], [int(x) for x in g[8:8 + rank]]
+    n = len(resolved["btree"])
+    addrs = np.ascontiguousarray(resolved["btree"], dtype=np.int64)
+    whole = np.frombuffer(f._m, dtype=np.uint8)
+    try:
+        rc = lib.th_h5_decode_device(whole.ctypes.data_as(C.c_void_p), whole.size, f._base, n, addrs.ctypes.data_as(C.POINTER(C.c_int64)), rank,
+                                     (C.c_int64 * rank)(*shape), (C.c_int64 * rank)(*chunk), esz, 1, (C.c_int * 1)(1),
+                                     1 if as_float32 else 0, int(device), C.c_void_p(int(d_out)))
+    finally:
+        del whole
+    if rc == -4:            # TH_EUNSUP: not an error, just not this path
+        return False
+    _lib.check(rc)
+    return True
