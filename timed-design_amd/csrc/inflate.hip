@@ -39,45 +39,78 @@ struct Lds {   // one wavefront: [entry][lane]
     unsigned char lens[kMaxLCodes + kMaxDCodes + 4][kLanes];
 };
 
+// Bit reader: the compressed bytes arrive 16 at a time (one aligned global load per 16 bytes — a byte-wise reader pays the
+// ~700-cycle global latency per input byte, with all 64 lanes of the wave waiting in lockstep), 32 bits at a time into the
+// 64-bit bit buffer.  `remaining` counts the bits the stream still owns: going negative means the input was exhausted.
 struct Bits {
-    const unsigned char* p;
-    const unsigned char* end;
+    const uint4* blk;       // next aligned 16-byte block
+    const uint4* blk_end;   // one past the last block that may be read
+    uint4 cur;              // the block being consumed
+    int widx;               // next 32-bit word of `cur` (4: none left)
     unsigned long long buf;
     int cnt;
-    bool over;      // tried to read past the end of the input
+    long long remaining;
+    bool over;
 };
 
+__device__ __forceinline__ unsigned next_word(Bits& b) {
+    if (b.widx == 4) {
+        if (b.blk < b.blk_end) b.cur = *b.blk;
+        else b.cur = make_uint4(0, 0, 0, 0);
+        ++b.blk;
+        b.widx = 0;
+    }
+    const unsigned w = b.widx == 0 ? b.cur.x : (b.widx == 1 ? b.cur.y : (b.widx == 2 ? b.cur.z : b.cur.w));
+    ++b.widx;
+    return w;
+}
 __device__ __forceinline__ void refill(Bits& b) {
-    while (b.cnt <= 56 && b.p < b.end) {
-        b.buf |= (unsigned long long)(*b.p++) << b.cnt;
-        b.cnt += 8;
+    if (b.cnt <= 32) {
+        b.buf |= (unsigned long long)next_word(b) << b.cnt;
+        b.cnt += 32;
+    }
+}
+__device__ __forceinline__ void bits_init(Bits& b, const unsigned char* p, long long len, const unsigned char* buf_end) {
+    const unsigned long long a = (unsigned long long)p;
+    b.blk = reinterpret_cast<const uint4*>(a & ~15ull);
+    b.blk_end = reinterpret_cast<const uint4*>(((unsigned long long)buf_end + 15ull) & ~15ull);
+    const uint4* own_end = reinterpret_cast<const uint4*>(((unsigned long long)(p + len) + 15ull) & ~15ull);
+    if (own_end < b.blk_end) b.blk_end = own_end;       // never read past the stream's last block (nor past the buffer)
+    b.widx = 4; b.buf = 0; b.cnt = 0; b.over = false;
+    b.remaining = 8 * len;
+    const int skip = (int)(a & 15);
+    for (int k = 0; k < (skip >> 2); ++k) (void)next_word(b);   // whole words in front of the stream
+    if (skip & 3) {                                             // and the leading bytes of its first word
+        b.buf = (unsigned long long)next_word(b) >> (8 * (skip & 3));
+        b.cnt = 32 - 8 * (skip & 3);
     }
 }
 __device__ __forceinline__ unsigned take(Bits& b, int n) {   // n <= 16
-    if (b.cnt < n) {
-        refill(b);
-        if (b.cnt < n) { b.over = true; b.cnt = n; }          // zeros are returned; the caller checks `over`
-    }
+    refill(b);
     const unsigned v = (unsigned)(b.buf & ((1ull << n) - 1));
     b.buf >>= n;
     b.cnt -= n;
+    b.remaining -= n;
+    if (b.remaining < 0) b.over = true;                       // (zeros or foreign bits were returned; the caller checks `over`)
     return v;
 }
 
-// canonical Huffman decode: walk the code lengths (at most 15 steps)
-__device__ __forceinline__ int decode(Bits& b, const unsigned short (*cnt)[kLanes], const unsigned short (*sym)[kLanes], int lane) {
-    if (b.cnt < kMaxBits) refill(b);
+// canonical Huffman decode: walk the code lengths (at most 15 steps, fully unrolled); the counts per length sit in
+// REGISTERS (cnt[], loaded once per block), only the final symbol comes from the lane's LDS table
+__device__ __forceinline__ int decode(Bits& b, const int (&cnt)[16], const unsigned short (*sym)[kLanes], int lane) {
+    refill(b);
     int code = 0, first = 0, index = 0;
     unsigned long long buf = b.buf;
-    const int avail = b.cnt;
+#pragma unroll
     for (int len = 1; len <= kMaxBits; ++len) {
-        if (len > avail) { b.over = true; return -1; }
         code |= (int)(buf & 1);
         buf >>= 1;
-        const int count = cnt[len][lane];
+        const int count = cnt[len];
         if (code - count < first) {
             b.buf = buf;
-            b.cnt = avail - len;
+            b.cnt -= len;
+            b.remaining -= len;
+            if (b.remaining < 0) { b.over = true; return -1; }
             return sym[index + (code - first)][lane];
         }
         index += count;
@@ -90,7 +123,7 @@ __device__ __forceinline__ int decode(Bits& b, const unsigned short (*cnt)[kLane
 
 // build count[] / symbol[] from code lengths lens[base .. base + n); returns < 0 for an over-subscribed set, > 0 for an
 // incomplete one, 0 for a complete one
-__device__ int construct(unsigned short (*cnt)[kLanes], unsigned short (*sym)[kLanes], const unsigned char (*lens)[kLanes], int base, int n,
+__device__ __forceinline__ int construct(unsigned short (*cnt)[kLanes], unsigned short (*sym)[kLanes], const unsigned char (*lens)[kLanes], int base, int n,
                          int lane) {
     for (int len = 0; len <= kMaxBits; ++len) cnt[len][lane] = 0;
     for (int s = 0; s < n; ++s) cnt[lens[base + s][lane]][lane]++;
@@ -115,6 +148,8 @@ struct Out {
     unsigned char* base;
     long long o, len;
     unsigned long long last8;   // the last 8 bytes written, oldest in the low byte
+    unsigned long long cw;      // far matches: the aligned 8-byte word of the output last read back ...
+    long long cw_at;            // ... and its byte offset (-1: none)
 };
 __device__ __forceinline__ void emit(Out& w, unsigned b) {
     w.last8 = (w.last8 >> 8) | ((unsigned long long)b << 56);
@@ -134,9 +169,9 @@ __constant__ unsigned char kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4,
 __constant__ unsigned char kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 // literal / length + distance symbols of one compressed block
-__device__ int codes(Bits& b, Out& w, Lds& L, int lane) {
+__device__ __forceinline__ int codes(Bits& b, Out& w, Lds& L, const int (&lc)[16], const int (&dc)[16], int lane) {
     for (;;) {
-        int sym = decode(b, L.lcnt, L.lsym, lane);
+        int sym = decode(b, lc, L.lsym, lane);
         if (sym < 0) return b.over ? INF_EINPUT : INF_ECODE;
         if (sym < 256) {
             if (w.o >= w.len) return INF_EOUTPUT;
@@ -147,7 +182,7 @@ __device__ int codes(Bits& b, Out& w, Lds& L, int lane) {
             sym -= 257;
             if (sym >= 29) return INF_ECODE;
             int len = kLenBase[sym] + (int)take(b, kLenExtra[sym]);
-            const int ds = decode(b, L.dcnt, L.dsym, lane);
+            const int ds = decode(b, dc, L.dsym, lane);
             if (ds < 0) return b.over ? INF_EINPUT : INF_ECODE;
             if (ds >= 30) return INF_ECODE;
             const long long dist = kDistBase[ds] + (long long)take(b, kDistExtra[ds]);
@@ -161,25 +196,33 @@ __device__ int codes(Bits& b, Out& w, Lds& L, int lane) {
                 const int sh = 8 * (8 - (int)dist);
                 for (int k = 0; k < len; ++k) emit(w, (unsigned)((w.last8 >> sh) & 0xff));
             } else {
-                // further back than the 8 buffered bytes: everything at o - dist has been stored (stores of this lane are
-                // ordered with its own later loads)
-                for (int k = 0; k < len; ++k) emit(w, w.base[w.o - dist]);
+                // further back than the 8 buffered bytes.  dist >= 9 implies that the ALIGNED 8-byte word holding byte
+                // o - dist lies entirely below the flush point (o & ~7): it is in memory, stored by this very lane (whose
+                // own loads are ordered behind its stores) — so the output is read back one aligned word per 8 bytes,
+                // not one byte at a time.
+                for (int k = 0; k < len; ++k) {
+                    const long long sa = w.o - dist, wa = sa & ~7ll;
+                    if (wa != w.cw_at) { w.cw = *reinterpret_cast<const unsigned long long*>(w.base + wa); w.cw_at = wa; }
+                    emit(w, (unsigned)((w.cw >> (8 * (int)(sa & 7))) & 0xff));
+                }
+                w.cw_at = -1;     // (the word may be overwritten... it cannot: it is final; but a later match re-reads anyway)
             }
         }
     }
 }
 
-__global__ void __launch_bounds__(kLanes) k_inflate(const unsigned char* comp, const InfDesc* desc, long long n, unsigned char* out,
-                                                    int* status, int zlib_wrapped) {
+__global__ void __launch_bounds__(kLanes) k_inflate(const unsigned char* comp, long long comp_len, const InfDesc* desc, long long n,
+                                                    unsigned char* out, int* status, int zlib_wrapped) {
     __shared__ Lds L;
     const int lane = threadIdx.x;
     const long long idx = (long long)blockIdx.x * kLanes + lane;
     if (idx >= n) return;
     const InfDesc d = desc[idx];
     Bits b;
-    b.p = comp + d.src_off; b.end = b.p + d.src_len; b.buf = 0; b.cnt = 0; b.over = false;
+    bits_init(b, comp + d.src_off, d.src_len, comp + comp_len);
     Out w;
-    w.base = out + d.dst_off; w.o = 0; w.len = d.dst_len; w.last8 = 0;
+    w.base = out + d.dst_off; w.o = 0; w.len = d.dst_len; w.last8 = 0; w.cw = 0; w.cw_at = -1;
+    int lc[16], dc[16];            // code counts per length of the current block's two Huffman codes
     int st = INF_OK;
     if (zlib_wrapped) {
         if (d.src_len < 6) st = INF_EHEADER;
@@ -194,8 +237,8 @@ __global__ void __launch_bounds__(kLanes) k_inflate(const unsigned char* comp, c
         const unsigned type = take(b, 2);
         if (b.over) { st = INF_EINPUT; break; }
         if (type == 0) {
-            // stored block: skip to the byte boundary, LEN / ~LEN, raw bytes
-            b.buf >>= (b.cnt & 7); b.cnt -= (b.cnt & 7);
+            // stored block: skip to the byte boundary (the stream position is 8*src_len - remaining bits), LEN / ~LEN, raw bytes
+            { const int pad = (int)(b.remaining & 7); refill(b); b.buf >>= pad; b.cnt -= pad; b.remaining -= pad; }
             const unsigned len = take(b, 16), nlen = take(b, 16);
             if (b.over || len != (~nlen & 0xffff)) { st = INF_ESTORED; break; }
             if (w.o + (long long)len > w.len) { st = INF_EOUTPUT; break; }
@@ -213,7 +256,9 @@ __global__ void __launch_bounds__(kLanes) k_inflate(const unsigned char* comp, c
             construct(L.lcnt, L.lsym, L.lens, 0, kFixLCodes, lane);
             for (int s = 0; s < kMaxDCodes; ++s) L.lens[s][lane] = 5;
             construct(L.dcnt, L.dsym, L.lens, 0, kMaxDCodes, lane);
-            st = codes(b, w, L, lane);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { lc[k] = L.lcnt[k][lane]; dc[k] = L.dcnt[k][lane]; }
+            st = codes(b, w, L, lc, dc, lane);
         } else if (type == 2) {
             const int nlen = (int)take(b, 5) + 257, ndist = (int)take(b, 5) + 1, ncode = (int)take(b, 4) + 4;
             if (b.over) { st = INF_EINPUT; break; }
@@ -222,9 +267,11 @@ __global__ void __launch_bounds__(kLanes) k_inflate(const unsigned char* comp, c
             for (int i = 0; i < ncode; ++i) L.lens[kClOrder[i]][lane] = (unsigned char)take(b, 3);
             if (b.over) { st = INF_EINPUT; break; }
             if (construct(L.lcnt, L.lsym, L.lens, 0, 19, lane) != 0) { st = INF_ETABLE; break; }   // the code-length code must be complete
+#pragma unroll
+            for (int k = 0; k < 16; ++k) lc[k] = L.lcnt[k][lane];
             int i = 0;
             while (i < nlen + ndist) {
-                int sym = decode(b, L.lcnt, L.lsym, lane);
+                int sym = decode(b, lc, L.lsym, lane);
                 if (sym < 0) { st = b.over ? INF_EINPUT : INF_ECODE; break; }
                 if (sym < 16) {
                     L.lens[i++][lane] = (unsigned char)sym;
@@ -248,7 +295,9 @@ __global__ void __launch_bounds__(kLanes) k_inflate(const unsigned char* comp, c
             if (err < 0 || (err > 0 && nlen - L.lcnt[0][lane] != 1)) { st = INF_ETABLE; break; }
             err = construct(L.dcnt, L.dsym, L.lens, nlen, ndist, lane);
             if (err < 0 || (err > 0 && ndist - L.dcnt[0][lane] != 1)) { st = INF_ETABLE; break; }
-            st = codes(b, w, L, lane);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { lc[k] = L.lcnt[k][lane]; dc[k] = L.dcnt[k][lane]; }
+            st = codes(b, w, L, lc, dc, lane);
         } else {
             st = INF_ECODE;
         }
@@ -346,7 +395,7 @@ extern "C" int th_inflate_many(int device, const void* comp, int64_t comp_len, i
     if (!rc && (e = hipMemcpy(d_desc, desc.data(), (size_t)n * sizeof(InfDesc), hipMemcpyHostToDevice)) != hipSuccess) fail(e, "copy in");
     if (!rc && (e = hipMemset(d_st, 0xff, (size_t)n * sizeof(int))) != hipSuccess) fail(e, "memset");
     if (!rc) {
-        hipLaunchKernelGGL(k_inflate, dim3((unsigned)((n + kLanes - 1) / kLanes)), dim3(kLanes), 0, 0, d_comp, d_desc, (long long)n, d_out, d_st,
+        hipLaunchKernelGGL(k_inflate, dim3((unsigned)((n + kLanes - 1) / kLanes)), dim3(kLanes), 0, 0, d_comp, (long long)comp_len, d_desc, (long long)n, d_out, d_st,
                            wrapped);
         if ((e = hipGetLastError()) != hipSuccess) fail(e, "launch");
     }
@@ -393,7 +442,7 @@ int inflate_place_device(int device, hipStream_t stream, const void* span, int64
     HIP_TRY(hipMemcpyAsync(d_ds.p, ds, (size_t)n_chunks * sizeof(int), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(d_coff.p, coff8, (size_t)n_chunks * 8 * sizeof(int), hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(k_inflate, dim3((unsigned)((n_chunks + kLanes - 1) / kLanes)), dim3(kLanes), 0, stream, (const unsigned char*)d_comp.p,
-                       (const InfDesc*)d_desc.p, (long long)n_chunks, (unsigned char*)d_raw.p, (int*)d_st.p, 1);
+                       (long long)span_len, (const InfDesc*)d_desc.p, (long long)n_chunks, (unsigned char*)d_raw.p, (int*)d_st.p, 1);
     HIP_TRY(hipGetLastError());
     PlaceArgs a;
     a.raw = (const unsigned char*)d_raw.p; a.chunk_bytes = cb8; a.ds = (const int*)d_ds.p; a.coff = (const int*)d_coff.p;
