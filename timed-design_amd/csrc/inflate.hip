@@ -9,12 +9,20 @@
 // every lane of every wavefront decodes its own stream into HBM, and a second kernel places the chunks into the
 // channels-last frame tensor (float64 -> float32 on the way: Keras' own cast).
 //
-// The decoder is the textbook one (canonical Huffman decode by code length, as in zlib's contrib/puff): count[16] +
-// symbol[] tables per lane in LDS (lane-interleaved: entry e of lane l at [e][l], conflict-free), a 64-bit bit buffer, and
-// the last 8 output bytes kept in a register — which serves both as the write-combining buffer (one 8-byte store per 8
-// bytes) and as the source of short-distance matches (distance <= 8: runs of zeros and of repeated doubles, the bulk of a
-// voxel frame), so that a match never reads back a byte that is still on its way to memory.  Every loop is bounded by the
-// declared input / output lengths: corrupt data ends in a status code, never in a hang or an out-of-range access.
+// Two kernels, because the two halves of DEFLATE parallelise differently:
+//   k_inflate_tokens   one LANE per stream: the Huffman layer (inherently serial per stream, so the parallelism is across
+//                      streams) — the textbook canonical decode by code length (zlib's contrib/puff): symbol tables per
+//                      lane in LDS (lane-interleaved, conflict-free), code counts in registers, the input fetched 16 bytes
+//                      per global load.  It does NOT produce bytes: it writes 32-bit tokens (a literal, or a match of
+//                      length L at distance D), so it never reads its own output back.
+//   k_lz_resolve       one WAVEFRONT per stream: the LZ77 layer in LDS — literals of 64 tokens land in parallel (wave
+//                      prefix sum of the lengths), matches are copied 64 bytes per step out of a 16-64 KB window of the
+//                      output that lives in LDS, and finished bytes leave for HBM in coalesced 8-byte stores.
+// A first, single-kernel version (a lane emitting bytes into HBM and reading far matches back from there) spent 64 ms on
+// the 32 768 chunks of a 1 024-frame batch: every read-back of a lane's own earlier store waits for the wave's whole store
+// queue, and with 64 independent streams per wave some lane is always at such a point.
+// Every loop is bounded by the declared input / output lengths: corrupt data ends in a status code, never in a hang or an
+// out-of-range access.
 #include "common.h"
 
 #include <cstring>
@@ -26,7 +34,7 @@ namespace {
 constexpr int kLanes = 64;
 constexpr int kMaxBits = 15, kMaxLCodes = 286, kMaxDCodes = 30, kFixLCodes = 288;
 
-struct InfDesc { int64_t src_off, src_len, dst_off, dst_len; };
+struct InfDesc { int64_t src_off, src_len, dst_off, dst_len, tok_off; };
 
 // status per chunk
 enum { INF_OK = 0, INF_EINPUT = 1, INF_EOUTPUT = 2, INF_EHEADER = 3, INF_ECODE = 4, INF_EDIST = 5, INF_ETABLE = 6, INF_ESTORED = 7, INF_ESHORT = 8 };
@@ -144,22 +152,15 @@ __device__ __forceinline__ int construct(unsigned short (*cnt)[kLanes], unsigned
     return left;
 }
 
+// token sink of pass 1: literal = the byte; match = bit 31 | length << 16 | (distance - 1)
 struct Out {
-    unsigned char* base;
-    long long o, len;
-    unsigned long long last8;   // the last 8 bytes written, oldest in the low byte
-    unsigned long long cw;      // far matches: the aligned 8-byte word of the output last read back ...
-    long long cw_at;            // ... and its byte offset (-1: none)
+    unsigned* tok;
+    long long nt;       // tokens written (never more than `o`, hence never more than the `len` slots this stream owns)
+    long long o, len;   // bytes the tokens stand for so far / declared output length
 };
 __device__ __forceinline__ void emit(Out& w, unsigned b) {
-    w.last8 = (w.last8 >> 8) | ((unsigned long long)b << 56);
+    w.tok[w.nt++] = b;
     ++w.o;
-    if ((w.o & 7) == 0) *reinterpret_cast<unsigned long long*>(w.base + w.o - 8) = w.last8;
-}
-__device__ __forceinline__ void flush(Out& w) {
-    const int tail = (int)(w.o & 7);
-    const unsigned long long v = w.last8 >> (8 * (8 - tail));
-    for (int k = 0; k < tail; ++k) w.base[(w.o & ~7ll) + k] = (unsigned char)(v >> (8 * k));
 }
 
 __constant__ unsigned short kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
@@ -189,30 +190,14 @@ __device__ __forceinline__ int codes(Bits& b, Out& w, Lds& L, const int (&lc)[16
             if (b.over) return INF_EINPUT;
             if (dist > w.o) return INF_EDIST;
             if (w.o + len > w.len) return INF_EOUTPUT;
-            if (dist <= 8) {
-                // the source bytes are among the last 8 written: take them from the register (never from memory, where
-                // they may not have arrived yet).  After each emitted byte the window has moved on by one, so the byte
-                // `dist` back always sits at the same position of last8.
-                const int sh = 8 * (8 - (int)dist);
-                for (int k = 0; k < len; ++k) emit(w, (unsigned)((w.last8 >> sh) & 0xff));
-            } else {
-                // further back than the 8 buffered bytes.  dist >= 9 implies that the ALIGNED 8-byte word holding byte
-                // o - dist lies entirely below the flush point (o & ~7): it is in memory, stored by this very lane (whose
-                // own loads are ordered behind its stores) — so the output is read back one aligned word per 8 bytes,
-                // not one byte at a time.
-                for (int k = 0; k < len; ++k) {
-                    const long long sa = w.o - dist, wa = sa & ~7ll;
-                    if (wa != w.cw_at) { w.cw = *reinterpret_cast<const unsigned long long*>(w.base + wa); w.cw_at = wa; }
-                    emit(w, (unsigned)((w.cw >> (8 * (int)(sa & 7))) & 0xff));
-                }
-                w.cw_at = -1;     // (the word may be overwritten... it cannot: it is final; but a later match re-reads anyway)
-            }
+            w.tok[w.nt++] = 0x80000000u | ((unsigned)len << 16) | (unsigned)(dist - 1);
+            w.o += len;
         }
     }
 }
 
-__global__ void __launch_bounds__(kLanes) k_inflate(const unsigned char* comp, long long comp_len, const InfDesc* desc, long long n,
-                                                    unsigned char* out, int* status, int zlib_wrapped) {
+__global__ void __launch_bounds__(kLanes) k_inflate_tokens(const unsigned char* comp, long long comp_len, const InfDesc* desc, long long n,
+                                                           unsigned* tokens, long long* ntok, int* status, int zlib_wrapped) {
     __shared__ Lds L;
     const int lane = threadIdx.x;
     const long long idx = (long long)blockIdx.x * kLanes + lane;
@@ -221,7 +206,7 @@ __global__ void __launch_bounds__(kLanes) k_inflate(const unsigned char* comp, l
     Bits b;
     bits_init(b, comp + d.src_off, d.src_len, comp + comp_len);
     Out w;
-    w.base = out + d.dst_off; w.o = 0; w.len = d.dst_len; w.last8 = 0; w.cw = 0; w.cw_at = -1;
+    w.tok = tokens + d.tok_off; w.nt = 0; w.o = 0; w.len = d.dst_len;
     int lc[16], dc[16];            // code counts per length of the current block's two Huffman codes
     int st = INF_OK;
     if (zlib_wrapped) {
@@ -303,8 +288,93 @@ __global__ void __launch_bounds__(kLanes) k_inflate(const unsigned char* comp, l
         }
     }
     if (st == INF_OK && w.o != w.len) st = INF_ESHORT;
-    flush(w);
+    ntok[idx] = st == INF_OK ? w.nt : 0;
     status[idx] = st;
+}
+
+// ---- pass 2: tokens -> bytes, one wavefront per stream, the window of the output in LDS ---------------------------------------
+// ring: R bytes (a power of two >= min(stream length, 64 KB)); byte i of the output lives at ring[i & (R - 1)] until it has
+// been flushed and the ring has come round.  Per batch of 64 tokens: lane l owns token l; an inclusive wave scan of the token
+// lengths gives every token its output position; literals are written at once; matches are then resolved one after the other
+// (a match may copy what an earlier match of the same batch produced), each by all 64 lanes: lane k copies byte k, k + 64, ...
+// For distances >= 64 the source of a 64-byte step is always older than the step; for shorter distances the source index is
+// folded back into the `distance` bytes in front of the match (k mod distance), which are complete.  Bytes older than 32 KB
+// (the DEFLATE window) are flushed to HBM in 8-byte words whenever a batch begins, so at most 32 KB + 7 + 64 * 258 bytes are
+// live: 64 KB of ring suffice for a stream of any length.
+__global__ void __launch_bounds__(kLanes) k_lz_resolve(const unsigned* tokens, const long long* ntok, const InfDesc* desc, long long n,
+                                                       unsigned char* out, int* status, unsigned R) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ring[];
+    const long long idx = blockIdx.x;
+    if (idx >= n || status[idx] != INF_OK) return;
+    const int lane = threadIdx.x;
+    const InfDesc d = desc[idx];
+    const unsigned* tok = tokens + d.tok_off;
+    const long long nt = ntok[idx];
+    unsigned char* dst = out + d.dst_off;
+    const unsigned M = R - 1;
+    long long o = 0, flushed = 0;
+    auto flush_to = [&](long long upto) {     // [flushed, upto), both multiples of 8
+        for (long long i = flushed + 8ll * lane; i < upto; i += 8ll * kLanes)
+            *reinterpret_cast<unsigned long long*>(dst + i) = *reinterpret_cast<const unsigned long long*>(ring + ((unsigned)i & M));
+        flushed = upto;
+    };
+    for (long long t0 = 0; t0 < nt; t0 += kLanes) {
+        const bool valid = t0 + lane < nt;
+        const unsigned tk = valid ? tok[t0 + lane] : 0u;
+        const bool is_m = valid && (tk >> 31);
+        const int len = is_m ? (int)((tk >> 16) & 0x1ff) : (valid ? 1 : 0);
+        int incl = len;
+#pragma unroll
+        for (int s = 1; s < kLanes; s <<= 1) {
+            const int v = __shfl_up(incl, s);
+            if (lane >= s) incl += v;
+        }
+        const int total = __shfl(incl, kLanes - 1);
+        const long long pos = o + incl - len;
+        // make room: everything older than the 32 KB window goes out
+        if (o - flushed > 32768 + 8) {
+            __syncthreads();
+            flush_to((o - 32768) & ~7ll);
+            __syncthreads();
+        }
+        if (valid && !is_m) ring[(unsigned)pos & M] = (unsigned char)(tk & 0xff);
+        __syncthreads();
+        unsigned long long mm = __ballot(is_m);
+        while (mm) {
+            const int l = __ffsll((long long)mm) - 1;
+            mm &= mm - 1;
+            const int mlen = __shfl(len, l);
+            const int mdist = (int)(__shfl((int)tk, l) & 0x7fff) + 1;
+            const long long mpos = __shfl((int)(pos - o), l) + o;
+            if (mdist >= kLanes) {
+                for (int k0 = 0; k0 < mlen; k0 += kLanes) {
+                    const int k = k0 + lane;
+                    if (k < mlen) ring[(unsigned)(mpos + k) & M] = ring[(unsigned)(mpos - mdist + k) & M];
+                    __syncthreads();
+                }
+            } else {
+                // every byte comes from the mdist bytes in front of the match: all 64-byte steps are independent
+                const float inv = 1.0f / (float)mdist;
+                for (int k0 = 0; k0 < mlen; k0 += kLanes) {
+                    const int k = k0 + lane;
+                    int q = (int)((float)k * inv);
+                    int r = k - q * mdist;
+                    if (r < 0) r += mdist;
+                    if (r >= mdist) r -= mdist;
+                    unsigned char v = 0;
+                    if (k < mlen) v = ring[(unsigned)(mpos - mdist + r) & M];
+                    __syncthreads();        // (all sources read before any byte of this step is written: a step may overwrite ...
+                    if (k < mlen) ring[(unsigned)(mpos + k) & M] = v;   // ... nothing it reads, but keep the order explicit)
+                }
+                __syncthreads();
+            }
+        }
+        o += total;
+    }
+    __syncthreads();
+    const long long whole = o & ~7ll;
+    flush_to(whole);
+    if (lane < (int)(o - whole)) dst[whole + lane] = ring[(unsigned)(whole + lane) & M];
 }
 
 // chunk -> frame placement: chunk `c` (chunk_bytes of raw data, C order over cdim[rank]) covers the box starting at
@@ -348,6 +418,9 @@ __global__ void k_place_chunks(const PlaceArgs a, long long n_chunks) {
     }
 }
 
+// LDS window of k_lz_resolve for streams of at most max_len bytes
+inline unsigned ring_bytes(int64_t max_len) { return max_len <= 16384 ? 16384u : (max_len <= 32768 ? 32768u : 65536u); }
+
 struct DevBuf {
     void* p = nullptr; size_t cap = 0;
     int ensure(size_t bytes) {
@@ -374,16 +447,21 @@ extern "C" int th_inflate_many(int device, const void* comp, int64_t comp_len, i
     if (n < 0 || (n && (!comp || !src_off || !src_len || !dst_off || !dst_len || !out))) TH_FAIL(TH_EINVAL, "th_inflate_many: null argument");
     if (n == 0) return TH_OK;
     std::vector<InfDesc> desc((size_t)n);
+    int64_t tok_total = 0, max_len = 0;
     for (int64_t i = 0; i < n; ++i) {
         if (src_off[i] < 0 || src_len[i] < 0 || src_off[i] > comp_len - src_len[i] || dst_off[i] < 0 || dst_len[i] < 0 ||
             dst_off[i] > out_len - dst_len[i] || (dst_off[i] & 7))
             TH_FAIL(TH_EINVAL, "th_inflate_many: stream %lld lies outside its buffer (or its output is not 8-byte aligned)", (long long)i);
-        desc[(size_t)i] = {src_off[i], src_len[i], dst_off[i], dst_len[i]};
+        desc[(size_t)i] = {src_off[i], src_len[i], dst_off[i], dst_len[i], tok_total};
+        tok_total += dst_len[i];
+        max_len = std::max<int64_t>(max_len, dst_len[i]);
     }
     HIP_TRY(hipSetDevice(device));
     unsigned char *d_comp = nullptr, *d_out = nullptr;
     InfDesc* d_desc = nullptr;
     int* d_st = nullptr;
+    unsigned* d_tok = nullptr;
+    long long* d_nt = nullptr;
     int rc = TH_OK;
     auto fail = [&](hipError_t e, const char* what) { th_set_error("th_inflate_many: %s: %s", what, hipGetErrorString(e)); rc = TH_EHIP; };
     hipError_t e;
@@ -391,19 +469,27 @@ extern "C" int th_inflate_many(int device, const void* comp, int64_t comp_len, i
     if (!rc && (e = hipMalloc(&d_out, (size_t)out_len + 16)) != hipSuccess) fail(e, "hipMalloc");
     if (!rc && (e = hipMalloc(&d_desc, (size_t)n * sizeof(InfDesc))) != hipSuccess) fail(e, "hipMalloc");
     if (!rc && (e = hipMalloc(&d_st, (size_t)n * sizeof(int))) != hipSuccess) fail(e, "hipMalloc");
+    if (!rc && (e = hipMalloc(&d_tok, (size_t)(tok_total + 16) * sizeof(unsigned))) != hipSuccess) fail(e, "hipMalloc");
+    if (!rc && (e = hipMalloc(&d_nt, (size_t)n * sizeof(long long))) != hipSuccess) fail(e, "hipMalloc");
     if (!rc && (e = hipMemcpy(d_comp, comp, (size_t)comp_len, hipMemcpyHostToDevice)) != hipSuccess) fail(e, "copy in");
     if (!rc && (e = hipMemcpy(d_desc, desc.data(), (size_t)n * sizeof(InfDesc), hipMemcpyHostToDevice)) != hipSuccess) fail(e, "copy in");
     if (!rc && (e = hipMemset(d_st, 0xff, (size_t)n * sizeof(int))) != hipSuccess) fail(e, "memset");
     if (!rc) {
-        hipLaunchKernelGGL(k_inflate, dim3((unsigned)((n + kLanes - 1) / kLanes)), dim3(kLanes), 0, 0, d_comp, (long long)comp_len, d_desc, (long long)n, d_out, d_st,
-                           wrapped);
+        hipLaunchKernelGGL(k_inflate_tokens, dim3((unsigned)((n + kLanes - 1) / kLanes)), dim3(kLanes), 0, 0, d_comp, (long long)comp_len, d_desc,
+                           (long long)n, d_tok, d_nt, d_st, wrapped);
         if ((e = hipGetLastError()) != hipSuccess) fail(e, "launch");
+    }
+    if (!rc) {
+        const unsigned R = ring_bytes(max_len);
+        if ((e = hipFuncSetAttribute((const void*)k_lz_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)) != hipSuccess) fail(e, "attribute");
+        hipLaunchKernelGGL(k_lz_resolve, dim3((unsigned)n), dim3(kLanes), R, 0, d_tok, d_nt, d_desc, (long long)n, d_out, d_st, R);
+        if (!rc && (e = hipGetLastError()) != hipSuccess) fail(e, "launch");
     }
     if (!rc && (e = hipDeviceSynchronize()) != hipSuccess) fail(e, "kernel");
     if (!rc && (e = hipMemcpy(out, d_out, (size_t)out_len, hipMemcpyDeviceToHost)) != hipSuccess) fail(e, "copy out");
     std::vector<int> st((size_t)n, 0);
     if (!rc && (e = hipMemcpy(st.data(), d_st, (size_t)n * sizeof(int), hipMemcpyDeviceToHost)) != hipSuccess) fail(e, "copy out");
-    for (void* p : {(void*)d_comp, (void*)d_out, (void*)d_desc, (void*)d_st})
+    for (void* p : {(void*)d_comp, (void*)d_out, (void*)d_desc, (void*)d_st, (void*)d_tok, (void*)d_nt})
         if (p) (void)hipFree(p);
     if (rc) return rc;
     int64_t bad = 0;
@@ -423,7 +509,7 @@ int inflate_place_device(int device, hipStream_t stream, const void* span, int64
                          const int64_t* csize, const int* ds, const int* coff8, int rank, const int64_t* shape, const int64_t* chunk, int esz,
                          int conv, void* d_out, int64_t* n_bad) {
     static std::mutex mu;                   // one decode at a time per process (the scratch buffers below are shared)
-    static DevBuf d_comp, d_raw, d_desc, d_st, d_ds, d_coff;
+    static DevBuf d_comp, d_raw, d_desc, d_st, d_ds, d_coff, d_tok, d_nt;
     static void* h_st = nullptr; static size_t h_st_cap = 0;
     std::lock_guard<std::mutex> lock(mu);
     HIP_TRY(hipSetDevice(device));
@@ -433,17 +519,25 @@ int inflate_place_device(int device, hipStream_t stream, const void* span, int64
     int rc;
     if ((rc = d_comp.ensure((size_t)span_len + 16)) || (rc = d_raw.ensure((size_t)(n_chunks * cb8) + 16)) ||
         (rc = d_desc.ensure((size_t)n_chunks * sizeof(InfDesc))) || (rc = d_st.ensure((size_t)n_chunks * sizeof(int))) ||
-        (rc = d_ds.ensure((size_t)n_chunks * sizeof(int))) || (rc = d_coff.ensure((size_t)n_chunks * 8 * sizeof(int))))
+        (rc = d_ds.ensure((size_t)n_chunks * sizeof(int))) || (rc = d_coff.ensure((size_t)n_chunks * 8 * sizeof(int))) ||
+        (rc = d_tok.ensure((size_t)(n_chunks * chunk_bytes + 16) * sizeof(unsigned))) || (rc = d_nt.ensure((size_t)n_chunks * sizeof(long long))))
         return rc;
     std::vector<InfDesc> desc((size_t)n_chunks);
-    for (int64_t i = 0; i < n_chunks; ++i) desc[(size_t)i] = {src_off[i], csize[i], i * cb8, chunk_bytes};
+    for (int64_t i = 0; i < n_chunks; ++i) desc[(size_t)i] = {src_off[i], csize[i], i * cb8, chunk_bytes, i * chunk_bytes};
     HIP_TRY(hipMemcpyAsync(d_comp.p, span, (size_t)span_len, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(d_desc.p, desc.data(), (size_t)n_chunks * sizeof(InfDesc), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(d_ds.p, ds, (size_t)n_chunks * sizeof(int), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(d_coff.p, coff8, (size_t)n_chunks * 8 * sizeof(int), hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(k_inflate, dim3((unsigned)((n_chunks + kLanes - 1) / kLanes)), dim3(kLanes), 0, stream, (const unsigned char*)d_comp.p,
-                       (long long)span_len, (const InfDesc*)d_desc.p, (long long)n_chunks, (unsigned char*)d_raw.p, (int*)d_st.p, 1);
+    hipLaunchKernelGGL(k_inflate_tokens, dim3((unsigned)((n_chunks + kLanes - 1) / kLanes)), dim3(kLanes), 0, stream, (const unsigned char*)d_comp.p,
+                       (long long)span_len, (const InfDesc*)d_desc.p, (long long)n_chunks, (unsigned*)d_tok.p, (long long*)d_nt.p, (int*)d_st.p, 1);
     HIP_TRY(hipGetLastError());
+    {
+        const unsigned R = ring_bytes(chunk_bytes);
+        HIP_TRY(hipFuncSetAttribute((const void*)k_lz_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        hipLaunchKernelGGL(k_lz_resolve, dim3((unsigned)n_chunks), dim3(kLanes), R, stream, (const unsigned*)d_tok.p, (const long long*)d_nt.p,
+                           (const InfDesc*)d_desc.p, (long long)n_chunks, (unsigned char*)d_raw.p, (int*)d_st.p, R);
+        HIP_TRY(hipGetLastError());
+    }
     PlaceArgs a;
     a.raw = (const unsigned char*)d_raw.p; a.chunk_bytes = cb8; a.ds = (const int*)d_ds.p; a.coff = (const int*)d_coff.p;
     a.rank = rank; a.esz = esz; a.conv = conv; a.out = (unsigned char*)d_out; a.out_elems = 1;
