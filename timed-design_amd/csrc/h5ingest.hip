@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -293,6 +294,9 @@ extern "C" int th_h5_decode_device(const void* file, int64_t file_len, int64_t b
     if (n_filters != 1 || !filter_ids || filter_ids[0] != 1) TH_FAIL(TH_EUNSUP, "th_h5_decode_device: only the deflate-only pipeline is decoded on the device");
     if (conv != 0 && !(conv == 1 && esz == 8)) TH_FAIL(TH_EINVAL, "th_h5_decode_device: conversion %d needs float64 elements", conv);
     if (n_datasets == 0) return TH_OK;
+    static const bool trace = getenv("TH_H5_TRACE") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
     Geometry g;
     g.file = (const uint8_t*)file; g.file_len = file_len; g.base = base; g.rank = rank; g.esz = esz; g.n_filters = n_filters;
     int64_t elems = 1;
@@ -333,6 +337,7 @@ extern "C" int th_h5_decode_device(const void* file, int64_t file_len, int64_t b
     if (unsupported.load()) TH_FAIL(TH_EUNSUP, "th_h5_decode_device: a chunk is stored without its filters");
     size_t nch = 0;
     for (auto& v : parts) nch += v.size();
+    const double t_walk = since();
     HIP_TRY(hipSetDevice(device));
     const int out_esz = conv == 1 ? 4 : esz;
     HIP_TRY(hipMemsetAsync(d_out, 0, (size_t)n_datasets * elems * out_esz, nullptr));
@@ -366,9 +371,13 @@ extern "C" int th_h5_decode_device(const void* file, int64_t file_len, int64_t b
     } else {
         for (size_t i = 0; i < nch; ++i) src_off[i] -= lo;
     }
+    const double t_prep = since();
     int64_t bad = 0;
     int rc = inflate_place_device(device, nullptr, span, span_len, (int64_t)nch, src_off.data(), csize.data(), ds.data(), coff.data(), rank,
                                   shape, chunk, esz, conv, d_out, &bad);
+    if (trace)
+        fprintf(stderr, "[h5 decode] %lld datasets, %zu chunks, span %.1f MB (%s): B-trees %.2f ms, memset + descriptors %.2f ms, copy + kernels %.2f ms\n",
+                (long long)n_datasets, nch, span_len / 1e6, gathered.empty() ? "direct" : "gathered", t_walk, t_prep - t_walk, since() - t_prep);
     if (rc) return rc;
     if (bad) TH_FAIL(TH_EIO, "th_h5_decode_device: %lld of %zu chunks did not inflate", (long long)bad, nch);
     return TH_OK;

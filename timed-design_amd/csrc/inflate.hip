@@ -103,30 +103,42 @@ __device__ __forceinline__ unsigned take(Bits& b, int n) {   // n <= 16
     return v;
 }
 
-// canonical Huffman decode: walk the code lengths (at most 15 steps, fully unrolled); the counts per length sit in
-// REGISTERS (cnt[], loaded once per block), only the final symbol comes from the lane's LDS table
-__device__ __forceinline__ int decode(Bits& b, const int (&cnt)[16], const unsigned short (*sym)[kLanes], int lane) {
-    refill(b);
-    int code = 0, first = 0, index = 0;
-    unsigned long long buf = b.buf;
+// Canonical Huffman decode WITHOUT a data-dependent loop (64 lanes decode 64 different streams in lockstep: a bit-serial walk
+// over the code lengths makes every lane pay for the longest code in the wave, branch by branch).  Per code, from the counts
+// per length:  first[L] = first code of length L, offs[L] = index of its symbol;  LEFT-ALIGNED to 15 bits,
+// limit[L] = (first[L] + count[L]) << (15 - L) is non-decreasing in L, and a 15-bit window v of the stream (first bit read =
+// most significant) holds a code of length L exactly when limit[L-1] <= v < limit[L].  So L = 1 + #{L' : v >= limit[L']}, and
+// the symbol index is (v >> (15 - L)) + base[L] with base[L] = offs[L] - first[L] — 15 compares, 14 selects, no branch.
+struct Code { int lim[16]; int bas[16]; };     // [1..15]; bas[1] = base[1], bas[L > 1] = base[L] - base[L-1] (deltas: a select
+                                               // chain over base[] itself is folded by hipcc into a register-array index = scratch)
+__device__ __forceinline__ void code_from_counts(Code& c, const unsigned short (*cnt)[kLanes], int lane) {
+    int first = 0, offs = 0, prev_base = 0;
 #pragma unroll
     for (int len = 1; len <= kMaxBits; ++len) {
-        code |= (int)(buf & 1);
-        buf >>= 1;
-        const int count = cnt[len];
-        if (code - count < first) {
-            b.buf = buf;
-            b.cnt -= len;
-            b.remaining -= len;
-            if (b.remaining < 0) { b.over = true; return -1; }
-            return sym[index + (code - first)][lane];
-        }
-        index += count;
-        first += count;
-        first <<= 1;
-        code <<= 1;
+        const int count = cnt[len][lane];
+        c.lim[len] = (first + count) << (kMaxBits - len);
+        c.bas[len] = (offs - first) - prev_base;
+        prev_base = offs - first;
+        offs += count;
+        first = (first + count) << 1;
     }
-    return -1;
+}
+__device__ __forceinline__ int decode(Bits& b, const Code& c, const unsigned short (*sym)[kLanes], int lane) {
+    refill(b);
+    const int v = (int)(__brev((unsigned)(b.buf & 0x7fff)) >> 17);
+    int len = 1, base = c.bas[1];
+#pragma unroll
+    for (int l = 1; l < kMaxBits; ++l) {
+        const bool ge = v >= c.lim[l];
+        len += ge ? 1 : 0;
+        base += ge ? c.bas[l + 1] : 0;
+    }
+    if (v >= c.lim[kMaxBits]) return -1;          // not a code of this (incomplete) set
+    b.buf >>= len;
+    b.cnt -= len;
+    b.remaining -= len;
+    if (b.remaining < 0) { b.over = true; return -1; }
+    return sym[(v >> (kMaxBits - len)) + base][lane];
 }
 
 // build count[] / symbol[] from code lengths lens[base .. base + n); returns < 0 for an over-subscribed set, > 0 for an
@@ -170,7 +182,7 @@ __constant__ unsigned char kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4,
 __constant__ unsigned char kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 // literal / length + distance symbols of one compressed block
-__device__ __forceinline__ int codes(Bits& b, Out& w, Lds& L, const int (&lc)[16], const int (&dc)[16], int lane) {
+__device__ __forceinline__ int codes(Bits& b, Out& w, Lds& L, const Code& lc, const Code& dc, int lane) {
     for (;;) {
         int sym = decode(b, lc, L.lsym, lane);
         if (sym < 0) return b.over ? INF_EINPUT : INF_ECODE;
@@ -207,7 +219,7 @@ __global__ void __launch_bounds__(kLanes) k_inflate_tokens(const unsigned char* 
     bits_init(b, comp + d.src_off, d.src_len, comp + comp_len);
     Out w;
     w.tok = tokens + d.tok_off; w.nt = 0; w.o = 0; w.len = d.dst_len;
-    int lc[16], dc[16];            // code counts per length of the current block's two Huffman codes
+    Code lc, dc;                   // the current block's two Huffman codes (limits / bases per length, in registers)
     int st = INF_OK;
     if (zlib_wrapped) {
         if (d.src_len < 6) st = INF_EHEADER;
@@ -241,8 +253,8 @@ __global__ void __launch_bounds__(kLanes) k_inflate_tokens(const unsigned char* 
             construct(L.lcnt, L.lsym, L.lens, 0, kFixLCodes, lane);
             for (int s = 0; s < kMaxDCodes; ++s) L.lens[s][lane] = 5;
             construct(L.dcnt, L.dsym, L.lens, 0, kMaxDCodes, lane);
-#pragma unroll
-            for (int k = 0; k < 16; ++k) { lc[k] = L.lcnt[k][lane]; dc[k] = L.dcnt[k][lane]; }
+            code_from_counts(lc, L.lcnt, lane);
+            code_from_counts(dc, L.dcnt, lane);
             st = codes(b, w, L, lc, dc, lane);
         } else if (type == 2) {
             const int nlen = (int)take(b, 5) + 257, ndist = (int)take(b, 5) + 1, ncode = (int)take(b, 4) + 4;
@@ -252,8 +264,7 @@ __global__ void __launch_bounds__(kLanes) k_inflate_tokens(const unsigned char* 
             for (int i = 0; i < ncode; ++i) L.lens[kClOrder[i]][lane] = (unsigned char)take(b, 3);
             if (b.over) { st = INF_EINPUT; break; }
             if (construct(L.lcnt, L.lsym, L.lens, 0, 19, lane) != 0) { st = INF_ETABLE; break; }   // the code-length code must be complete
-#pragma unroll
-            for (int k = 0; k < 16; ++k) lc[k] = L.lcnt[k][lane];
+            code_from_counts(lc, L.lcnt, lane);
             int i = 0;
             while (i < nlen + ndist) {
                 int sym = decode(b, lc, L.lsym, lane);
@@ -280,8 +291,8 @@ __global__ void __launch_bounds__(kLanes) k_inflate_tokens(const unsigned char* 
             if (err < 0 || (err > 0 && nlen - L.lcnt[0][lane] != 1)) { st = INF_ETABLE; break; }
             err = construct(L.dcnt, L.dsym, L.lens, nlen, ndist, lane);
             if (err < 0 || (err > 0 && ndist - L.dcnt[0][lane] != 1)) { st = INF_ETABLE; break; }
-#pragma unroll
-            for (int k = 0; k < 16; ++k) { lc[k] = L.lcnt[k][lane]; dc[k] = L.dcnt[k][lane]; }
+            code_from_counts(lc, L.lcnt, lane);
+            code_from_counts(dc, L.dcnt, lane);
             st = codes(b, w, L, lc, dc, lane);
         } else {
             st = INF_ECODE;
