@@ -25,6 +25,7 @@
 // out-of-range access.
 #include "common.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -39,13 +40,28 @@ struct InfDesc { int64_t src_off, src_len, dst_off, dst_len, tok_off; };
 // status per chunk
 enum { INF_OK = 0, INF_EINPUT = 1, INF_EOUTPUT = 2, INF_EHEADER = 3, INF_ECODE = 4, INF_EDIST = 5, INF_ETABLE = 6, INF_ESTORED = 7, INF_ESHORT = 8 };
 
-struct Lds {   // one wavefront: [entry][lane]
-    unsigned short lcnt[16][kLanes];
-    unsigned short lsym[kFixLCodes][kLanes];
-    unsigned short dcnt[16][kLanes];
-    unsigned short dsym[kMaxDCodes][kLanes];
-    unsigned char lens[kMaxLCodes + kMaxDCodes + 4][kLanes];
+// one wavefront, [entry][lane].  Packed so that four wavefronts share a CU (37 KB each): the kernel is bound by instruction
+// latency with every lane on its own data-dependent path, so resident wavefronts are what buys throughput.  Symbols are 9 bits
+// (0..287): the low byte in lsym, bit 8 in a bit array; code lengths are 4 bits, two per byte.
+// LPW = streams (active lanes) per wavefront.  A batch of 1 024 frames is ~30 000 streams: at 64 per wavefront that is 500
+// wavefronts for 1 024 SIMDs, each crawling through 64 unrelated streams in lockstep.  With 8 streams per wavefront there are 8x
+// more wavefronts (several per SIMD, hiding each other's latency), each waits only for the slowest of 8 paths, and its tables
+// take 4.6 KB of LDS.  The idle lanes cost nothing: this kernel is bound by latency, not by lanes.
+template <int LPW>
+struct LdsT {
+    unsigned short lcnt[16][LPW];
+    unsigned char lsym[kFixLCodes][LPW];
+    unsigned lhi[kFixLCodes / 32][LPW];
+    unsigned short dcnt[16][LPW];
+    unsigned char dsym[32][LPW];
+    unsigned char lens[(kMaxLCodes + kMaxDCodes + 4) / 2][LPW];
 };
+template <class Lds> __device__ __forceinline__ int get_len(const Lds& L, int i, int lane) { return (L.lens[i >> 1][lane] >> ((i & 1) * 4)) & 15; }
+template <class Lds> __device__ __forceinline__ void set_len(Lds& L, int i, int lane, int v) {
+    const int sh = (i & 1) * 4;
+    L.lens[i >> 1][lane] = (unsigned char)((L.lens[i >> 1][lane] & ~(15 << sh)) | (v << sh));
+}
+
 
 // Bit reader: the compressed bytes arrive 16 at a time (one aligned global load per 16 bytes — a byte-wise reader pays the
 // ~700-cycle global latency per input byte, with all 64 lanes of the wave waiting in lockstep), 32 bits at a time into the
@@ -54,6 +70,8 @@ struct Bits {
     const uint4* blk;       // next aligned 16-byte block
     const uint4* blk_end;   // one past the last block that may be read
     uint4 cur;              // the block being consumed
+    uint4 nxt;              // the block after it, requested when `cur` was taken: a load issued only when its data is needed
+                            // would have to wait — behind every token store the wavefront has queued before it — on each refill
     int widx;               // next 32-bit word of `cur` (4: none left)
     unsigned long long buf;
     int cnt;
@@ -63,8 +81,9 @@ struct Bits {
 
 __device__ __forceinline__ unsigned next_word(Bits& b) {
     if (b.widx == 4) {
-        if (b.blk < b.blk_end) b.cur = *b.blk;
-        else b.cur = make_uint4(0, 0, 0, 0);
+        b.cur = b.nxt;
+        if (b.blk < b.blk_end) b.nxt = *b.blk;
+        else b.nxt = make_uint4(0, 0, 0, 0);
         ++b.blk;
         b.widx = 0;
     }
@@ -86,6 +105,10 @@ __device__ __forceinline__ void bits_init(Bits& b, const unsigned char* p, long 
     if (own_end < b.blk_end) b.blk_end = own_end;       // never read past the stream's last block (nor past the buffer)
     b.widx = 4; b.buf = 0; b.cnt = 0; b.over = false;
     b.remaining = 8 * len;
+    b.cur = make_uint4(0, 0, 0, 0);
+    if (b.blk < b.blk_end) b.nxt = *b.blk;            // prime the pipeline: the first block
+    else b.nxt = make_uint4(0, 0, 0, 0);
+    ++b.blk;
     const int skip = (int)(a & 15);
     for (int k = 0; k < (skip >> 2); ++k) (void)next_word(b);   // whole words in front of the stream
     if (skip & 3) {                                             // and the leading bytes of its first word
@@ -111,7 +134,8 @@ __device__ __forceinline__ unsigned take(Bits& b, int n) {   // n <= 16
 // the symbol index is (v >> (15 - L)) + base[L] with base[L] = offs[L] - first[L] — 15 compares, 14 selects, no branch.
 struct Code { int lim[16]; int bas[16]; };     // [1..15]; bas[1] = base[1], bas[L > 1] = base[L] - base[L-1] (deltas: a select
                                                // chain over base[] itself is folded by hipcc into a register-array index = scratch)
-__device__ __forceinline__ void code_from_counts(Code& c, const unsigned short (*cnt)[kLanes], int lane) {
+template <int LPW>
+__device__ __forceinline__ void code_from_counts(Code& c, const unsigned short (*cnt)[LPW], int lane) {
     int first = 0, offs = 0, prev_base = 0;
 #pragma unroll
     for (int len = 1; len <= kMaxBits; ++len) {
@@ -123,7 +147,8 @@ __device__ __forceinline__ void code_from_counts(Code& c, const unsigned short (
         first = (first + count) << 1;
     }
 }
-__device__ __forceinline__ int decode(Bits& b, const Code& c, const unsigned short (*sym)[kLanes], int lane) {
+template <bool WIDE, class Lds, int LPW>     // WIDE: the literal/length table (9-bit symbols: byte + bit array); else the byte table `sym`
+__device__ __forceinline__ int decode(Bits& b, const Code& c, const Lds& L, const unsigned char (*sym)[LPW], int lane) {
     refill(b);
     const int v = (int)(__brev((unsigned)(b.buf & 0x7fff)) >> 17);
     int len = 1, base = c.bas[1];
@@ -138,15 +163,17 @@ __device__ __forceinline__ int decode(Bits& b, const Code& c, const unsigned sho
     b.cnt -= len;
     b.remaining -= len;
     if (b.remaining < 0) { b.over = true; return -1; }
-    return sym[(v >> (kMaxBits - len)) + base][lane];
+    const int idx = (v >> (kMaxBits - len)) + base;
+    if (WIDE) return (int)L.lsym[idx][lane] | (int)(((L.lhi[idx >> 5][lane] >> (idx & 31)) & 1u) << 8);
+    return sym[idx][lane];
 }
 
-// build count[] / symbol[] from code lengths lens[base .. base + n); returns < 0 for an over-subscribed set, > 0 for an
+// build count[] / symbol[] from the code lengths lens[base .. base + n); returns < 0 for an over-subscribed set, > 0 for an
 // incomplete one, 0 for a complete one
-__device__ __forceinline__ int construct(unsigned short (*cnt)[kLanes], unsigned short (*sym)[kLanes], const unsigned char (*lens)[kLanes], int base, int n,
-                         int lane) {
+template <bool WIDE, class Lds, int LPW>
+__device__ __forceinline__ int construct(Lds& L, unsigned short (*cnt)[LPW], unsigned char (*sym)[LPW], int base, int n, int lane) {
     for (int len = 0; len <= kMaxBits; ++len) cnt[len][lane] = 0;
-    for (int s = 0; s < n; ++s) cnt[lens[base + s][lane]][lane]++;
+    for (int s = 0; s < n; ++s) cnt[get_len(L, base + s, lane)][lane]++;
     if (cnt[0][lane] == n) return 0;   // no codes: complete, but decoding will fail
     int left = 1;
     for (int len = 1; len <= kMaxBits; ++len) {
@@ -154,12 +181,30 @@ __device__ __forceinline__ int construct(unsigned short (*cnt)[kLanes], unsigned
         left -= cnt[len][lane];
         if (left < 0) return left;
     }
-    unsigned short offs[kMaxBits + 1];
-    offs[1] = 0;
+    // offs[len]: where the next symbol of that length goes — kept in LDS by reusing cnt[] after the counts were consumed would
+    // lose them (code_from_counts needs them), so: a running prefix in registers, one pass per length would be 15 passes; instead
+    // the offsets live in a small per-lane array that the compiler keeps in registers (all indices below are select chains)
+    int offs[kMaxBits + 1];
+    offs[0] = 0; offs[1] = 0;
+#pragma unroll
     for (int len = 1; len < kMaxBits; ++len) offs[len + 1] = offs[len] + cnt[len][lane];
+    if (WIDE) {
+#pragma unroll
+        for (int w = 0; w < kFixLCodes / 32; ++w) L.lhi[w][lane] = 0;
+    }
     for (int s = 0; s < n; ++s) {
-        const int l = lens[base + s][lane];
-        if (l != 0) sym[offs[l]++][lane] = (unsigned short)s;
+        const int l = get_len(L, base + s, lane);
+        if (l != 0) {
+            int at = 0;
+#pragma unroll
+            for (int k = 1; k <= kMaxBits; ++k) {
+                const bool here = k == l;
+                at += here ? offs[k] : 0;
+                offs[k] += here ? 1 : 0;
+            }
+            sym[at][lane] = (unsigned char)(s & 0xff);
+            if (WIDE && (s & 0x100)) L.lhi[at >> 5][lane] |= 1u << (at & 31);
+        }
     }
     return left;
 }
@@ -175,16 +220,31 @@ __device__ __forceinline__ void emit(Out& w, unsigned b) {
     ++w.o;
 }
 
-__constant__ unsigned short kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-__constant__ unsigned char kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-__constant__ unsigned short kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-__constant__ unsigned char kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
-__constant__ unsigned char kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+// Length / distance bases and extra-bit counts by formula (RFC 1951 §3.2.5) — as tables in constant memory they were global
+// loads per match, and a load in this kernel waits behind every token store queued before it.
+__device__ __forceinline__ void len_code(int s, int* base, int* extra) {      // s = symbol - 257 in 0..28
+    const int e = s < 8 ? 0 : (s >> 2) - 1;
+    *extra = s == 28 ? 0 : e;
+    *base = s == 28 ? 258 : (s < 8 ? 3 + s : 3 + ((4 + (s & 3)) << e));
+}
+__device__ __forceinline__ void dist_code(int s, int* base, int* extra) {     // s in 0..29
+    const int e = s < 4 ? 0 : (s >> 1) - 1;
+    *extra = e;
+    *base = s < 4 ? 1 + s : 1 + ((2 + (s & 1)) << e);
+}
+// order of the code-length code lengths (RFC 1951 §3.2.7), 5 bits each: 16 17 18 0 8 7 9 6 10 5 11 4 | 12 3 13 2 14 1 15
+__device__ __forceinline__ int cl_order(int i) {
+    const unsigned long long A = 16ull | 17ull << 5 | 18ull << 10 | 0ull << 15 | 8ull << 20 | 7ull << 25 | 9ull << 30 | 6ull << 35 | 10ull << 40 |
+                                 5ull << 45 | 11ull << 50 | 4ull << 55;
+    const unsigned long long B = 12ull | 3ull << 5 | 13ull << 10 | 2ull << 15 | 14ull << 20 | 1ull << 25 | 15ull << 30;
+    return (int)((i < 12 ? A >> (5 * i) : B >> (5 * (i - 12))) & 31);
+}
 
 // literal / length + distance symbols of one compressed block
+template <class Lds>
 __device__ __forceinline__ int codes(Bits& b, Out& w, Lds& L, const Code& lc, const Code& dc, int lane) {
     for (;;) {
-        int sym = decode(b, lc, L.lsym, lane);
+        int sym = decode<true>(b, lc, L, L.lsym, lane);
         if (sym < 0) return b.over ? INF_EINPUT : INF_ECODE;
         if (sym < 256) {
             if (w.o >= w.len) return INF_EOUTPUT;
@@ -194,11 +254,15 @@ __device__ __forceinline__ int codes(Bits& b, Out& w, Lds& L, const Code& lc, co
         } else {
             sym -= 257;
             if (sym >= 29) return INF_ECODE;
-            int len = kLenBase[sym] + (int)take(b, kLenExtra[sym]);
-            const int ds = decode(b, dc, L.dsym, lane);
+            int lbase, lextra;
+            len_code(sym, &lbase, &lextra);
+            const int len = lbase + (int)take(b, lextra);
+            const int ds = decode<false>(b, dc, L, L.dsym, lane);
             if (ds < 0) return b.over ? INF_EINPUT : INF_ECODE;
             if (ds >= 30) return INF_ECODE;
-            const long long dist = kDistBase[ds] + (long long)take(b, kDistExtra[ds]);
+            int dbase, dextra;
+            dist_code(ds, &dbase, &dextra);
+            const long long dist = dbase + (long long)take(b, dextra);
             if (b.over) return INF_EINPUT;
             if (dist > w.o) return INF_EDIST;
             if (w.o + len > w.len) return INF_EOUTPUT;
@@ -208,12 +272,14 @@ __device__ __forceinline__ int codes(Bits& b, Out& w, Lds& L, const Code& lc, co
     }
 }
 
+template <int LPW>
 __global__ void __launch_bounds__(kLanes) k_inflate_tokens(const unsigned char* comp, long long comp_len, const InfDesc* desc, long long n,
-                                                           unsigned* tokens, long long* ntok, int* status, int zlib_wrapped) {
+                                                        unsigned* tokens, long long* ntok, int* status, int zlib_wrapped) {
+    typedef LdsT<LPW> Lds;
     __shared__ Lds L;
     const int lane = threadIdx.x;
-    const long long idx = (long long)blockIdx.x * kLanes + lane;
-    if (idx >= n) return;
+    const long long idx = (long long)blockIdx.x * LPW + lane;
+    if (lane >= LPW || idx >= n) return;
     const InfDesc d = desc[idx];
     Bits b;
     bits_init(b, comp + d.src_off, d.src_len, comp + comp_len);
@@ -246,13 +312,13 @@ __global__ void __launch_bounds__(kLanes) k_inflate_tokens(const unsigned char* 
             }
             if (b.over) { st = INF_EINPUT; break; }
         } else if (type == 1) {
-            for (int s = 0; s < 144; ++s) L.lens[s][lane] = 8;
-            for (int s = 144; s < 256; ++s) L.lens[s][lane] = 9;
-            for (int s = 256; s < 280; ++s) L.lens[s][lane] = 7;
-            for (int s = 280; s < kFixLCodes; ++s) L.lens[s][lane] = 8;
-            construct(L.lcnt, L.lsym, L.lens, 0, kFixLCodes, lane);
-            for (int s = 0; s < kMaxDCodes; ++s) L.lens[s][lane] = 5;
-            construct(L.dcnt, L.dsym, L.lens, 0, kMaxDCodes, lane);
+            for (int s = 0; s < 144; ++s) set_len(L, s, lane, 8);
+            for (int s = 144; s < 256; ++s) set_len(L, s, lane, 9);
+            for (int s = 256; s < 280; ++s) set_len(L, s, lane, 7);
+            for (int s = 280; s < kFixLCodes; ++s) set_len(L, s, lane, 8);
+            construct<true>(L, L.lcnt, L.lsym, 0, kFixLCodes, lane);
+            for (int s = 0; s < kMaxDCodes; ++s) set_len(L, s, lane, 5);
+            construct<false>(L, L.dcnt, L.dsym, 0, kMaxDCodes, lane);
             code_from_counts(lc, L.lcnt, lane);
             code_from_counts(dc, L.dcnt, lane);
             st = codes(b, w, L, lc, dc, lane);
@@ -260,36 +326,36 @@ __global__ void __launch_bounds__(kLanes) k_inflate_tokens(const unsigned char* 
             const int nlen = (int)take(b, 5) + 257, ndist = (int)take(b, 5) + 1, ncode = (int)take(b, 4) + 4;
             if (b.over) { st = INF_EINPUT; break; }
             if (nlen > kMaxLCodes || ndist > kMaxDCodes) { st = INF_ETABLE; break; }
-            for (int i = 0; i < 19; ++i) L.lens[i][lane] = 0;
-            for (int i = 0; i < ncode; ++i) L.lens[kClOrder[i]][lane] = (unsigned char)take(b, 3);
+            for (int i = 0; i < 19; ++i) set_len(L, i, lane, 0);
+            for (int i = 0; i < ncode; ++i) set_len(L, cl_order(i), lane, (int)take(b, 3));
             if (b.over) { st = INF_EINPUT; break; }
-            if (construct(L.lcnt, L.lsym, L.lens, 0, 19, lane) != 0) { st = INF_ETABLE; break; }   // the code-length code must be complete
+            if (construct<false>(L, L.lcnt, L.dsym, 0, 19, lane) != 0) { st = INF_ETABLE; break; }   // the code-length code must be complete (its 19 symbols borrow dsym)
             code_from_counts(lc, L.lcnt, lane);
             int i = 0;
             while (i < nlen + ndist) {
-                int sym = decode(b, lc, L.lsym, lane);
+                int sym = decode<false>(b, lc, L, L.dsym, lane);
                 if (sym < 0) { st = b.over ? INF_EINPUT : INF_ECODE; break; }
                 if (sym < 16) {
-                    L.lens[i++][lane] = (unsigned char)sym;
+                    set_len(L, i++, lane, sym);
                 } else {
                     int rep, val = 0;
                     if (sym == 16) {
                         if (i == 0) { st = INF_ETABLE; break; }
-                        val = L.lens[i - 1][lane];
+                        val = get_len(L, i - 1, lane);
                         rep = 3 + (int)take(b, 2);
                     } else if (sym == 17) rep = 3 + (int)take(b, 3);
                     else rep = 11 + (int)take(b, 7);
                     if (b.over) { st = INF_EINPUT; break; }
                     if (i + rep > nlen + ndist) { st = INF_ETABLE; break; }
-                    while (rep--) L.lens[i++][lane] = (unsigned char)val;
+                    while (rep--) set_len(L, i++, lane, val);
                 }
             }
             if (st != INF_OK) break;
-            if (L.lens[256][lane] == 0) { st = INF_ETABLE; break; }        // no end-of-block code
+            if (get_len(L, 256, lane) == 0) { st = INF_ETABLE; break; }        // no end-of-block code
             // (the code-length tables in lcnt/lsym are done with: build the real ones; lens[] is read, never written, here)
-            int err = construct(L.lcnt, L.lsym, L.lens, 0, nlen, lane);
+            int err = construct<true>(L, L.lcnt, L.lsym, 0, nlen, lane);
             if (err < 0 || (err > 0 && nlen - L.lcnt[0][lane] != 1)) { st = INF_ETABLE; break; }
-            err = construct(L.dcnt, L.dsym, L.lens, nlen, ndist, lane);
+            err = construct<false>(L, L.dcnt, L.dsym, nlen, ndist, lane);
             if (err < 0 || (err > 0 && ndist - L.dcnt[0][lane] != 1)) { st = INF_ETABLE; break; }
             code_from_counts(lc, L.lcnt, lane);
             code_from_counts(dc, L.dcnt, lane);
@@ -429,6 +495,19 @@ __global__ void k_place_chunks(const PlaceArgs a, long long n_chunks) {
     }
 }
 
+// streams per wavefront: as few as keeps the grid under ~8 k wavefronts (see LdsT)
+inline void launch_tokens(hipStream_t stream, const unsigned char* comp, long long comp_len, const InfDesc* desc, long long n, unsigned* tok,
+                          long long* ntok, int* st, int wrapped) {
+    static const int forced = getenv("TH_INFLATE_LPW") ? atoi(getenv("TH_INFLATE_LPW")) : 0;     // A/B: 8, 16 or 64
+    const int lpw = forced ? forced : (n <= 8 * 8192 ? 8 : (n <= 16 * 8192 ? 16 : 64));
+    if (lpw == 8)
+        hipLaunchKernelGGL(k_inflate_tokens<8>, dim3((unsigned)((n + 7) / 8)), dim3(kLanes), 0, stream, comp, comp_len, desc, n, tok, ntok, st, wrapped);
+    else if (lpw == 16)
+        hipLaunchKernelGGL(k_inflate_tokens<16>, dim3((unsigned)((n + 15) / 16)), dim3(kLanes), 0, stream, comp, comp_len, desc, n, tok, ntok, st, wrapped);
+    else
+        hipLaunchKernelGGL(k_inflate_tokens<64>, dim3((unsigned)((n + 63) / 64)), dim3(kLanes), 0, stream, comp, comp_len, desc, n, tok, ntok, st, wrapped);
+}
+
 // LDS window of k_lz_resolve for streams of at most max_len bytes
 inline unsigned ring_bytes(int64_t max_len) { return max_len <= 16384 ? 16384u : (max_len <= 32768 ? 32768u : 65536u); }
 
@@ -486,8 +565,7 @@ extern "C" int th_inflate_many(int device, const void* comp, int64_t comp_len, i
     if (!rc && (e = hipMemcpy(d_desc, desc.data(), (size_t)n * sizeof(InfDesc), hipMemcpyHostToDevice)) != hipSuccess) fail(e, "copy in");
     if (!rc && (e = hipMemset(d_st, 0xff, (size_t)n * sizeof(int))) != hipSuccess) fail(e, "memset");
     if (!rc) {
-        hipLaunchKernelGGL(k_inflate_tokens, dim3((unsigned)((n + kLanes - 1) / kLanes)), dim3(kLanes), 0, 0, d_comp, (long long)comp_len, d_desc,
-                           (long long)n, d_tok, d_nt, d_st, wrapped);
+        launch_tokens(nullptr, d_comp, (long long)comp_len, d_desc, (long long)n, d_tok, d_nt, d_st, wrapped);
         if ((e = hipGetLastError()) != hipSuccess) fail(e, "launch");
     }
     if (!rc) {
@@ -539,8 +617,8 @@ int inflate_place_device(int device, hipStream_t stream, const void* span, int64
     HIP_TRY(hipMemcpyAsync(d_desc.p, desc.data(), (size_t)n_chunks * sizeof(InfDesc), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(d_ds.p, ds, (size_t)n_chunks * sizeof(int), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(d_coff.p, coff8, (size_t)n_chunks * 8 * sizeof(int), hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(k_inflate_tokens, dim3((unsigned)((n_chunks + kLanes - 1) / kLanes)), dim3(kLanes), 0, stream, (const unsigned char*)d_comp.p,
-                       (long long)span_len, (const InfDesc*)d_desc.p, (long long)n_chunks, (unsigned*)d_tok.p, (long long*)d_nt.p, (int*)d_st.p, 1);
+    launch_tokens(stream, (const unsigned char*)d_comp.p, (long long)span_len, (const InfDesc*)d_desc.p, (long long)n_chunks, (unsigned*)d_tok.p,
+                  (long long*)d_nt.p, (int*)d_st.p, 1);
     HIP_TRY(hipGetLastError());
     {
         const unsigned R = ring_bytes(chunk_bytes);
