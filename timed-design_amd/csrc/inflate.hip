@@ -495,11 +495,14 @@ __global__ void k_place_chunks(const PlaceArgs a, long long n_chunks) {
     }
 }
 
-// streams per wavefront: as few as keeps the grid under ~8 k wavefronts (see LdsT)
+// streams per wavefront (see LdsT)
 inline void launch_tokens(hipStream_t stream, const unsigned char* comp, long long comp_len, const InfDesc* desc, long long n, unsigned* tok,
                           long long* ntok, int* st, int wrapped) {
     static const int forced = getenv("TH_INFLATE_LPW") ? atoi(getenv("TH_INFLATE_LPW")) : 0;     // A/B: 8, 16 or 64
-    const int lpw = forced ? forced : (n <= 8 * 8192 ? 8 : (n <= 16 * 8192 ? 16 : 64));
+    // measured (gzip float64 frames, ~28 KB chunks): 32 k streams take 5 ms whatever LPW is (the serial chain of one stream);
+    // 131 k streams 10.0 / 11.3 / 16.1 ms at LPW 64 / 16 / 8 — a wavefront costs the same instruction slots with 8 active lanes
+    // as with 64, and the lanes in flight are bounded by LDS (580 B per stream) either way.  Few streams: spread them over CUs.
+    const int lpw = forced ? forced : (n >= 16384 ? 64 : (n >= 2048 ? 16 : 8));
     if (lpw == 8)
         hipLaunchKernelGGL(k_inflate_tokens<8>, dim3((unsigned)((n + 7) / 8)), dim3(kLanes), 0, stream, comp, comp_len, desc, n, tok, ntok, st, wrapped);
     else if (lpw == 16)

@@ -293,6 +293,32 @@ class _DevicePool:
 
 
 _DEVICE_POOL = _DevicePool()
+_H5_KEEP: dict = {}      # path -> (mtime, size, h5lite.File): the dataset load_batch_device read last stays mapped
+
+
+def _kept_h5lite(dataset_path):
+    """The reference re-opens the dataset for every batch (utils.py:514); mapping and unmapping a multi-GB file costs ~7 ms
+    per call (munmap), so the device path keeps the file it read last open (re-opened when the file changed on disk)."""
+    from timed_hip import h5lite
+    key = os.path.abspath(os.fspath(dataset_path))
+    st = os.stat(key)
+    kept = _H5_KEEP.get(key)
+    if kept is not None and kept[0] == st.st_mtime_ns and kept[1] == st.st_size:
+        return kept[2]
+    for _k, (_m, _s, f) in list(_H5_KEEP.items()):
+        try:
+            f.close()
+        except Exception:
+            pass
+    _H5_KEEP.clear()
+    try:
+        import h5py  # noqa: F401  (when h5py is importable the general readers use it: this path is h5lite-only)
+        return None
+    except ImportError:
+        pass
+    f = h5lite.File(key)
+    _H5_KEEP[key] = (st.st_mtime_ns, st.st_size, f)
+    return f
 
 
 def load_batch_device(dataset_path: Path, data_point_batch, device: int = 0):
@@ -307,9 +333,10 @@ def load_batch_device(dataset_path: Path, data_point_batch, device: int = 0):
     n = len(data_point_batch)
     if n == 0:
         return None
-    with open_frame_dataset(dataset_path) as dataset:
-        if not _is_h5lite_file(dataset):
-            return None
+    dataset = _kept_h5lite(dataset_path)
+    if dataset is None:
+        return None
+    if True:
         dims = tuple(int(d) for d in np.asarray(dataset.attrs["frame_dims"]).ravel())
         gaussian = bool(dataset.attrs["voxels_as_gaussian"])
         addrs = np.full(n, -1, dtype=np.int64)
