@@ -261,6 +261,14 @@ int th_h5_resolve(const void* file, int64_t file_len, int64_t base, int64_t n, c
                   double* num_out, int num_len, const char* str_attr, char* str_out, int str_len, int64_t* btree_out,
                   int64_t* geom_out, int* status_out, int nthreads);
 
+/* Every link of one old-style HDF5 group in one call (create_flat_dataset_map, reference utils.py:357-375, lists each pdb
+ * group, its chain groups and every residue name: `for pdb_code in dataset_file`, `.keys()`).  btree_addr: the group B-tree of
+ * the symbol-table message; heap_data / heap_size: absolute offset and length of the local heap's data segment.  names receives
+ * the link names, NUL-terminated, in B-tree (name) order — *names_len bytes —, addrs[i] the object-header address of link i,
+ * *n_out the count.  TH_ENOMEM: a capacity was too small; TH_EINVAL: not a well-formed group B-tree inside the file. */
+int th_h5_group_links(const void* file, int64_t file_len, int64_t base, int64_t btree_addr, int64_t heap_data, int64_t heap_size,
+                      char* names, int64_t names_cap, int64_t* addrs, int64_t addrs_cap, int64_t* n_out, int64_t* names_len);
+
 /* ---- voxeliser: the producer of the frames — replaces aposteriori.make_frame_dataset as the reference invokes it
  * (ui.py:73-86: frame_edge_length 21.0, voxels_per_side 21, Codec.CNOCACB, voxels_as_gaussian=True; README.md:83-97).
  * PARITY UNPINNED: aposteriori's source is not in the reference tree; the specification implemented here is written out

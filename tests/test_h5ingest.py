@@ -291,3 +291,124 @@ def test_load_batch_on_corrupted_files_raises_or_returns(tmp_path):
             outcomes["raised"] += 1
         p.unlink()
     assert outcomes["ok"] + outcomes["raised"] == 60 and outcomes["ok"] > 0
+
+
+def _group_tables(f):
+    """(btree, heap data offset, heap size, python-walked links) of every old-style group of an h5lite file"""
+    import struct
+    out = []
+    todo, seen = [f._root], set()
+    while todo:
+        g = todo.pop()
+        if g._addr in seen:
+            continue
+        seen.add(g._addr)
+        for mtype, _fl, d in g._messages():
+            if mtype == 0x11:
+                btree, heap = struct.unpack_from("<QQ", d, 0)
+                hd = g._local_heap(heap)
+                links = {}
+                g._walk_btree(btree, hd, links)
+                out.append((btree, hd[0], hd[1], links))
+        for name in g.keys():
+            child = g[name]
+            if isinstance(child, h5lite.Group):
+                todo.append(child)
+    return out
+
+
+@pytest.mark.parametrize("name", ["frames_tiny.hdf5", "frames_tiny_bool.hdf5"])
+def test_native_group_listing_equals_interpreter_walk(name):
+    """th_h5_group_links (what Group._load now calls) against h5lite's own symbol-table walk, which the real-h5py fixtures of
+    test_host_utils.py pin: same names, same object-header addresses, same (B-tree) order; a capacity one short is refused"""
+    import ctypes as C
+    from timed_hip import _lib
+    lib = _lib.load()
+    with h5lite.File(os.path.join(G, name)) as f:
+        tables = _group_tables(f)
+        assert len(tables) >= 3
+        whole = np.frombuffer(f._m, dtype=np.uint8)
+        for btree, hoff, hsize, links in tables:
+            names = np.zeros(hsize + 8, np.uint8)
+            addrs = np.zeros(hsize + 8, np.int64)
+            n, used = C.c_int64(), C.c_int64()
+            rc = lib.th_h5_group_links(whole.ctypes.data_as(C.c_void_p), whole.size, f._base, btree, hoff, hsize,
+                                       names.ctypes.data_as(C.c_void_p), names.size, addrs.ctypes.data_as(C.POINTER(C.c_int64)), addrs.size,
+                                       C.byref(n), C.byref(used))
+            assert rc == 0 and n.value == len(links)
+            got = names[:used.value].tobytes().decode().split("\0")[:-1]
+            assert got == list(links.keys()) and addrs[:n.value].tolist() == list(links.values())
+            if n.value:
+                rc = lib.th_h5_group_links(whole.ctypes.data_as(C.c_void_p), whole.size, f._base, btree, hoff, hsize,
+                                           names.ctypes.data_as(C.c_void_p), names.size, addrs.ctypes.data_as(C.POINTER(C.c_int64)),
+                                           n.value - 1, C.byref(n), C.byref(used))
+                assert rc != 0
+                rc = lib.th_h5_group_links(whole.ctypes.data_as(C.c_void_p), whole.size, f._base, btree, hoff, hsize,
+                                           names.ctypes.data_as(C.c_void_p), used.value - 1, addrs.ctypes.data_as(C.POINTER(C.c_int64)),
+                                           addrs.size, C.byref(n), C.byref(used))
+                assert rc != 0
+        del whole
+        # and the product path: Group._load through the native call == through the interpreter walk
+        g = next(iter(f[next(iter(f))].keys()))
+        grp = f[next(iter(f))][g]
+        native = dict(grp._load())
+        grp._links = None
+        grp._links_native = lambda *a: False
+        assert grp._load() == native and list(grp._load().keys()) == list(native.keys())
+
+
+def test_group_listing_survives_truncated_and_corrupted_files():
+    """th_h5_group_links parses untrusted bytes: truncations and byte flips inside the B-tree / SNOD / heap region, the buffer
+    ending exactly at a PROT_NONE guard page — every call returns (0 or an error code), none reads past the buffer"""
+    import ctypes as C
+    import mmap
+    from timed_hip import _lib
+    lib = _lib.load()
+    path = os.path.join(G, "frames_tiny.hdf5")
+    data = open(path, "rb").read()
+    with h5lite.File(path) as f:
+        tables = [(b, o, s) for b, o, s, _ in _group_tables(f)]
+        base = f._base
+    libc = C.CDLL(None, use_errno=True)
+    libc.mprotect.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+    page = mmap.PAGESIZE
+    names = np.zeros(1 << 16, np.uint8)
+    addrs = np.zeros(1 << 13, np.int64)
+
+    def run(buf: bytes):
+        size = len(buf)
+        npages = (size + page - 1) // page + 1
+        m = mmap.mmap(-1, npages * page)
+        start = (npages - 1) * page - size
+        m[start:start + size] = buf
+        addr = C.addressof(C.c_char.from_buffer(m))
+        assert libc.mprotect(addr + (npages - 1) * page, page, 0) == 0
+        rcs = []
+        for btree, hoff, hsize in tables:
+            n, used = C.c_int64(), C.c_int64()
+            rcs.append(lib.th_h5_group_links(C.c_void_p(addr + start), size, base, btree, hoff, hsize, names.ctypes.data_as(C.c_void_p),
+                                             names.size, addrs.ctypes.data_as(C.POINTER(C.c_int64)), addrs.size, C.byref(n), C.byref(used)))
+            assert 0 <= n.value <= addrs.size and 0 <= used.value <= names.size
+        libc.mprotect(addr + (npages - 1) * page, page, 3)
+        del addr
+        m.close()
+        return rcs
+
+    assert all(rc == 0 for rc in run(data))
+    for cut in range(len(data) - 1, 64, -89):
+        run(data[:cut])
+    rng = np.random.default_rng(1)
+    lo = min(min(b + base, o) for b, o, _ in tables)
+    hi = min(len(data), max(max(b + base, o + s) for b, o, s in tables) + 4096)
+    for _ in range(300):
+        b = bytearray(data)
+        for pos in rng.integers(lo, hi, size=int(rng.integers(1, 12))):
+            b[pos] = int(rng.integers(0, 256))
+        run(bytes(b))
+    # wild arguments
+    n, used = C.c_int64(), C.c_int64()
+    buf = np.frombuffer(data, np.uint8)
+    for btree, hoff, hsize in [(10 ** 15, 0, 8), (-5, 0, 8), (tables[0][0], len(data) - 4, 64), (tables[0][0], -1, 8), (tables[0][0], 0, -3)]:
+        rc = lib.th_h5_group_links(buf.ctypes.data_as(C.c_void_p), buf.size, base, btree, hoff, hsize, names.ctypes.data_as(C.c_void_p),
+                                   names.size, addrs.ctypes.data_as(C.POINTER(C.c_int64)), addrs.size, C.byref(n), C.byref(used))
+        assert rc != 0

@@ -743,3 +743,63 @@ extern "C" int th_h5_read_contiguous_as(const void* file, int64_t file_len, int6
     }
     return TH_OK;
 }
+
+// ---- group listing ---------------------------------------------------------------------------------------------------
+// Every link of one old-style group (symbol-table message: a version-1 group B-tree over SNOD nodes, names in a local heap)
+// in one call: create_flat_dataset_map (reference utils.py:357-375) lists a pdb group, its chain groups and ~100 residue
+// names per chain; walking 40 k symbol-table entries in the interpreter costs 1.4 us each.  `heap_data` / `heap_size` are the
+// ABSOLUTE offset and length of the local heap's data segment.  names: the link names, each NUL-terminated, in B-tree order;
+// addrs[i]: the object-header address of link i.  TH_EINVAL for anything that is not a well-formed group B-tree inside the
+// file (the caller's Python walk then raises its own format error), TH_ENOMEM when a capacity is too small.
+namespace {
+int walk_group_node(const uint8_t* f, int64_t len, int64_t base, uint64_t addr, int64_t heap_data, int64_t heap_size, char* names,
+                    int64_t names_cap, int64_t* addrs, int64_t addrs_cap, int64_t* n, int64_t* used_names, int depth, int64_t* budget) {
+    if (depth > 32 || --*budget < 0) return TH_EINVAL;
+    if (addr == kUndef || addr > (uint64_t)len || base < 0 || base > len) return TH_EINVAL;
+    const int64_t a = base + (int64_t)addr;
+    if (a < 0 || a > len - 24 || std::memcmp(f + a, "TREE", 4) != 0 || f[a + 4] != 0) return TH_EINVAL;
+    const int level = f[a + 5];
+    const int entries = rd<uint16_t>(f + a + 6);
+    if (a + 24 + (int64_t)entries * 16 + 8 > len) return TH_EINVAL;
+    for (int i = 0; i < entries; ++i) {
+        const uint64_t child = rd<uint64_t>(f + a + 24 + (int64_t)i * 16 + 8);
+        if (level > 0) {
+            const int rc = walk_group_node(f, len, base, child, heap_data, heap_size, names, names_cap, addrs, addrs_cap, n, used_names,
+                                           depth + 1, budget);
+            if (rc != TH_OK) return rc;
+            continue;
+        }
+        if (child == kUndef || child > (uint64_t)len) return TH_EINVAL;
+        const int64_t s = base + (int64_t)child;
+        if (s < 0 || s > len - 8 || std::memcmp(f + s, "SNOD", 4) != 0) return TH_EINVAL;
+        const int nsym = rd<uint16_t>(f + s + 6);
+        if (s + 8 + (int64_t)nsym * 40 > len) return TH_EINVAL;
+        for (int k = 0; k < nsym; ++k) {
+            const uint8_t* e = f + s + 8 + (int64_t)k * 40;
+            const uint64_t noff = rd<uint64_t>(e), ohdr = rd<uint64_t>(e + 8);
+            if (noff >= (uint64_t)heap_size) return TH_EINVAL;
+            const uint8_t* name = f + heap_data + noff;
+            const void* z = std::memchr(name, 0, (size_t)(heap_size - (int64_t)noff));
+            if (!z) return TH_EINVAL;
+            const int64_t nl = (const uint8_t*)z - name + 1;
+            if (*n >= addrs_cap || *used_names + nl > names_cap) return TH_ENOMEM;
+            std::memcpy(names + *used_names, name, (size_t)nl);
+            *used_names += nl;
+            addrs[(*n)++] = (int64_t)ohdr;
+        }
+    }
+    return TH_OK;
+}
+}  // namespace
+
+extern "C" int th_h5_group_links(const void* file, int64_t file_len, int64_t base, int64_t btree_addr, int64_t heap_data, int64_t heap_size,
+                                 char* names, int64_t names_cap, int64_t* addrs, int64_t addrs_cap, int64_t* n_out, int64_t* names_len) {
+    if (!file || !names || !addrs || !n_out || !names_len || file_len < 0 || names_cap < 0 || addrs_cap < 0) return TH_EINVAL;
+    if (heap_data < 0 || heap_size < 0 || heap_data > file_len || heap_size > file_len - heap_data) return TH_EINVAL;
+    int64_t n = 0, used = 0, budget = 1 << 20;
+    const int rc = walk_group_node((const uint8_t*)file, file_len, base, (uint64_t)btree_addr, heap_data, heap_size, names, names_cap, addrs,
+                                   addrs_cap, &n, &used, 0, &budget);
+    *n_out = n;
+    *names_len = used;
+    return rc;
+}

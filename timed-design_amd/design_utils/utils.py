@@ -11,6 +11,7 @@ alphanumeric map codes, rm_tree.
 """
 from __future__ import annotations
 
+import contextlib
 import os
 import typing as t
 import warnings
@@ -94,7 +95,9 @@ def create_flat_dataset_map(
     uncommon = UNCOMMON_RESIDUE_DICT if uncommon_residue_dict is None else uncommon_residue_dict
     training_set_pdbs = set()
     flat_dataset_map = []
-    with open_frame_dataset(frame_dataset) as dataset_file:
+    chains = []
+    kept = _kept_h5lite(frame_dataset)      # stays mapped, link tables parsed once: load_batch_device reads the same handle
+    with (contextlib.nullcontext(kept) if kept is not None else open_frame_dataset(frame_dataset)) as dataset_file:
         for pdb_code in dataset_file:
             if pdb_code[:4] in filter_list:
                 if remove_blacklist_silently:
@@ -108,18 +111,25 @@ def create_flat_dataset_map(
                 chain_group = pdb_group[chain_id]
                 residue_n = np.array(list(chain_group.keys()), dtype=int)
                 residue_n.sort()
-                labels = _chain_labels(dataset_file, chain_group, residue_n)
-                for k, residue_id in enumerate(residue_n.astype(str)):
-                    residue_label = labels[k] if labels is not None else _as_str(chain_group[str(residue_id)].attrs["label"])
-                    if residue_label not in standard_residues:
-                        if residue_label in uncommon:
-                            warnings.warn(f"{residue_label} is not a standard residue.")
-                            residue_label = uncommon[residue_label]
-                            warnings.warn(f"Residue converted to {residue_label}.")
-                        else:
-                            raise AssertionError(f"Expected natural amino acid, but got {residue_label}.")
-                    flat_dataset_map.append((pdb_code, chain_id, str(residue_id), residue_label))
-                    training_set_pdbs.add(pdb_code)
+                chains.append((pdb_code, chain_id, chain_group, residue_n))
+        # the `label` attribute of every residue (utils.py:375): h5lite files resolve ALL object headers of the file in one
+        # threaded native call; anything else reads attribute by attribute as the reference does
+        all_labels = _all_chain_labels(dataset_file, chains)
+        at = 0
+        for pdb_code, chain_id, chain_group, residue_n in chains:
+            labels = all_labels[at:at + len(residue_n)] if all_labels is not None else None
+            at += len(residue_n)
+            for k, residue_id in enumerate(residue_n.astype(str).tolist()):
+                residue_label = labels[k] if labels is not None else _as_str(chain_group[residue_id].attrs["label"])
+                if residue_label not in standard_residues:
+                    if residue_label in uncommon:
+                        warnings.warn(f"{residue_label} is not a standard residue.")
+                        residue_label = uncommon[residue_label]
+                        warnings.warn(f"Residue converted to {residue_label}.")
+                    else:
+                        raise AssertionError(f"Expected natural amino acid, but got {residue_label}.")
+                flat_dataset_map.append((pdb_code, chain_id, residue_id, residue_label))
+                training_set_pdbs.add(pdb_code)
     return flat_dataset_map, training_set_pdbs
 
 
@@ -143,16 +153,18 @@ def flat_dataset_map_array(frame_dataset: Path, filter_list: t.Sequence[str] = (
     return np.array(flat)
 
 
-def _chain_labels(dataset_file, chain_group, residue_n):
-    """`label` attribute of every residue dataset of one chain in ONE native call (h5lite files only; None otherwise:
+def _all_chain_labels(dataset_file, chains):
+    """`label` attribute of every residue dataset of every chain in ONE native call (h5lite files only; None otherwise:
     the caller then reads attribute by attribute)."""
-    if not _is_h5lite_group(chain_group):
+    if not chains or not all(_is_h5lite_group(c[2]) for c in chains):
         return None
     from timed_hip import h5lite
-    links = chain_group._load()
+    addrs = []
     try:
-        addrs = [links[str(r)] for r in residue_n]
-    except KeyError:
+        for _pdb, _chain, chain_group, residue_n in chains:
+            links = chain_group._load()
+            addrs.extend(links[r] for r in residue_n.astype(str).tolist())
+    except KeyError:        # a residue name that is not its own canonical integer ("007"): the general path handles it
         return None
     res = h5lite.resolve_many(dataset_file, addrs, str_attr="label", str_len=16)
     if res is None or not np.all(res["status"] & 4):

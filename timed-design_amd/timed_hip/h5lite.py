@@ -348,7 +348,8 @@ class Group(_Object):
             if mtype == 0x11:  # symbol table
                 btree, heap = struct.unpack_from("<QQ", d, 0)
                 heap_data = self._local_heap(heap)
-                self._walk_btree(btree, heap_data, links)
+                if not self._links_native(btree, heap_data, links):
+                    self._walk_btree(btree, heap_data, links)
             elif mtype == 0x06:  # link message
                 ver, flags = d[0], d[1]
                 p = 2
@@ -373,6 +374,39 @@ class Group(_Object):
                     raise H5Unsupported(f"{self.name}: dense link storage (file written with libver='latest')")
         self._links = links
         return links
+
+    def _links_native(self, btree: int, heap: Tuple[int, int], links: Dict[str, int]) -> bool:
+        """the whole symbol table in one native call (libtimedhip th_h5_group_links); False when the library is not there
+        or the call declines (the interpreter walk below then runs and raises its own format errors)"""
+        import ctypes as C
+        try:
+            from . import _lib
+            lib = _lib.load()
+        except Exception:
+            return False
+        f = self._f
+        cap = max(int(heap[1]), 16)
+        names = np.empty(cap + 8, dtype=np.uint8)
+        addrs = np.empty(cap // 2 + 8, dtype=np.int64)       # a name takes at least 2 heap bytes ("x\0")
+        n, used = C.c_int64(0), C.c_int64(0)
+        whole = np.frombuffer(f._m, dtype=np.uint8)
+        try:
+            rc = lib.th_h5_group_links(whole.ctypes.data_as(C.c_void_p), whole.size, f._base, int(btree), int(heap[0]), int(heap[1]),
+                                       names.ctypes.data_as(C.c_void_p), names.size, addrs.ctypes.data_as(C.POINTER(C.c_int64)), addrs.size,
+                                       C.byref(n), C.byref(used))
+        finally:
+            del whole
+        if rc != 0:
+            return False
+        if n.value:
+            try:
+                keys = names[:used.value - 1].tobytes().decode().split("\0")
+            except UnicodeDecodeError:
+                return False
+            if len(keys) != n.value:
+                return False
+            links.update(zip(keys, addrs[:n.value].tolist()))
+        return True
 
     def _local_heap(self, addr: int) -> Tuple[int, int]:
         m = self._f._m
@@ -773,7 +807,14 @@ def resolve_many(f: File, addrs, num_attr: Optional[str] = None, num_len: int = 
         return None
     strs = None
     if sbuf is not None:
-        strs = [bytes(row).split(b"\0", 1)[0].rstrip(b" ").decode("utf-8", "replace") for row in sbuf]
+        # fixed-width rows -> str: "S<n>" drops the trailing NULs; a NUL inside a row ends the string as the C side wrote it
+        if str_len > 1 and not np.any((sbuf[:, :-1] == 0) & (sbuf[:, 1:] != 0)):
+            try:
+                strs = np.char.rstrip(sbuf.view(f"S{str_len}").ravel(), b" ").astype(str).tolist()
+            except UnicodeDecodeError:
+                strs = None
+        if strs is None:
+            strs = [bytes(row).split(b"\0", 1)[0].rstrip(b" ").decode("utf-8", "replace") for row in sbuf]
     return dict(status=status, btree=btree, geom=geom, num=num, strs=strs)
 
 

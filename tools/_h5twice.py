@@ -1,0 +1,24 @@
+import os, sys, time, subprocess, tempfile, warnings
+from pathlib import Path
+ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "timed-design_amd"))
+import predict
+from timed_hip import pack, synth
+cfg, w = synth.timed_synth(20)
+td = tempfile.mkdtemp()
+mp = Path(td) / "TIMED.pack"; mp.write_bytes(pack.keras_to_pack(cfg, w))
+h5 = os.path.join(td, "frames.hdf5")
+subprocess.run(["/opt/conda/bin/python3.9", os.path.join(ROOT, "tools", "make_synthetic_hdf5.py"), h5, "400", "100"], check=True, capture_output=True)
+for k in range(3):
+    out = Path(td) / f"out{k}"; out.mkdir()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        import cProfile, pstats
+        pr = cProfile.Profile()
+        t0 = time.perf_counter()
+        if k == 2: pr.enable()
+        predict.load_dataset_and_predict([mp], h5, batch_size=500, dataset_map_path=out / "datasetmap.txt", path_to_output=out)
+        if k == 2: pr.disable()
+        dt = time.perf_counter() - t0
+        if k == 2: pstats.Stats(pr).sort_stats("cumulative").print_stats(35)
+    print(f"run {k}: {dt:.3f} s  {40000/dt:.0f} fps", flush=True)
