@@ -380,6 +380,8 @@ extern "C" int th_h5_decode_device(const void* file, int64_t file_len, int64_t b
                 (long long)n_datasets, nch, span_len / 1e6, gathered.empty() ? "direct" : "gathered", t_walk, t_prep - t_walk, since() - t_prep);
     if (rc) return rc;
     if (bad) TH_FAIL(TH_EIO, "th_h5_decode_device: %lld of %zu chunks did not inflate", (long long)bad, nch);
+    parts.clear(); parts.shrink_to_fit();
+    if (trace) fprintf(stderr, "[h5 decode] returning after %.2f ms\n", since());
     return TH_OK;
 }
 

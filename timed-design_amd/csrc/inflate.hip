@@ -27,7 +27,10 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <chrono>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -369,17 +372,35 @@ __global__ void __launch_bounds__(kLanes) k_inflate_tokens(const unsigned char* 
     status[idx] = st;
 }
 
+// k_lz_resolve's workgroup IS one wavefront: the LDS executes a wavefront's operations in issue order, so what one lane wrote
+// is visible to the next read of any lane — all that is needed is that the compiler keeps the order.  (__syncthreads() would
+// also wait for every global load and store in flight: the prefetched tokens, the flushed words.)
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// inclusive prefix sum over the 64 lanes on the DPP network (row shifts inside each row of 16, then the two row broadcasts):
+// six VALU operations instead of six trips through the LDS crossbar
+__device__ __forceinline__ int wave_scan_incl(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);     // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);     // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);     // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);     // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);     // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);     // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 // ---- pass 2: tokens -> bytes, one wavefront per stream, the window of the output in LDS ---------------------------------------
-// ring: R bytes (a power of two >= min(stream length, 64 KB)); byte i of the output lives at ring[i & (R - 1)] until it has
-// been flushed and the ring has come round.  Per batch of 64 tokens: lane l owns token l; an inclusive wave scan of the token
-// lengths gives every token its output position; literals are written at once; matches are then resolved one after the other
-// (a match may copy what an earlier match of the same batch produced), each by all 64 lanes: lane k copies byte k, k + 64, ...
-// For distances >= 64 the source of a 64-byte step is always older than the step; for shorter distances the source index is
-// folded back into the `distance` bytes in front of the match (k mod distance), which are complete.  Bytes older than 32 KB
-// (the DEFLATE window) are flushed to HBM in 8-byte words whenever a batch begins, so at most 32 KB + 7 + 64 * 258 bytes are
-// live: 64 KB of ring suffice for a stream of any length.
+// window: byte i of the output lives at ring[i & M].  A stream of up to 60 KB is kept whole (M = ~0, the LDS allocation is the
+// stream length); a longer one goes round a 64 KB ring (M = 65535): bytes older than the 32 KB DEFLATE window are flushed to HBM in
+// 8-byte words whenever a batch begins, so at most 32 KB + 7 + 64 * 258 bytes are live.  Per batch of 64 tokens: lane l owns token
+// l; an inclusive wave scan of the token lengths gives every token its output position; literals are written at once; matches are
+// then resolved one after the other (a match may copy what an earlier match of the same batch produced), each in one step by all
+// 64 lanes.
 __global__ void __launch_bounds__(kLanes) k_lz_resolve(const unsigned* tokens, const long long* ntok, const InfDesc* desc, long long n,
-                                                       unsigned char* out, int* status, unsigned R) {
+                                                       unsigned char* out, int* status, unsigned M) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ring[];
     const long long idx = blockIdx.x;
     if (idx >= n || status[idx] != INF_OK) return;
@@ -388,67 +409,72 @@ __global__ void __launch_bounds__(kLanes) k_lz_resolve(const unsigned* tokens, c
     const unsigned* tok = tokens + d.tok_off;
     const long long nt = ntok[idx];
     unsigned char* dst = out + d.dst_off;
-    const unsigned M = R - 1;
     long long o = 0, flushed = 0;
     auto flush_to = [&](long long upto) {     // [flushed, upto), both multiples of 8
         for (long long i = flushed + 8ll * lane; i < upto; i += 8ll * kLanes)
             *reinterpret_cast<unsigned long long*>(dst + i) = *reinterpret_cast<const unsigned long long*>(ring + ((unsigned)i & M));
         flushed = upto;
     };
+    if (nt <= 0) return;      // (an empty stream has no bytes either)
+    unsigned tk_next = tok[min((long long)lane, nt - 1)];
     for (long long t0 = 0; t0 < nt; t0 += kLanes) {
         const bool valid = t0 + lane < nt;
-        const unsigned tk = valid ? tok[t0 + lane] : 0u;
+        const unsigned tk = tk_next;
         const bool is_m = valid && (tk >> 31);
         const int len = is_m ? (int)((tk >> 16) & 0x1ff) : (valid ? 1 : 0);
-        int incl = len;
-#pragma unroll
-        for (int s = 1; s < kLanes; s <<= 1) {
-            const int v = __shfl_up(incl, s);
-            if (lane >= s) incl += v;
-        }
-        const int total = __shfl(incl, kLanes - 1);
+        const int incl = wave_scan_incl(len);
+        const int total = __builtin_amdgcn_readlane(incl, kLanes - 1);
         const long long pos = o + incl - len;
         // make room: everything older than the 32 KB window goes out
         if (o - flushed > 32768 + 8) {
-            __syncthreads();
+            wave_sync();
             flush_to((o - 32768) & ~7ll);
-            __syncthreads();
+            wave_sync();
         }
+        // the next batch's tokens: in flight while this batch is resolved (issued after the flush's stores, so that waiting
+        // for it at the top of the loop waits for nothing else)
+        tk_next = tok[min(t0 + kLanes + lane, nt - 1)];
         if (valid && !is_m) ring[(unsigned)pos & M] = (unsigned char)(tk & 0xff);
-        __syncthreads();
+        wave_sync();
+        // matches, one after the other (a match may copy what an earlier one of the batch produced), each in ONE step by the
+        // whole wavefront: byte k of a match is byte (k mod distance) of the `distance` bytes in front of it, which are final —
+        // so all (at most 258) bytes are independent; lane l takes bytes l, l + 64, ... : every read is issued before any write
         unsigned long long mm = __ballot(is_m);
         while (mm) {
             const int l = __ffsll((long long)mm) - 1;
             mm &= mm - 1;
-            const int mlen = __shfl(len, l);
-            const int mdist = (int)(__shfl((int)tk, l) & 0x7fff) + 1;
-            const long long mpos = __shfl((int)(pos - o), l) + o;
-            if (mdist >= kLanes) {
-                for (int k0 = 0; k0 < mlen; k0 += kLanes) {
-                    const int k = k0 + lane;
-                    if (k < mlen) ring[(unsigned)(mpos + k) & M] = ring[(unsigned)(mpos - mdist + k) & M];
-                    __syncthreads();
-                }
-            } else {
-                // every byte comes from the mdist bytes in front of the match: all 64-byte steps are independent
-                const float inv = 1.0f / (float)mdist;
-                for (int k0 = 0; k0 < mlen; k0 += kLanes) {
-                    const int k = k0 + lane;
-                    int q = (int)((float)k * inv);
-                    int r = k - q * mdist;
+            const int mlen = __builtin_amdgcn_readlane(len, l);
+            const int mdist = (__builtin_amdgcn_readlane((int)tk, l) & 0x7fff) + 1;
+            const unsigned to = (unsigned)(__builtin_amdgcn_readlane((int)(pos - o), l) + o);
+            const unsigned from = to - (unsigned)mdist;
+            // (k mod mdist by a float reciprocal + one correction step: exact for k < 320, mdist <= 32768; the reads of lanes
+            // beyond the match fetch some byte of the ring and are dropped — no branch between the reads, so they overlap)
+            const float inv = 1.0f / (float)mdist;
+            auto copy = [&](auto nb) {
+                constexpr int NB = decltype(nb)::value;
+                unsigned char v[NB];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const int k = lane + kLanes * j;
+                    int r = k - (int)((float)k * inv) * mdist;
                     if (r < 0) r += mdist;
                     if (r >= mdist) r -= mdist;
-                    unsigned char v = 0;
-                    if (k < mlen) v = ring[(unsigned)(mpos - mdist + r) & M];
-                    __syncthreads();        // (all sources read before any byte of this step is written: a step may overwrite ...
-                    if (k < mlen) ring[(unsigned)(mpos + k) & M] = v;   // ... nothing it reads, but keep the order explicit)
+                    v[j] = ring[(from + (unsigned)r) & M];
                 }
-                __syncthreads();
-            }
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const int k = lane + kLanes * j;
+                    if (k < mlen) ring[(to + (unsigned)k) & M] = v[j];
+                }
+            };
+            if (mlen <= kLanes) copy(std::integral_constant<int, 1>{});
+            else if (mlen <= 2 * kLanes) copy(std::integral_constant<int, 2>{});
+            else copy(std::integral_constant<int, 5>{});
+            wave_sync();
         }
         o += total;
     }
-    __syncthreads();
+    wave_sync();
     const long long whole = o & ~7ll;
     flush_to(whole);
     if (lane < (int)(o - whole)) dst[whole + lane] = ring[(unsigned)(whole + lane) & M];
@@ -512,7 +538,13 @@ inline void launch_tokens(hipStream_t stream, const unsigned char* comp, long lo
 }
 
 // LDS window of k_lz_resolve for streams of at most max_len bytes
-inline unsigned ring_bytes(int64_t max_len) { return max_len <= 16384 ? 16384u : (max_len <= 32768 ? 32768u : 65536u); }
+// (a stream that fits is kept whole — its LDS is its length and positions are used as they are, mask ~0 —, so 17 KB chunks
+// run 9 wavefronts per CU instead of the 5 a 32 KB power-of-two ring allows; longer streams go round a 64 KB ring)
+struct RingGeom { unsigned lds, mask; };
+inline RingGeom ring_geom(int64_t max_len) {
+    if (max_len <= 61440) return {(unsigned)((std::max<int64_t>(max_len, 16) + 15) & ~15ll), 0xffffffffu};
+    return {65536u, 65535u};
+}
 
 struct DevBuf {
     void* p = nullptr; size_t cap = 0;
@@ -572,9 +604,9 @@ extern "C" int th_inflate_many(int device, const void* comp, int64_t comp_len, i
         if ((e = hipGetLastError()) != hipSuccess) fail(e, "launch");
     }
     if (!rc) {
-        const unsigned R = ring_bytes(max_len);
+        const RingGeom rg = ring_geom(max_len);
         if ((e = hipFuncSetAttribute((const void*)k_lz_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)) != hipSuccess) fail(e, "attribute");
-        hipLaunchKernelGGL(k_lz_resolve, dim3((unsigned)n), dim3(kLanes), R, 0, d_tok, d_nt, d_desc, (long long)n, d_out, d_st, R);
+        hipLaunchKernelGGL(k_lz_resolve, dim3((unsigned)n), dim3(kLanes), rg.lds, 0, d_tok, d_nt, d_desc, (long long)n, d_out, d_st, rg.mask);
         if (!rc && (e = hipGetLastError()) != hipSuccess) fail(e, "launch");
     }
     if (!rc && (e = hipDeviceSynchronize()) != hipSuccess) fail(e, "kernel");
@@ -614,9 +646,13 @@ int inflate_place_device(int device, hipStream_t stream, const void* span, int64
         (rc = d_ds.ensure((size_t)n_chunks * sizeof(int))) || (rc = d_coff.ensure((size_t)n_chunks * 8 * sizeof(int))) ||
         (rc = d_tok.ensure((size_t)(n_chunks * chunk_bytes + 16) * sizeof(unsigned))) || (rc = d_nt.ensure((size_t)n_chunks * sizeof(long long))))
         return rc;
+    static const bool trace = getenv("TH_H5_TRACE") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
     std::vector<InfDesc> desc((size_t)n_chunks);
     for (int64_t i = 0; i < n_chunks; ++i) desc[(size_t)i] = {src_off[i], csize[i], i * cb8, chunk_bytes, i * chunk_bytes};
     HIP_TRY(hipMemcpyAsync(d_comp.p, span, (size_t)span_len, hipMemcpyHostToDevice, stream));
+    const double t_span = since();
     HIP_TRY(hipMemcpyAsync(d_desc.p, desc.data(), (size_t)n_chunks * sizeof(InfDesc), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(d_ds.p, ds, (size_t)n_chunks * sizeof(int), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(d_coff.p, coff8, (size_t)n_chunks * 8 * sizeof(int), hipMemcpyHostToDevice, stream));
@@ -624,10 +660,10 @@ int inflate_place_device(int device, hipStream_t stream, const void* span, int64
                   (long long*)d_nt.p, (int*)d_st.p, 1);
     HIP_TRY(hipGetLastError());
     {
-        const unsigned R = ring_bytes(chunk_bytes);
+        const RingGeom rg = ring_geom(chunk_bytes);
         HIP_TRY(hipFuncSetAttribute((const void*)k_lz_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-        hipLaunchKernelGGL(k_lz_resolve, dim3((unsigned)n_chunks), dim3(kLanes), R, stream, (const unsigned*)d_tok.p, (const long long*)d_nt.p,
-                           (const InfDesc*)d_desc.p, (long long)n_chunks, (unsigned char*)d_raw.p, (int*)d_st.p, R);
+        hipLaunchKernelGGL(k_lz_resolve, dim3((unsigned)n_chunks), dim3(kLanes), rg.lds, stream, (const unsigned*)d_tok.p, (const long long*)d_nt.p,
+                           (const InfDesc*)d_desc.p, (long long)n_chunks, (unsigned char*)d_raw.p, (int*)d_st.p, rg.mask);
         HIP_TRY(hipGetLastError());
     }
     PlaceArgs a;
@@ -644,7 +680,9 @@ int inflate_place_device(int device, hipStream_t stream, const void* span, int64
         h_st_cap = (size_t)n_chunks * sizeof(int) * 2 + 4096;
     }
     HIP_TRY(hipMemcpyAsync(h_st, d_st.p, (size_t)n_chunks * sizeof(int), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));   // `span` / the descriptor vectors may go away now, and the statuses are needed
+    const double t_enq = since();
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (trace) fprintf(stderr, "[inflate] span upload returned after %.2f ms, launches enqueued after %.2f ms, stream drained after %.2f ms\n", t_span, t_enq, since());   // `span` / the descriptor vectors may go away now, and the statuses are needed
     int64_t bad = 0;
     for (int64_t i = 0; i < n_chunks; ++i)
         if (((const int*)h_st)[i] != 0) ++bad;
