@@ -214,12 +214,14 @@ __device__ __forceinline__ int construct(Lds& L, unsigned short (*cnt)[LPW], uns
 
 // token sink of pass 1: literal = the byte; match = bit 31 | length << 16 | (distance - 1)
 struct Out {
+    int dbg;
     unsigned* tok;
     long long nt;       // tokens written (never more than `o`, hence never more than the `len` slots this stream owns)
     long long o, len;   // bytes the tokens stand for so far / declared output length
 };
 __device__ __forceinline__ void emit(Out& w, unsigned b) {
-    w.tok[w.nt++] = b;
+    if (!(w.dbg & 1)) w.tok[w.nt] = b;
+    ++w.nt;
     ++w.o;
 }
 
@@ -243,36 +245,89 @@ __device__ __forceinline__ int cl_order(int i) {
     return (int)((i < 12 ? A >> (5 * i) : B >> (5 * (i - 12))) & 31);
 }
 
-// literal / length + distance symbols of one compressed block
+// Predicated variants for the symbol loop: no refill inside (the loop refills at two fixed points), bits are consumed only
+// where `on`, an invalid code gives -1 and consumes nothing, the table index is clamped so the LDS read is always in range.
+__device__ __forceinline__ unsigned take_nr(Bits& b, int n) {   // n <= 16, the buffer holds at least n bits
+    const unsigned v = (unsigned)b.buf & ((1u << n) - 1u);
+    b.buf >>= n;
+    b.cnt -= n;
+    b.remaining -= n;
+    return v;
+}
+template <bool WIDE, class Lds, int LPW>
+__device__ __forceinline__ int decode_p(Bits& b, const Code& c, const Lds& L, const unsigned char (*sym)[LPW], int lane, bool on) {
+    const int v = (int)(__brev((unsigned)(b.buf & 0x7fff)) >> 17);
+    int len = 1, base = c.bas[1];
+#pragma unroll
+    for (int l = 1; l < kMaxBits; ++l) {
+        const bool ge = v >= c.lim[l];
+        len += ge ? 1 : 0;
+        base += ge ? c.bas[l + 1] : 0;
+    }
+    const bool bad = v >= c.lim[kMaxBits];          // not a code of this (incomplete) set
+    const int use = (on && !bad) ? len : 0;
+    b.buf >>= use;
+    b.cnt -= use;
+    b.remaining -= use;
+    int idx = (v >> (kMaxBits - len)) + base;
+    idx = min(max(idx, 0), (WIDE ? kFixLCodes : kMaxDCodes) - 1);
+    int s;
+    if (WIDE) s = (int)L.lsym[idx][lane] | (int)(((L.lhi[idx >> 5][lane] >> (idx & 31)) & 1u) << 8);
+    else s = sym[idx][lane];
+    return bad ? -1 : s;
+}
+
+// literal / length + distance symbols of one compressed block.  The 64 lanes decode 64 different streams: a literal here, a
+// match there, an end of block elsewhere.  Written with branches, every one of those cases (and every error exit) is a divergent
+// region the wavefront walks through one after the other — 600 instructions and 48 exec-mask regions per token.  So the body is
+// straight-line and PREDICATED: every lane runs the literal/length decode, the length extra bits (0 bits unless it holds a match),
+// the distance decode and its extra bits (consuming nothing unless it holds a match); what a lane found is sorted out with
+// selects at the end; the only branches are wave-uniform (no lane holds a match: skip the distance half; no lane is running: leave).
 template <class Lds>
 __device__ __forceinline__ int codes(Bits& b, Out& w, Lds& L, const Code& lc, const Code& dc, int lane) {
+    int st = -1;                                  // -1: this lane is still inside the block
     for (;;) {
-        int sym = decode<true>(b, lc, L, L.lsym, lane);
-        if (sym < 0) return b.over ? INF_EINPUT : INF_ECODE;
-        if (sym < 256) {
-            if (w.o >= w.len) return INF_EOUTPUT;
-            emit(w, (unsigned)sym);
-        } else if (sym == 256) {
-            return INF_OK;
-        } else {
-            sym -= 257;
-            if (sym >= 29) return INF_ECODE;
-            int lbase, lextra;
-            len_code(sym, &lbase, &lextra);
-            const int len = lbase + (int)take(b, lextra);
-            const int ds = decode<false>(b, dc, L, L.dsym, lane);
-            if (ds < 0) return b.over ? INF_EINPUT : INF_ECODE;
-            if (ds >= 30) return INF_ECODE;
+        const bool run = st < 0;
+        refill(b);                                // >= 33 bits: a literal/length code (15) and its extra bits (5)
+        const int s = decode_p<true>(b, lc, L, L.lsym, lane, run);
+        bool bad = s < 0;
+        const bool is_m = s > 256, is_l = s >= 0 && s < 256, eob = s == 256;
+        const int ms = s - 257;
+        bad = bad || (is_m && ms >= 29);
+        int lbase, lextra;
+        len_code(min(max(ms, 0), 28), &lbase, &lextra);
+        const bool mrun = run && is_m && !bad;
+        const int len = lbase + (int)take_nr(b, mrun ? lextra : 0);
+        long long dist = 0;
+        if (__any(mrun)) {
+            refill(b);                            // >= 33 bits again: a distance code (15) and its extra bits (13)
+            const int ds = decode_p<false>(b, dc, L, L.dsym, lane, mrun);
+            bad = bad || (mrun && (ds < 0 || ds >= 30));
             int dbase, dextra;
-            dist_code(ds, &dbase, &dextra);
-            const long long dist = dbase + (long long)take(b, dextra);
-            if (b.over) return INF_EINPUT;
-            if (dist > w.o) return INF_EDIST;
-            if (w.o + len > w.len) return INF_EOUTPUT;
-            w.tok[w.nt++] = 0x80000000u | ((unsigned)len << 16) | (unsigned)(dist - 1);
-            w.o += len;
+            dist_code(min(max(ds, 0), 29), &dbase, &dextra);
+            dist = dbase + (long long)take_nr(b, (mrun && !bad) ? dextra : 0);
         }
+        const bool over = b.remaining < 0;        // (zeros or foreign bits were decoded: whatever came out does not count)
+        const int n = is_m ? len : 1;
+        int now = -1;
+        if (bad) now = over ? INF_EINPUT : INF_ECODE;
+        else if (over) now = INF_EINPUT;
+        else if (eob) now = INF_OK;
+        else if (is_m && dist > w.o) now = INF_EDIST;
+        else if (w.o + n > w.len) now = INF_EOUTPUT;
+        if (run) {
+            st = now;
+            if (now < 0) {
+                const unsigned tk = is_l ? (unsigned)s : (0x80000000u | ((unsigned)len << 16) | (unsigned)(dist - 1));
+                if (!(w.dbg & 1)) w.tok[w.nt] = tk;
+                ++w.nt;
+                w.o += n;
+            }
+        }
+        if (!__any(st < 0)) break;
     }
+    if (st == INF_EINPUT) b.over = true;
+    return st;
 }
 
 template <int LPW>
@@ -287,6 +342,7 @@ __global__ void __launch_bounds__(kLanes) k_inflate_tokens(const unsigned char* 
     Bits b;
     bits_init(b, comp + d.src_off, d.src_len, comp + comp_len);
     Out w;
+    w.dbg = zlib_wrapped >> 8; zlib_wrapped &= 0xff;
     w.tok = tokens + d.tok_off; w.nt = 0; w.o = 0; w.len = d.dst_len;
     Code lc, dc;                   // the current block's two Huffman codes (limits / bases per length, in registers)
     int st = INF_OK;
@@ -529,6 +585,7 @@ inline void launch_tokens(hipStream_t stream, const unsigned char* comp, long lo
     // 131 k streams 10.0 / 11.3 / 16.1 ms at LPW 64 / 16 / 8 — a wavefront costs the same instruction slots with 8 active lanes
     // as with 64, and the lanes in flight are bounded by LDS (580 B per stream) either way.  Few streams: spread them over CUs.
     const int lpw = forced ? forced : (n >= 16384 ? 64 : (n >= 2048 ? 16 : 8));
+    if (getenv("TH_INF_DBG")) wrapped |= atoi(getenv("TH_INF_DBG")) << 8;
     if (lpw == 8)
         hipLaunchKernelGGL(k_inflate_tokens<8>, dim3((unsigned)((n + 7) / 8)), dim3(kLanes), 0, stream, comp, comp_len, desc, n, tok, ntok, st, wrapped);
     else if (lpw == 16)
