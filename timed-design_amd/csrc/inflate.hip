@@ -277,6 +277,31 @@ __device__ __forceinline__ int decode_p(Bits& b, const Code& c, const Lds& L, co
     return bad ? -1 : s;
 }
 
+// Input queue of the symbol loop.  Global loads and stores retire in order behind ONE counter (vmcnt): with block switches
+// wherever a lane happens to run dry, some lane of the 64 switches in almost every iteration, and its wait for the block it
+// asked for 12 tokens ago is a wait for the load another lane issued a moment ago — a full memory latency per token (46 % of the
+// wave cycles).  So all memory traffic of the loop happens at wave-synchronous points, every second iteration: the blocks asked
+// for two iterations ago have arrived (nothing younger is in flight), the queue advances, the next block is requested and the
+// (at most two) tokens of the last two iterations are stored.  Two iterations consume at most 4 words (2 refills of 32 bits
+// each): `cur` + `nxt` (8 words, of which at most 3 were used up before) always cover them; `nx2` is the block in flight.
+struct InQ { uint4 cur, nxt, nx2; int widx; };     // widx: next word to take, 0..3 in cur, 4..7 in nxt
+__device__ __forceinline__ uint4 load_block(Bits& b) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (b.blk < b.blk_end) v = *b.blk;
+    ++b.blk;
+    return v;
+}
+__device__ __forceinline__ void refill_q(Bits& b, InQ& q) {     // branch-free: a word is taken where the buffer is at most half full
+    const bool need = b.cnt <= 32;
+    const bool hi = q.widx >= 4;
+    const unsigned x = hi ? q.nxt.x : q.cur.x, y = hi ? q.nxt.y : q.cur.y, z = hi ? q.nxt.z : q.cur.z, t = hi ? q.nxt.w : q.cur.w;
+    const int k = q.widx & 3;
+    const unsigned wd = k == 0 ? x : (k == 1 ? y : (k == 2 ? z : t));
+    b.buf |= need ? ((unsigned long long)wd << b.cnt) : 0ull;
+    b.cnt += need ? 32 : 0;
+    q.widx += need ? 1 : 0;
+}
+
 // literal / length + distance symbols of one compressed block.  The 64 lanes decode 64 different streams: a literal here, a
 // match there, an end of block elsewhere.  Written with branches, every one of those cases (and every error exit) is a divergent
 // region the wavefront walks through one after the other — 600 instructions and 48 exec-mask regions per token.  So the body is
@@ -285,10 +310,28 @@ __device__ __forceinline__ int decode_p(Bits& b, const Code& c, const Lds& L, co
 // selects at the end; the only branches are wave-uniform (no lane holds a match: skip the distance half; no lane is running: leave).
 template <class Lds>
 __device__ __forceinline__ int codes(Bits& b, Out& w, Lds& L, const Code& lc, const Code& dc, int lane) {
+    InQ q;
+    q.cur = b.cur; q.nxt = b.nxt; q.widx = b.widx;
+    q.nx2 = load_block(b);
+    unsigned t0 = 0, t1 = 0;
+    int held = 0;                                 // tokens of this lane waiting for the next synchronous point
     int st = -1;                                  // -1: this lane is still inside the block
-    for (;;) {
+    for (int it = 0;; ++it) {
+        if ((it & 1) == 0) {                      // ---- the synchronous point (wave-uniform) ----
+            const bool adv = q.widx >= 4;
+            if (adv) {
+                q.cur = q.nxt; q.nxt = q.nx2; q.widx -= 4;
+                q.nx2 = load_block(b);
+            }
+            if (!(w.dbg & 1)) {
+                if (held >= 1) w.tok[w.nt] = t0;
+                if (held == 2) w.tok[w.nt + 1] = t1;
+            }
+            w.nt += held;
+            held = 0;
+        }
         const bool run = st < 0;
-        refill(b);                                // >= 33 bits: a literal/length code (15) and its extra bits (5)
+        refill_q(b, q);                           // >= 33 bits: a literal/length code (15) and its extra bits (5)
         const int s = decode_p<true>(b, lc, L, L.lsym, lane, run);
         bool bad = s < 0;
         const bool is_m = s > 256, is_l = s >= 0 && s < 256, eob = s == 256;
@@ -300,7 +343,7 @@ __device__ __forceinline__ int codes(Bits& b, Out& w, Lds& L, const Code& lc, co
         const int len = lbase + (int)take_nr(b, mrun ? lextra : 0);
         long long dist = 0;
         if (__any(mrun)) {
-            refill(b);                            // >= 33 bits again: a distance code (15) and its extra bits (13)
+            refill_q(b, q);                       // >= 33 bits again: a distance code (15) and its extra bits (13)
             const int ds = decode_p<false>(b, dc, L, L.dsym, lane, mrun);
             bad = bad || (mrun && (ds < 0 || ds >= 30));
             int dbase, dextra;
@@ -315,17 +358,23 @@ __device__ __forceinline__ int codes(Bits& b, Out& w, Lds& L, const Code& lc, co
         else if (eob) now = INF_OK;
         else if (is_m && dist > w.o) now = INF_EDIST;
         else if (w.o + n > w.len) now = INF_EOUTPUT;
-        if (run) {
-            st = now;
-            if (now < 0) {
-                const unsigned tk = is_l ? (unsigned)s : (0x80000000u | ((unsigned)len << 16) | (unsigned)(dist - 1));
-                if (!(w.dbg & 1)) w.tok[w.nt] = tk;
-                ++w.nt;
-                w.o += n;
-            }
-        }
+        const bool emit = run && now < 0;
+        const unsigned tk = is_l ? (unsigned)s : (0x80000000u | ((unsigned)len << 16) | (unsigned)(dist - 1));
+        t0 = (emit && held == 0) ? tk : t0;
+        t1 = (emit && held == 1) ? tk : t1;
+        held += emit ? 1 : 0;
+        w.o += emit ? n : 0;
+        st = run ? now : st;
         if (!__any(st < 0)) break;
     }
+    if (!(w.dbg & 1)) {
+        if (held >= 1) w.tok[w.nt] = t0;
+        if (held == 2) w.tok[w.nt + 1] = t1;
+    }
+    w.nt += held;
+    // back to the block-at-a-time reader of the headers: it holds `cur`, `nxt` and the address of the block after them
+    if (q.widx >= 4) { b.cur = q.nxt; b.nxt = q.nx2; b.widx = q.widx - 4; }
+    else { b.cur = q.cur; b.nxt = q.nxt; b.widx = q.widx; --b.blk; }
     if (st == INF_EINPUT) b.over = true;
     return st;
 }
