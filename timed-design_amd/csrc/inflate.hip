@@ -72,6 +72,7 @@ template <class Lds> __device__ __forceinline__ void set_len(Lds& L, int i, int 
 struct Bits {
     const uint4* blk;       // next aligned 16-byte block
     const uint4* blk_end;   // one past the last block that may be read
+    const uint4* blk_first; // the block the stream begins in
     uint4 cur;              // the block being consumed
     uint4 nxt;              // the block after it, requested when `cur` was taken: a load issued only when its data is needed
                             // would have to wait — behind every token store the wavefront has queued before it — on each refill
@@ -82,10 +83,19 @@ struct Bits {
     bool over;
 };
 
+// A block load must be a GLOBAL load: through a generic pointer it is a flat load, which also counts in lgkmcnt — every wait
+// for an LDS table read then waits for the block in flight as well.  (HIP's uint4 is a class: its copy goes through a generic
+// reference, so the block is loaded as a native vector through an address-space-1 pointer.)
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) v4u* GlobalBlockPtr;
+__device__ __forceinline__ uint4 load_global_block(const uint4* p) {
+    const v4u v = *(GlobalBlockPtr)(unsigned long long)p;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ unsigned next_word(Bits& b) {
     if (b.widx == 4) {
         b.cur = b.nxt;
-        if (b.blk < b.blk_end) b.nxt = *b.blk;
+        if (b.blk < b.blk_end) b.nxt = load_global_block(b.blk);
         else b.nxt = make_uint4(0, 0, 0, 0);
         ++b.blk;
         b.widx = 0;
@@ -103,13 +113,14 @@ __device__ __forceinline__ void refill(Bits& b) {
 __device__ __forceinline__ void bits_init(Bits& b, const unsigned char* p, long long len, const unsigned char* buf_end) {
     const unsigned long long a = (unsigned long long)p;
     b.blk = reinterpret_cast<const uint4*>(a & ~15ull);
+    b.blk_first = b.blk;
     b.blk_end = reinterpret_cast<const uint4*>(((unsigned long long)buf_end + 15ull) & ~15ull);
     const uint4* own_end = reinterpret_cast<const uint4*>(((unsigned long long)(p + len) + 15ull) & ~15ull);
     if (own_end < b.blk_end) b.blk_end = own_end;       // never read past the stream's last block (nor past the buffer)
     b.widx = 4; b.buf = 0; b.cnt = 0; b.over = false;
     b.remaining = 8 * len;
     b.cur = make_uint4(0, 0, 0, 0);
-    if (b.blk < b.blk_end) b.nxt = *b.blk;            // prime the pipeline: the first block
+    if (b.blk < b.blk_end) b.nxt = load_global_block(b.blk);            // prime the pipeline: the first block
     else b.nxt = make_uint4(0, 0, 0, 0);
     ++b.blk;
     const int skip = (int)(a & 15);
@@ -285,12 +296,10 @@ __device__ __forceinline__ int decode_p(Bits& b, const Code& c, const Lds& L, co
 // (at most two) tokens of the last two iterations are stored.  Two iterations consume at most 4 words (2 refills of 32 bits
 // each): `cur` + `nxt` (8 words, of which at most 3 were used up before) always cover them; `nx2` is the block in flight.
 struct InQ { uint4 cur, nxt, nx2; int widx; };     // widx: next word to take, 0..3 in cur, 4..7 in nxt
-__device__ __forceinline__ uint4 load_block(Bits& b) {
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (b.blk < b.blk_end) v = *b.blk;
-    ++b.blk;
-    return v;
-}
+// (no branch around the load and no zero for "past the end": a select or a merge after the load makes the compiler wait for the
+// data on the spot.  Past its last block a stream re-reads that block; whatever is decoded from it is discarded, because
+// `remaining` has gone negative by then.  blk_last >= the first block of the stream, which lies inside the buffer.)
+__device__ __forceinline__ const uint4* clamp_block(const Bits& b, const uint4* last) { return b.blk < b.blk_end ? b.blk : last; }
 __device__ __forceinline__ void refill_q(Bits& b, InQ& q) {     // branch-free: a word is taken where the buffer is at most half full
     const bool need = b.cnt <= 32;
     const bool hi = q.widx >= 4;
@@ -312,7 +321,9 @@ template <class Lds>
 __device__ __forceinline__ int codes(Bits& b, Out& w, Lds& L, const Code& lc, const Code& dc, int lane) {
     InQ q;
     q.cur = b.cur; q.nxt = b.nxt; q.widx = b.widx;
-    q.nx2 = load_block(b);
+    const uint4* last = b.blk_end - 1 > b.blk_first ? b.blk_end - 1 : b.blk_first;
+    q.nx2 = load_global_block(clamp_block(b, last));
+    ++b.blk;
     unsigned t0 = 0, t1 = 0;
     int held = 0;                                 // tokens of this lane waiting for the next synchronous point
     int st = -1;                                  // -1: this lane is still inside the block
@@ -321,7 +332,8 @@ __device__ __forceinline__ int codes(Bits& b, Out& w, Lds& L, const Code& lc, co
             const bool adv = q.widx >= 4;
             if (adv) {
                 q.cur = q.nxt; q.nxt = q.nx2; q.widx -= 4;
-                q.nx2 = load_block(b);
+                q.nx2 = load_global_block(clamp_block(b, last));
+                ++b.blk;
             }
             if (!(w.dbg & 1)) {
                 if (held >= 1) w.tok[w.nt] = t0;
