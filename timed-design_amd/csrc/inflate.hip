@@ -489,6 +489,16 @@ __global__ void __launch_bounds__(kLanes) k_inflate_tokens(const unsigned char* 
     status[idx] = st;
 }
 
+// chunk -> frame placement: chunk `c` (chunk_bytes of raw data, C order over cdim[rank]) covers the box starting at
+// coff[c][rank] of dataset ds[c]; elements inside the dataset's shape go to out[ds][...] (C order), float64 -> float32 when
+// conv == 1.  One workgroup per chunk.
+struct PlaceArgs {
+    const unsigned char* raw; long long chunk_bytes;
+    const int* ds; const int* coff;     // [n_chunks], [n_chunks][8]
+    int rank; int shape[8]; int cdim[8]; int esz; int conv;
+    unsigned char* out; long long out_elems;   // elements per dataset in the output
+    unsigned celems;                           // elements per chunk
+};
 // k_lz_resolve's workgroup IS one wavefront: the LDS executes a wavefront's operations in issue order, so what one lane wrote
 // is visible to the next read of any lane — all that is needed is that the compiler keeps the order.  (__syncthreads() would
 // also wait for every global load and store in flight: the prefetched tokens, the flushed words.)
@@ -517,7 +527,7 @@ __device__ __forceinline__ int wave_scan_incl(int v) {
 // then resolved one after the other (a match may copy what an earlier match of the same batch produced), each in one step by all
 // 64 lanes.
 __global__ void __launch_bounds__(kLanes) k_lz_resolve(const unsigned* tokens, const long long* ntok, const InfDesc* desc, long long n,
-                                                       unsigned char* out, int* status, unsigned M) {
+                                                       unsigned char* out, int* status, unsigned M, const PlaceArgs pa, int fused) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ring[];
     const long long idx = blockIdx.x;
     if (idx >= n || status[idx] != INF_OK) return;
@@ -592,20 +602,68 @@ __global__ void __launch_bounds__(kLanes) k_lz_resolve(const unsigned* tokens, c
         o += total;
     }
     wave_sync();
+    if (fused) {
+        // the whole chunk sits in LDS (M = ~0): place it straight into its frame — float64 -> float32 on the way when asked —
+        // instead of writing the raw bytes out for k_place_chunks to read back
+        const int out_esz = pa.conv == 1 ? 4 : pa.esz;
+        unsigned char* dd = pa.out + (long long)pa.ds[idx] * pa.out_elems * out_esz;
+        const int* co = pa.coff + idx * 8;
+        // element e of the chunk -> its coordinates (last dimension fastest).  Lane l takes e = l, l + 64, ...: the coordinates are
+        // worked out once by division and then advanced by the mixed-radix digits of 64 with carries — no division per element.
+        auto place = [&](auto rank_c) {
+            constexpr int R = decltype(rank_c)::value;
+            int cd[R], sh[R], c0[R], dg[R], ix[R];
+            long long stride[R];
+            unsigned step = kLanes, mine = (unsigned)lane;
+            long long mul = 1;
+#pragma unroll
+            for (int dm = R - 1; dm >= 0; --dm) {
+                cd[dm] = pa.cdim[dm]; sh[dm] = pa.shape[dm]; c0[dm] = co[dm];
+                dg[dm] = (int)(step % (unsigned)cd[dm]); step /= (unsigned)cd[dm];
+                ix[dm] = (int)(mine % (unsigned)cd[dm]); mine /= (unsigned)cd[dm];
+                stride[dm] = mul; mul *= sh[dm];
+            }
+            for (unsigned e = lane; e < pa.celems; e += kLanes) {
+                bool inside = true;
+                long long oidx = 0;
+#pragma unroll
+                for (int dm = 0; dm < R; ++dm) {
+                    const int g = c0[dm] + ix[dm];
+                    inside = inside && g < sh[dm];
+                    oidx += (long long)g * stride[dm];
+                }
+                if (inside) {
+                    if (pa.conv == 1) {
+                        reinterpret_cast<float*>(dd)[oidx] = (float)*reinterpret_cast<const double*>(ring + 8ull * e);
+                    } else {
+                        for (int k = 0; k < pa.esz; ++k) dd[oidx * pa.esz + k] = ring[(unsigned long long)e * pa.esz + k];
+                    }
+                }
+                int carry = 0;
+#pragma unroll
+                for (int dm = R - 1; dm >= 0; --dm) {
+                    int v = ix[dm] + dg[dm] + carry;
+                    carry = v >= cd[dm] ? 1 : 0;
+                    ix[dm] = v - (carry ? cd[dm] : 0);
+                }
+            }
+        };
+        switch (pa.rank) {
+            case 1: place(std::integral_constant<int, 1>{}); break;
+            case 2: place(std::integral_constant<int, 2>{}); break;
+            case 3: place(std::integral_constant<int, 3>{}); break;
+            case 4: place(std::integral_constant<int, 4>{}); break;
+            case 5: place(std::integral_constant<int, 5>{}); break;
+            case 6: place(std::integral_constant<int, 6>{}); break;
+            default: place(std::integral_constant<int, 7>{}); break;
+        }
+        return;
+    }
     const long long whole = o & ~7ll;
     flush_to(whole);
     if (lane < (int)(o - whole)) dst[whole + lane] = ring[(unsigned)(whole + lane) & M];
 }
 
-// chunk -> frame placement: chunk `c` (chunk_bytes of raw data, C order over cdim[rank]) covers the box starting at
-// coff[c][rank] of dataset ds[c]; elements inside the dataset's shape go to out[ds][...] (C order), float64 -> float32 when
-// conv == 1.  One workgroup per chunk.
-struct PlaceArgs {
-    const unsigned char* raw; long long chunk_bytes;
-    const int* ds; const int* coff;     // [n_chunks], [n_chunks][8]
-    int rank; int shape[8]; int cdim[8]; int esz; int conv;
-    unsigned char* out; long long out_elems;   // elements per dataset in the output
-};
 __global__ void k_place_chunks(const PlaceArgs a, long long n_chunks) {
     const long long c = blockIdx.x;
     if (c >= n_chunks) return;
@@ -724,7 +782,7 @@ extern "C" int th_inflate_many(int device, const void* comp, int64_t comp_len, i
     if (!rc) {
         const RingGeom rg = ring_geom(max_len);
         if ((e = hipFuncSetAttribute((const void*)k_lz_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)) != hipSuccess) fail(e, "attribute");
-        hipLaunchKernelGGL(k_lz_resolve, dim3((unsigned)n), dim3(kLanes), rg.lds, 0, d_tok, d_nt, d_desc, (long long)n, d_out, d_st, rg.mask);
+        hipLaunchKernelGGL(k_lz_resolve, dim3((unsigned)n), dim3(kLanes), rg.lds, 0, d_tok, d_nt, d_desc, (long long)n, d_out, d_st, rg.mask, PlaceArgs{}, 0);
         if (!rc && (e = hipGetLastError()) != hipSuccess) fail(e, "launch");
     }
     if (!rc && (e = hipDeviceSynchronize()) != hipSuccess) fail(e, "kernel");
@@ -759,7 +817,9 @@ int inflate_place_device(int device, hipStream_t stream, const void* span, int64
     for (int d = 0; d < rank; ++d) chunk_bytes *= chunk[d];
     const int64_t cb8 = (chunk_bytes + 7) / 8 * 8;
     int rc;
-    if ((rc = d_comp.ensure((size_t)span_len + 16)) || (rc = d_raw.ensure((size_t)(n_chunks * cb8) + 16)) ||
+    // a chunk that fits the LDS window whole is placed by k_lz_resolve itself: no raw bytes in HBM, no placement kernel
+    const bool fused = ring_geom(chunk_bytes).mask == 0xffffffffu && chunk_bytes / esz < (1ll << 31);
+    if ((rc = d_comp.ensure((size_t)span_len + 16)) || (rc = d_raw.ensure(fused ? 16 : (size_t)(n_chunks * cb8) + 16)) ||
         (rc = d_desc.ensure((size_t)n_chunks * sizeof(InfDesc))) || (rc = d_st.ensure((size_t)n_chunks * sizeof(int))) ||
         (rc = d_ds.ensure((size_t)n_chunks * sizeof(int))) || (rc = d_coff.ensure((size_t)n_chunks * 8 * sizeof(int))) ||
         (rc = d_tok.ensure((size_t)(n_chunks * chunk_bytes + 16) * sizeof(unsigned))) || (rc = d_nt.ensure((size_t)n_chunks * sizeof(long long))))
@@ -777,20 +837,23 @@ int inflate_place_device(int device, hipStream_t stream, const void* span, int64
     launch_tokens(stream, (const unsigned char*)d_comp.p, (long long)span_len, (const InfDesc*)d_desc.p, (long long)n_chunks, (unsigned*)d_tok.p,
                   (long long*)d_nt.p, (int*)d_st.p, 1);
     HIP_TRY(hipGetLastError());
-    {
-        const RingGeom rg = ring_geom(chunk_bytes);
-        HIP_TRY(hipFuncSetAttribute((const void*)k_lz_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-        hipLaunchKernelGGL(k_lz_resolve, dim3((unsigned)n_chunks), dim3(kLanes), rg.lds, stream, (const unsigned*)d_tok.p, (const long long*)d_nt.p,
-                           (const InfDesc*)d_desc.p, (long long)n_chunks, (unsigned char*)d_raw.p, (int*)d_st.p, rg.mask);
-        HIP_TRY(hipGetLastError());
-    }
     PlaceArgs a;
     a.raw = (const unsigned char*)d_raw.p; a.chunk_bytes = cb8; a.ds = (const int*)d_ds.p; a.coff = (const int*)d_coff.p;
     a.rank = rank; a.esz = esz; a.conv = conv; a.out = (unsigned char*)d_out; a.out_elems = 1;
     for (int d = 0; d < 8; ++d) { a.shape[d] = d < rank ? (int)shape[d] : 1; a.cdim[d] = d < rank ? (int)chunk[d] : 1; }
     for (int d = 0; d < rank; ++d) a.out_elems *= shape[d];
-    hipLaunchKernelGGL(k_place_chunks, dim3((unsigned)n_chunks), dim3(256), 0, stream, a, (long long)n_chunks);
-    HIP_TRY(hipGetLastError());
+    a.celems = (unsigned)(chunk_bytes / esz);
+    {
+        const RingGeom rg = ring_geom(chunk_bytes);
+        HIP_TRY(hipFuncSetAttribute((const void*)k_lz_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        hipLaunchKernelGGL(k_lz_resolve, dim3((unsigned)n_chunks), dim3(kLanes), rg.lds, stream, (const unsigned*)d_tok.p, (const long long*)d_nt.p,
+                           (const InfDesc*)d_desc.p, (long long)n_chunks, (unsigned char*)d_raw.p, (int*)d_st.p, rg.mask, a, fused ? 1 : 0);
+        HIP_TRY(hipGetLastError());
+    }
+    if (!fused) {
+        hipLaunchKernelGGL(k_place_chunks, dim3((unsigned)n_chunks), dim3(256), 0, stream, a, (long long)n_chunks);
+        HIP_TRY(hipGetLastError());
+    }
     if (h_st_cap < (size_t)n_chunks * sizeof(int)) {
         if (h_st) (void)hipHostFree(h_st);
         h_st = nullptr; h_st_cap = 0;
