@@ -225,14 +225,12 @@ __device__ __forceinline__ int construct(Lds& L, unsigned short (*cnt)[LPW], uns
 
 // token sink of pass 1: literal = the byte; match = bit 31 | length << 16 | (distance - 1)
 struct Out {
-    int dbg;
     unsigned* tok;
     long long nt;       // tokens written (never more than `o`, hence never more than the `len` slots this stream owns)
     long long o, len;   // bytes the tokens stand for so far / declared output length
 };
 __device__ __forceinline__ void emit(Out& w, unsigned b) {
-    if (!(w.dbg & 1)) w.tok[w.nt] = b;
-    ++w.nt;
+    w.tok[w.nt++] = b;
     ++w.o;
 }
 
@@ -335,10 +333,8 @@ __device__ __forceinline__ int codes(Bits& b, Out& w, Lds& L, const Code& lc, co
                 q.nx2 = load_global_block(clamp_block(b, last));
                 ++b.blk;
             }
-            if (!(w.dbg & 1)) {
-                if (held >= 1) w.tok[w.nt] = t0;
-                if (held == 2) w.tok[w.nt + 1] = t1;
-            }
+            if (held >= 1) w.tok[w.nt] = t0;
+            if (held == 2) w.tok[w.nt + 1] = t1;
             w.nt += held;
             held = 0;
         }
@@ -379,10 +375,8 @@ __device__ __forceinline__ int codes(Bits& b, Out& w, Lds& L, const Code& lc, co
         st = run ? now : st;
         if (!__any(st < 0)) break;
     }
-    if (!(w.dbg & 1)) {
-        if (held >= 1) w.tok[w.nt] = t0;
-        if (held == 2) w.tok[w.nt + 1] = t1;
-    }
+    if (held >= 1) w.tok[w.nt] = t0;
+    if (held == 2) w.tok[w.nt + 1] = t1;
     w.nt += held;
     // back to the block-at-a-time reader of the headers: it holds `cur`, `nxt` and the address of the block after them
     if (q.widx >= 4) { b.cur = q.nxt; b.nxt = q.nx2; b.widx = q.widx - 4; }
@@ -403,7 +397,6 @@ __global__ void __launch_bounds__(kLanes) k_inflate_tokens(const unsigned char* 
     Bits b;
     bits_init(b, comp + d.src_off, d.src_len, comp + comp_len);
     Out w;
-    w.dbg = zlib_wrapped >> 8; zlib_wrapped &= 0xff;
     w.tok = tokens + d.tok_off; w.nt = 0; w.o = 0; w.len = d.dst_len;
     Code lc, dc;                   // the current block's two Huffman codes (limits / bases per length, in registers)
     int st = INF_OK;
@@ -700,11 +693,10 @@ __global__ void k_place_chunks(const PlaceArgs a, long long n_chunks) {
 inline void launch_tokens(hipStream_t stream, const unsigned char* comp, long long comp_len, const InfDesc* desc, long long n, unsigned* tok,
                           long long* ntok, int* st, int wrapped) {
     static const int forced = getenv("TH_INFLATE_LPW") ? atoi(getenv("TH_INFLATE_LPW")) : 0;     // A/B: 8, 16 or 64
-    // measured (gzip float64 frames, ~28 KB chunks): 32 k streams take 5 ms whatever LPW is (the serial chain of one stream);
-    // 131 k streams 10.0 / 11.3 / 16.1 ms at LPW 64 / 16 / 8 — a wavefront costs the same instruction slots with 8 active lanes
-    // as with 64, and the lanes in flight are bounded by LDS (580 B per stream) either way.  Few streams: spread them over CUs.
+    // measured (gzip float64 frames, 17 KB chunks): a wavefront costs the same instruction slots with 8 active lanes as with 64,
+    // and the streams in flight are bounded by LDS (580 B each) either way — 131 k streams ran 10.0 / 11.3 / 16.1 ms at LPW
+    // 64 / 16 / 8 (before the predicated loop; 5.9 ms at 64 now).  Few streams: spread them over the CUs.
     const int lpw = forced ? forced : (n >= 16384 ? 64 : (n >= 2048 ? 16 : 8));
-    if (getenv("TH_INF_DBG")) wrapped |= atoi(getenv("TH_INF_DBG")) << 8;
     if (lpw == 8)
         hipLaunchKernelGGL(k_inflate_tokens<8>, dim3((unsigned)((n + 7) / 8)), dim3(kLanes), 0, stream, comp, comp_len, desc, n, tok, ntok, st, wrapped);
     else if (lpw == 16)
