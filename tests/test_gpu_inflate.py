@@ -181,3 +181,44 @@ def test_predict_py_with_gpu_inflate_writes_the_same_files(gpu, tmp_path, monkey
         assert len(calls) == 4
     for fn in sorted(x.name for x in a.iterdir()):
         assert (a / fn).read_bytes() == (b / fn).read_bytes(), fn
+
+
+def test_multi_chunk_h5py_file_decoded_on_the_gpu_equals_h5py(gpu):
+    """tests/golden/frames_chunked.hdf5 (real h5py: float64, gzip, automatic (6,11,11,3) chunking, 32 chunks per frame with
+    partly-outside edge chunks): every chunk fits the LDS window, so k_lz_resolve places it straight into the frame — against
+    h5py's own read of the file, for the whole map and for a permuted selection"""
+    import os
+    import warnings
+    from design_utils import utils
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    z = np.load(os.path.join(G, "frames_chunked_expected.npz"))
+    path = os.path.join(G, "frames_chunked.hdf5")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fmap = np.array(utils.create_flat_dataset_map(path)[0])
+        got = utils.load_batch_device(path, fmap, device=gpu)
+        assert got is not None, "a deflate-only float64 dataset must take the device path"
+        dev, y = got
+        assert dev.dtype == np.float32 and dev.shape == (5, 21, 21, 21, 6)
+        assert np.array_equal(dev.buffer.download(dev.shape, dev.dtype), z["frames32"])
+        assert np.array_equal(y.argmax(1), [(3 * r) % 20 for r in range(5)])
+        order = [4, 0, 2]
+        d2, _ = utils.load_batch_device(path, fmap[order], device=gpu)
+        assert np.array_equal(d2.buffer.download(d2.shape, d2.dtype), z["frames32"][order])
+
+
+def test_boolean_h5py_fixture_decoded_on_the_gpu(gpu):
+    """the deflate-only residues of tests/golden/frames_tiny_bool.hdf5 (real h5py, 1-byte elements: the non-converting placement)"""
+    import os
+    import warnings
+    from design_utils import utils
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    path = os.path.join(G, "frames_tiny_bool.hdf5")
+    rows = np.array([("1ubq", "A", r, "ALA") for r in ("11", "13", "5", "7")] + [("2xyz_0", "B", r, "ALA") for r in ("11", "5", "7")])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        X, y = utils.load_batch(path, rows)
+        got = utils.load_batch_device(path, rows, device=gpu)
+    assert got is not None
+    dev, yd = got
+    assert np.array_equal(dev.buffer.download(dev.shape, dev.dtype).astype(X.dtype), X) and np.array_equal(yd, y)

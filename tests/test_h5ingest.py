@@ -412,3 +412,23 @@ def test_group_listing_survives_truncated_and_corrupted_files():
         rc = lib.th_h5_group_links(buf.ctypes.data_as(C.c_void_p), buf.size, base, btree, hoff, hsize, names.ctypes.data_as(C.c_void_p),
                                    names.size, addrs.ctypes.data_as(C.POINTER(C.c_int64)), addrs.size, C.byref(n), C.byref(used))
         assert rc != 0
+
+
+def test_multi_chunk_float64_frames_equal_h5py(tmp_path):
+    """tests/golden/frames_chunked.hdf5 is what h5py writes for the reference's real data: (21,21,21,6) float64, gzip, h5py's
+    automatic (6,11,11,3) chunking — 32 chunks per frame, the upper-edge ones only partly inside the dataset.  The map, the
+    labels and load_batch (float64 as stored, and the float32 option) against h5py's own read of the file (the .npz)."""
+    z = np.load(os.path.join(G, "frames_chunked_expected.npz"))
+    path = os.path.join(G, "frames_chunked.hdf5")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fmap, pdbs = utils.create_flat_dataset_map(path)
+        assert [r[2] for r in fmap] == list(z["residues"]) and [r[3] for r in fmap] == list(z["labels"]) and pdbs == {"1abc"}
+        X, y = utils.load_batch(path, fmap)
+        X32, _ = utils.load_batch(path, fmap, dtype=np.float32)
+    assert X.dtype == np.float64 and np.array_equal(X.astype(np.float32), z["frames32"])
+    assert X32.dtype == np.float32 and np.array_equal(X32, z["frames32"])
+    assert y.shape == (5, 20) and np.array_equal(y.argmax(1), [(3 * r) % 20 for r in range(5)])
+    with h5lite.File(path) as f:
+        geo = f["1abc"]["A"]["3"].chunked_geometry()
+    assert geo[2] == (6, 11, 11, 3) and geo[4] == (1,)
