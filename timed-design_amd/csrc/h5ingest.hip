@@ -340,8 +340,14 @@ extern "C" int th_h5_decode_device(const void* file, int64_t file_len, int64_t b
     const double t_walk = since();
     HIP_TRY(hipSetDevice(device));
     const int out_esz = conv == 1 ? 4 : esz;
-    HIP_TRY(hipMemsetAsync(d_out, 0, (size_t)n_datasets * elems * out_esz, nullptr));
-    HIP_TRY(hipStreamSynchronize(nullptr));
+    // chunks that were never written read as zeros; when every chunk of every dataset is there, the placement writes every
+    // element and the 0.9 GB memset of a 4 096-frame batch is skipped
+    int64_t chunks_per_dataset = 1;
+    for (int d = 0; d < rank; ++d) chunks_per_dataset *= (shape[d] + chunk[d] - 1) / chunk[d];
+    if ((int64_t)nch != n_datasets * chunks_per_dataset) {
+        HIP_TRY(hipMemsetAsync(d_out, 0, (size_t)n_datasets * elems * out_esz, nullptr));
+        HIP_TRY(hipStreamSynchronize(nullptr));
+    }
     if (nch == 0) return TH_OK;
     std::vector<int64_t> src_off(nch), csize(nch);
     std::vector<int> ds(nch), coff(nch * 8);

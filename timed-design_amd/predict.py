@@ -30,6 +30,7 @@ predict.py:123 — the UI and scripts expect the real name); the consensus files
 import argparse
 import os
 import sys
+import threading
 from collections import deque
 from concurrent.futures import ThreadPoolExecutor
 from math import ceil
@@ -197,6 +198,8 @@ def _run_groups(models, dataset_path, flat_dataset_map, groups, consume, gpu_dec
 
     decode_on_gpu = [bool(gpu_decode) and not framepack.is_pack(dataset_path) and not framepack.is_structure(dataset_path)]
 
+    host_lock = threading.Lock()       # the host reader's buffer ring is filled by one loader at a time
+
     def _load(k):
         lo, hi = groups[k]
         if decode_on_gpu[0]:
@@ -207,12 +210,13 @@ def _run_groups(models, dataset_path, flat_dataset_map, groups, consume, gpu_dec
             if got is not None:
                 return got
             decode_on_gpu[0] = False
-        slot = k % ring_size
-        # float32 frames: the rounding Keras applies to load_batch's float64 anyway, done while the chunks are placed
-        X, y = du.load_batch(dataset_path, flat_dataset_map[lo:hi], dtype=np.float32, out=ring[slot] if slot < len(ring) else None)
-        if use_ring and len(ring) == slot and isinstance(X, np.ndarray) and X.base is None and len(X) == max_rows:
-            ring.append(X)
-        return X, y
+        with host_lock:
+            slot = k % ring_size
+            # float32 frames: the rounding Keras applies to load_batch's float64 anyway, done while the chunks are placed
+            X, y = du.load_batch(dataset_path, flat_dataset_map[lo:hi], dtype=np.float32, out=ring[slot] if slot < len(ring) else None)
+            if use_ring and len(ring) == slot and isinstance(X, np.ndarray) and X.base is None and len(X) == max_rows:
+                ring.append(X)
+            return X, y
 
     def finish(ticket, labels):
         consume(ticket.result(), labels)
@@ -224,7 +228,9 @@ def _run_groups(models, dataset_path, flat_dataset_map, groups, consume, gpu_dec
     switch = sys.getswitchinterval()
     sys.setswitchinterval(2e-4)
     try:
-        _pump(models, groups, load, finish, pending, writing, depth)
+        # (one loader: two of them on GPU-inflated datasets — the host part and the pageable upload of batch g+2 under the inflate
+        # kernels of batch g+1 — were measured at the same 0.38 s per 40 k frames; TIMED_LOADERS is there to try again)
+        _pump(models, groups, load, finish, pending, writing, depth, loaders=max(1, int(os.environ.get("TIMED_LOADERS", "1"))))
     finally:
         sys.setswitchinterval(switch)
     if os.environ.get("TIMED_PIPELINE_TRACE"):
@@ -232,21 +238,21 @@ def _run_groups(models, dataset_path, flat_dataset_map, groups, consume, gpu_dec
     del ring[:]
 
 
-def _pump(models, groups, load, finish, pending, writing, depth):
+def _pump(models, groups, load, finish, pending, writing, depth, loaders=1):
     trace = os.environ.get("TIMED_PIPELINE_TRACE")
     if trace:
         import time
         t_load = t_wait = t_submit = 0.0
         clock = time.perf_counter
-    with ThreadPoolExecutor(max_workers=1, thread_name_prefix="load_batch") as loader, \
+    with ThreadPoolExecutor(max_workers=loaders, thread_name_prefix="load_batch") as loader, \
             ThreadPoolExecutor(max_workers=1, thread_name_prefix="write_outputs") as writer:
-        nxt = loader.submit(load, 0)
+        ahead = deque(loader.submit(load, j) for j in range(min(loaders, len(groups))))     # groups being loaded, in order
         for k in range(len(groups)):
             if trace:
                 t0 = clock()
-            X, y = nxt.result()
-            if k + 1 < len(groups):
-                nxt = loader.submit(load, k + 1)
+            X, y = ahead.popleft().result()
+            if k + loaders < len(groups):
+                ahead.append(loader.submit(load, k + loaders))
             if trace:
                 t1 = clock(); t_load += t1 - t0
             # a model has 4 tickets (th_predict_async): at most 3 consecutive groups per model are outstanding here,
