@@ -801,43 +801,22 @@ extern "C" int th_inflate_many(int device, const void* comp, int64_t comp_len, i
 int inflate_place_device(int device, hipStream_t stream, const void* span, int64_t span_len, int64_t n_chunks, const int64_t* src_off,
                          const int64_t* csize, const int* ds, const int* coff8, int rank, const int64_t* shape, const int64_t* chunk, int esz,
                          int conv, void* d_out, int64_t* n_bad) {
-    // Scratch memory with its own (non-blocking) stream, one caller at a time.  (Measured with TWO sets and two loader threads in
-    // predict.py, so that the pageable upload of one batch runs under the kernels of the other: each call then took twice as long
-    // — the same 0.38 s for 40 k frames warm — and the first call of a process paid for a second 9 GB token arena: 0.49 -> 1.09 s.
-    // kSets stays 1.)  `stream`: nullptr (the usual case) means "the set's own stream".
+    // Scratch memory with its own (non-blocking) stream, one caller at a time per device.  (Measured with TWO sets per device and
+    // two loader threads in predict.py, so that the pageable upload of one batch runs under the kernels of the other: each call then
+    // took twice as long — the same 0.38 s for 40 k frames warm — and the first call of a process paid for a second 9 GB token
+    // arena: 0.49 -> 1.09 s.  One set it is.)  `stream`: nullptr (the usual case) means "the set's own stream".
     struct Scratch {
         std::mutex mu;
         DevBuf d_comp, d_raw, d_desc, d_st, d_ds, d_coff, d_tok, d_nt;
         void* h_st = nullptr; size_t h_st_cap = 0;
         hipStream_t own = nullptr;
-        int device = -1;
     };
-    constexpr unsigned kSets = 1;
-    static Scratch sets[kSets];
-    static std::atomic<unsigned> turn{0};
-    Scratch* sc = nullptr;
-    std::unique_lock<std::mutex> lock;
-    for (Scratch& c : sets) {
-        std::unique_lock<std::mutex> l(c.mu, std::try_to_lock);
-        if (l.owns_lock()) { sc = &c; lock = std::move(l); break; }
-    }
-    if (!sc) {
-        sc = &sets[turn.fetch_add(1) % kSets];
-        lock = std::unique_lock<std::mutex>(sc->mu);
-    }
+    constexpr int kMaxDevices = 16;         // one set per device (`predict.py --devices 0,1,...` decodes on the GPU that predicts)
+    static Scratch sets[kMaxDevices];
+    if (device < 0 || device >= kMaxDevices) TH_FAIL(TH_EINVAL, "inflate: device %d outside 0..%d", device, kMaxDevices - 1);
+    Scratch* sc = &sets[device];
+    std::unique_lock<std::mutex> lock(sc->mu);
     HIP_TRY(hipSetDevice(device));
-    if (sc->device != device) {             // scratch memory lives on ONE device: a caller that moves to another one starts over
-        if (sc->device >= 0) {
-            HIP_TRY(hipSetDevice(sc->device));
-            for (DevBuf* b : {&sc->d_comp, &sc->d_raw, &sc->d_desc, &sc->d_st, &sc->d_ds, &sc->d_coff, &sc->d_tok, &sc->d_nt}) {
-                if (b->p) (void)hipFree(b->p);
-                b->p = nullptr; b->cap = 0;
-            }
-            if (sc->own) { (void)hipStreamDestroy(sc->own); sc->own = nullptr; }
-            HIP_TRY(hipSetDevice(device));
-        }
-        sc->device = device;
-    }
     if (!sc->own) HIP_TRY(hipStreamCreateWithFlags(&sc->own, hipStreamNonBlocking));
     if (!stream) stream = sc->own;
     DevBuf &d_comp = sc->d_comp, &d_raw = sc->d_raw, &d_desc = sc->d_desc, &d_st = sc->d_st, &d_ds = sc->d_ds, &d_coff = sc->d_coff,
