@@ -222,3 +222,30 @@ def test_boolean_h5py_fixture_decoded_on_the_gpu(gpu):
     assert got is not None
     dev, yd = got
     assert np.array_equal(dev.buffer.download(dev.shape, dev.dtype).astype(X.dtype), X) and np.array_equal(yd, y)
+
+
+def test_gpu_decode_is_taken_when_h5py_is_installed(gpu, monkeypatch):
+    """`import h5py` working (the reference's normal environment) must not disable the device path: a stand-in h5py that refuses
+    to open files is installed, load_batch_device still decodes on the GPU through the kept h5lite handle"""
+    import os
+    import sys
+    import types
+    import warnings
+    from design_utils import utils
+    fake = types.ModuleType("h5py")
+
+    def _refuse(*a, **k):
+        raise RuntimeError("h5py.File was called")
+    fake.File = _refuse
+    monkeypatch.setitem(sys.modules, "h5py", fake)
+    utils._H5_KEEP.clear()
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    z = np.load(os.path.join(G, "frames_chunked_expected.npz"))
+    path = os.path.join(G, "frames_chunked.hdf5")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fmap = np.array(utils.create_flat_dataset_map(path)[0])
+        got = utils.load_batch_device(path, fmap, device=gpu)
+    assert got is not None
+    assert np.array_equal(got[0].buffer.download(got[0].shape, got[0].dtype), z["frames32"])
+    utils._H5_KEEP.clear()

@@ -432,3 +432,28 @@ def test_multi_chunk_float64_frames_equal_h5py(tmp_path):
     with h5lite.File(path) as f:
         geo = f["1abc"]["A"]["3"].chunked_geometry()
     assert geo[2] == (6, 11, 11, 3) and geo[4] == (1,)
+
+
+def test_native_map_path_does_not_depend_on_h5py_being_absent(monkeypatch):
+    """the reference's users HAVE h5py installed: the native map path (and with it load_batch_device's GPU decode, which shares
+    the kept h5lite handle) must not switch itself off because `import h5py` works.  A stand-in h5py whose File refuses to open
+    anything proves that the map is built without it; a file h5lite cannot read falls through to h5py (here: the refusal)."""
+    import sys
+    import types
+    fake = types.ModuleType("h5py")
+
+    def _refuse(*a, **k):
+        raise RuntimeError("h5py.File was called")
+    fake.File = _refuse
+    monkeypatch.setitem(sys.modules, "h5py", fake)
+    utils._H5_KEEP.clear()
+    path = os.path.join(G, "frames_chunked.hdf5")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fmap, _ = utils.create_flat_dataset_map(path)
+    assert len(fmap) == 5 and utils._kept_h5lite(path) is not None
+    bogus = os.path.join(G, "h5_expected.npz")                       # not an HDF5 file
+    assert utils._kept_h5lite(bogus) is None
+    with pytest.raises(RuntimeError, match="h5py.File was called"):
+        utils.create_flat_dataset_map(bogus)
+    utils._H5_KEEP.clear()

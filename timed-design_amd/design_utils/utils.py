@@ -91,13 +91,28 @@ def create_flat_dataset_map(
     if framepack.is_structure(frame_dataset):   # a PDB file: voxelised on the GPU (row f-4), one frame per residue
         fmap = [tuple(str(x) for x in r) for r in _structure_pack(frame_dataset).flat_map if r[0][:4] not in filter_list]
         return fmap, {r[0] for r in fmap}
-    standard_residues = list(standard_amino_acids.values())
     uncommon = UNCOMMON_RESIDUE_DICT if uncommon_residue_dict is None else uncommon_residue_dict
+    kept = _kept_h5lite(frame_dataset)      # stays mapped, link tables parsed once: load_batch_device reads the same handle
+    if kept is not None:
+        from timed_hip import h5lite
+        try:
+            return _flat_map_of(kept, filter_list, remove_blacklist_silently, uncommon)
+        except (h5lite.H5Unsupported, h5lite.H5FormatError):
+            try:                         # a file feature h5lite does not read: h5py's job, when it is there
+                import h5py  # noqa: F401
+            except ImportError:
+                raise
+    with open_frame_dataset(frame_dataset) as dataset_file:
+        return _flat_map_of(dataset_file, filter_list, remove_blacklist_silently, uncommon)
+
+
+def _flat_map_of(dataset_file, filter_list, remove_blacklist_silently, uncommon):
+    """create_flat_dataset_map over an open dataset (h5py.File or h5lite.File)"""
+    standard_residues = list(standard_amino_acids.values())
     training_set_pdbs = set()
     flat_dataset_map = []
     chains = []
-    kept = _kept_h5lite(frame_dataset)      # stays mapped, link tables parsed once: load_batch_device reads the same handle
-    with (contextlib.nullcontext(kept) if kept is not None else open_frame_dataset(frame_dataset)) as dataset_file:
+    if True:
         for pdb_code in dataset_file:
             if pdb_code[:4] in filter_list:
                 if remove_blacklist_silently:
@@ -310,10 +325,15 @@ _H5_KEEP: dict = {}      # path -> (mtime, size, h5lite.File): the dataset load_
 
 def _kept_h5lite(dataset_path):
     """The reference re-opens the dataset for every batch (utils.py:514); mapping and unmapping a multi-GB file costs ~7 ms
-    per call (munmap), so the device path keeps the file it read last open (re-opened when the file changed on disk)."""
+    per call (munmap), so the native paths (dataset map, GPU decode) keep the file they read last open through timed_hip.h5lite
+    (re-opened when the file changed on disk) — also when h5py is installed: h5py then still serves the general reader.
+    None when h5lite cannot open the file (not HDF5, a superblock version it does not read ...)."""
     from timed_hip import h5lite
     key = os.path.abspath(os.fspath(dataset_path))
-    st = os.stat(key)
+    try:
+        st = os.stat(key)
+    except OSError:
+        return None
     kept = _H5_KEEP.get(key)
     if kept is not None and kept[0] == st.st_mtime_ns and kept[1] == st.st_size:
         return kept[2]
@@ -324,11 +344,9 @@ def _kept_h5lite(dataset_path):
             pass
     _H5_KEEP.clear()
     try:
-        import h5py  # noqa: F401  (when h5py is importable the general readers use it: this path is h5lite-only)
+        f = h5lite.File(key)
+    except (h5lite.H5Unsupported, h5lite.H5FormatError, OSError, ValueError):
         return None
-    except ImportError:
-        pass
-    f = h5lite.File(key)
     _H5_KEEP[key] = (st.st_mtime_ns, st.st_size, f)
     return f
 
@@ -348,6 +366,14 @@ def load_batch_device(dataset_path: Path, data_point_batch, device: int = 0):
     dataset = _kept_h5lite(dataset_path)
     if dataset is None:
         return None
+    try:
+        return _load_batch_device(dataset, data_point_batch, n, device)
+    except (h5lite.H5Unsupported, h5lite.H5FormatError, KeyError):      # a file feature h5lite does not read: the host reader's job
+        return None
+
+
+def _load_batch_device(dataset, data_point_batch, n, device):
+    from timed_hip import engine, h5lite
     if True:
         dims = tuple(int(d) for d in np.asarray(dataset.attrs["frame_dims"]).ravel())
         gaussian = bool(dataset.attrs["voxels_as_gaussian"])

@@ -204,7 +204,7 @@ def _run_groups(models, dataset_path, flat_dataset_map, groups, consume, gpu_dec
         lo, hi = groups[k]
         if decode_on_gpu[0]:
             # gzip .hdf5: the chunks of this group are inflated ON the GPU that will predict it (th_h5_decode_device) — the
-            # frames never exist on the host; a dataset that cannot take the path (other filters, h5py in use ...) says so
+            # frames never exist on the host; a dataset that cannot take the path (other filters, a layout h5lite does not read ...) says so
             # once and the host reader takes over
             got = du.load_batch_device(dataset_path, flat_dataset_map[lo:hi], device=models[k % len(models)].device)
             if got is not None:
