@@ -452,6 +452,8 @@ def test_native_map_path_does_not_depend_on_h5py_being_absent(monkeypatch):
         warnings.simplefilter("ignore")
         fmap, _ = utils.create_flat_dataset_map(path)
     assert len(fmap) == 5 and utils._kept_h5lite(path) is not None
+    X32, y = utils.load_batch(path, fmap, dtype=np.float32)           # the native host reader, too
+    assert np.array_equal(X32, np.load(os.path.join(G, "frames_chunked_expected.npz"))["frames32"]) and y.shape == (5, 20)
     bogus = os.path.join(G, "h5_expected.npz")                       # not an HDF5 file
     assert utils._kept_h5lite(bogus) is None
     with pytest.raises(RuntimeError, match="h5py.File was called"):

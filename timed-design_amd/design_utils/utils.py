@@ -248,8 +248,26 @@ def load_batch(dataset_path: Path, data_point_batch: t.List[t.Tuple], dtype=None
         return _frame_pack(dataset_path).load_batch(data_point_batch)
     if framepack.is_structure(dataset_path):
         return _structure_pack(dataset_path).load_batch(data_point_batch)
-    batch_size = len(data_point_batch)
+    # the native readers (th_h5_resolve + th_h5_read_chunked_as on host threads) work on the kept h5lite mapping of the file,
+    # whether or not h5py is installed; what h5lite cannot read at all is h5py's job when it is there
+    kept = _kept_h5lite(dataset_path)
+    if kept is not None:
+        from timed_hip import h5lite
+        try:
+            return _load_batch_from(kept, data_point_batch, dtype, out)
+        except (h5lite.H5Unsupported, h5lite.H5FormatError):
+            try:
+                import h5py  # noqa: F401
+            except ImportError:
+                raise
     with open_frame_dataset(dataset_path) as dataset:
+        return _load_batch_from(dataset, data_point_batch, dtype, out)
+
+
+def _load_batch_from(dataset, data_point_batch, dtype, out):
+    """load_batch over an open dataset (h5py.File or h5lite.File)"""
+    batch_size = len(data_point_batch)
+    if True:
         dims = tuple(int(d) for d in np.asarray(dataset.attrs["frame_dims"]).ravel())
         voxels_as_gaussian = bool(dataset.attrs["voxels_as_gaussian"])
         as_f32 = dtype is not None and np.dtype(dtype) == np.float32 and voxels_as_gaussian
