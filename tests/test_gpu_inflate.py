@@ -249,3 +249,51 @@ def test_gpu_decode_is_taken_when_h5py_is_installed(gpu, monkeypatch):
     assert got is not None
     assert np.array_equal(got[0].buffer.download(got[0].shape, got[0].dtype), z["frames32"])
     utils._H5_KEEP.clear()
+
+
+@pytest.mark.parametrize("wrapped", [1, 0])
+def test_random_streams_of_every_strategy_match_zlib(gpu, lib, wrapped):
+    """600 seeded random payloads (runs, periodic data of random period, noise, sparse doubles, mixtures; 0 .. 70 000 bytes)
+    compressed at random levels with every zlib strategy (default, filtered, Huffman-only, RLE, fixed) and window size: the
+    decoder's output is zlib's input, byte for byte"""
+    rng = np.random.default_rng(20240 + wrapped)
+
+    def payload():
+        kind = int(rng.integers(0, 7))
+        n = int(rng.choice([0, 1, 2, 3, 17, 255, 256, 257, 258, 259, 1000, 4096, 33000, 70000])) if rng.random() < 0.3 else int(rng.integers(0, 6000))
+        if kind == 0:
+            return bytes(n)
+        if kind == 1:
+            return rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        if kind == 2:
+            period = int(rng.integers(1, 300))
+            return (rng.integers(0, 256, period, dtype=np.uint8).tobytes() * (n // period + 1))[:n]
+        if kind == 3:
+            return np.repeat(rng.integers(0, 4, max(1, n // 20), dtype=np.uint8), rng.integers(1, 40, max(1, n // 20))).tobytes()[:n]
+        if kind == 4:
+            g = np.zeros(max(1, n // 8))
+            k = max(1, g.size // 10)
+            g[rng.integers(0, g.size, k)] = rng.random(k)
+            return g.tobytes()[:n]
+        if kind == 5:
+            return rng.integers(97, 101, n, dtype=np.uint8).tobytes()          # 4-letter alphabet: short codes, many matches
+        a = rng.integers(0, 256, max(1, n // 3), dtype=np.uint8).tobytes()
+        return (a + bytes(n // 3) + a)[:n]                                       # a far match across a run of zeros
+
+    strategies = [zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED]
+    streams, sizes, want = [], [], []
+    for _ in range(600):
+        p = payload()
+        wbits = int(rng.integers(9, 16))
+        c = zlib.compressobj(int(rng.integers(0, 10)), zlib.DEFLATED, wbits if wrapped else -wbits, int(rng.integers(1, 10)),
+                             strategies[int(rng.integers(0, 5))])
+        half = len(p) // 2
+        data = c.compress(p[:half])
+        if rng.random() < 0.3:
+            data += c.flush(zlib.Z_FULL_FLUSH)                       # an empty stored block in the middle of the stream
+        data += c.compress(p[half:]) + c.flush()
+        streams.append(data); sizes.append(len(p)); want.append(p)
+    rc, status, got, _ = _inflate(lib, gpu, streams, sizes, wrapped=wrapped)
+    assert rc == 0 and not status.any(), f"statuses {np.unique(status)}"
+    bad = [k for k, (a, b) in enumerate(zip(got, want)) if a != b]
+    assert not bad, f"streams {bad[:5]} differ"
