@@ -245,7 +245,8 @@ int th_h5_decode_device(const void* file, int64_t file_len, int64_t base, int64_
 /* n independent zlib (wrapped = 1) or raw DEFLATE (wrapped = 0) streams inflated on `device`: stream i is
  * comp[src_off[i] .. + src_len[i]) and decodes to exactly dst_len[i] bytes at out[dst_off[i]] (8-byte aligned).  comp / out are
  * host buffers.  status_out[i] (optional): 0, or why stream i failed (1 input exhausted, 2 output overrun, 3 bad zlib header,
- * 4 invalid code, 5 distance too far back, 6 bad code table, 7 bad stored block, 8 ended short of dst_len).  TH_EIO if any failed. */
+ * 4 invalid code, 5 distance too far back, 6 bad code table, 7 bad stored block, 8 ended short of dst_len, 9 Adler-32 of the
+ * output differs from the zlib trailer — what zlib reports as "incorrect data check"; raw streams carry none).  TH_EIO if any failed. */
 int th_inflate_many(int device, const void* comp, int64_t comp_len, int64_t n, const int64_t* src_off, const int64_t* src_len,
                     const int64_t* dst_off, const int64_t* dst_len, void* out, int64_t out_len, int wrapped, int* status_out);
 

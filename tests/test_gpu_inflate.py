@@ -108,10 +108,10 @@ def test_corrupt_streams_end_in_a_status(gpu, lib):
             ref = zlib.decompress(streams[k])
         except zlib.error:
             ref = None
-        if status[k] == 0:             # (the adler32 trailer is not checked: a flip there, or one that still decodes to n bytes)
-            assert ref is None or got[k] == ref
-        else:
-            assert ref is None or len(ref) != n or True
+        if status[k] == 0:             # accepted here => accepted by zlib, with the same bytes (the Adler-32 trailer is checked)
+            assert ref is not None and got[k] == ref
+        elif ref is not None:          # rejected here but fine for zlib: only if it does not hold exactly the n declared bytes
+            assert len(ref) != n
     assert rc == -2 and np.count_nonzero(status) > 200                # TH_EIO: most of them are rejected
     assert raw[-8:].tolist() == [0xAB] * 8
     assert lib.th_inflate_many(gpu, None, 0, 1, None, None, None, None, None, 0, 1, None) == -1
@@ -297,3 +297,67 @@ def test_random_streams_of_every_strategy_match_zlib(gpu, lib, wrapped):
     assert rc == 0 and not status.any(), f"statuses {np.unique(status)}"
     bad = [k for k, (a, b) in enumerate(zip(got, want)) if a != b]
     assert not bad, f"streams {bad[:5]} differ"
+
+
+def test_adler32_trailer_is_verified_like_zlib_does(gpu, lib):
+    """zlib (and with it h5py's deflate filter) refuses a stream whose Adler-32 does not match its data; so does the GPU path:
+    a flipped trailer byte, and a flipped payload byte inside a STORED block (which every Huffman-level check lets through),
+    end in status 9 — for a stream kept whole in LDS and for one that goes round the 64 KB ring; raw deflate has no trailer"""
+    rng = np.random.default_rng(5)
+    small = rng.integers(0, 256, 5000, dtype=np.uint8).tobytes()
+    big = (rng.integers(0, 256, 3000, dtype=np.uint8).tobytes() * 40)[:100003]           # > 60 KB: the ring path, ragged length
+    streams, sizes, expect = [], [], []
+    for p in (small, big, b"", b"x"):
+        for level in (0, 6):
+            good = zlib.compress(p, level)
+            streams.append(good); sizes.append(len(p)); expect.append(0)
+            bad = bytearray(good); bad[-2] ^= 0x10                                        # trailer
+            streams.append(bytes(bad)); sizes.append(len(p)); expect.append(9)
+            if level == 0 and len(p) > 100:
+                bad = bytearray(good); bad[len(good) // 2] ^= 0x01                        # payload of a stored block
+                assert zlib.decompressobj().decompress(bytes(bad[:-4])) != p
+                streams.append(bytes(bad)); sizes.append(len(p)); expect.append(9)
+    rc, status, got, _ = _inflate(lib, gpu, streams, sizes, expect_ok=False)
+    assert status.tolist() == expect, status.tolist()
+    for k, e in enumerate(expect):
+        if e == 0:
+            assert got[k] == zlib.decompress(streams[k])
+    # raw deflate: nothing to compare against, the payload flip in a stored block goes through (as it does in zlib)
+    c = zlib.compressobj(0, zlib.DEFLATED, -15)
+    raw = bytearray(c.compress(small) + c.flush()); raw[len(raw) // 2] ^= 1
+    rc, status, got, _ = _inflate(lib, gpu, [bytes(raw)], [len(small)], wrapped=0)
+    assert rc == 0 and status[0] == 0 and got[0] == zlib.decompressobj(-15).decompress(bytes(raw))
+
+
+def test_corrupt_chunk_in_an_hdf5_file_is_an_error_not_a_frame(gpu, tmp_path):
+    """a byte of one gzip chunk of the real-h5py fixture is flipped — once in the Adler-32 trailer, once in the middle of the
+    compressed data: the host reader (zlib) raises, and so does the GPU path (th_h5_decode_device -> TH_EIO), instead of handing
+    a wrong frame to the model"""
+    import os
+    import struct
+    import warnings
+    from design_utils import utils
+    from timed_hip import h5lite
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    data = bytearray(open(os.path.join(G, "frames_chunked.hdf5"), "rb").read())
+    with h5lite.File(os.path.join(G, "frames_chunked.hdf5")) as f:
+        btree, _shape, chunk, _esz, _filters = f["1abc"]["A"]["5"].chunked_geometry()
+        a = f._base + btree
+        assert bytes(f._m[a:a + 4]) == b"TREE" and f._m[a + 5] == 0            # a leaf node
+        csize = struct.unpack_from("<I", f._m, a + 24)[0]
+        child = struct.unpack_from("<Q", f._m, a + 24 + 8 + 8 * (len(chunk) + 1))[0] + f._base
+    for k, pos in enumerate((child + csize - 1, child + csize // 2)):
+        bad = bytearray(data)
+        bad[pos] ^= 0x20
+        p = tmp_path / f"bad{k}.hdf5"
+        p.write_bytes(bytes(bad))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            fmap = np.array(utils.create_flat_dataset_map(p)[0])
+            with pytest.raises(Exception):
+                utils.load_batch(p, fmap, dtype=np.float32)
+            with pytest.raises(RuntimeError, match="did not inflate"):
+                utils.load_batch_device(p, fmap, device=gpu)
+            good_rows = fmap[[0, 1, 3, 4]]                                      # the other residues are intact
+            assert utils.load_batch_device(p, good_rows, device=gpu) is not None
+    utils._H5_KEEP.clear()

@@ -42,7 +42,7 @@ constexpr int kMaxBits = 15, kMaxLCodes = 286, kMaxDCodes = 30, kFixLCodes = 288
 struct InfDesc { int64_t src_off, src_len, dst_off, dst_len, tok_off; };
 
 // status per chunk
-enum { INF_OK = 0, INF_EINPUT = 1, INF_EOUTPUT = 2, INF_EHEADER = 3, INF_ECODE = 4, INF_EDIST = 5, INF_ETABLE = 6, INF_ESTORED = 7, INF_ESHORT = 8 };
+enum { INF_OK = 0, INF_EINPUT = 1, INF_EOUTPUT = 2, INF_EHEADER = 3, INF_ECODE = 4, INF_EDIST = 5, INF_ETABLE = 6, INF_ESTORED = 7, INF_ESHORT = 8, INF_ECHECK = 9 };
 
 // one wavefront, [entry][lane].  Packed so that four wavefronts share a CU (37 KB each): the kernel is bound by instruction
 // latency with every lane on its own data-dependent path, so resident wavefronts are what buys throughput.  Symbols are 9 bits
@@ -388,7 +388,7 @@ __device__ __forceinline__ int codes(Bits& b, Out& w, Lds& L, const Code& lc, co
 
 template <int LPW>
 __global__ void __launch_bounds__(kLanes) k_inflate_tokens(const unsigned char* comp, long long comp_len, const InfDesc* desc, long long n,
-                                                        unsigned* tokens, long long* ntok, int* status, int zlib_wrapped) {
+                                                        unsigned* tokens, long long* ntok, int* status, unsigned* adler, int zlib_wrapped) {
     typedef LdsT<LPW> Lds;
     __shared__ Lds L;
     const int lane = threadIdx.x;
@@ -479,6 +479,16 @@ __global__ void __launch_bounds__(kLanes) k_inflate_tokens(const unsigned char* 
         }
     }
     if (st == INF_OK && w.o != w.len) st = INF_ESHORT;
+    // zlib trailer (RFC 1950): the Adler-32 of the uncompressed data, big-endian, at the next byte boundary.  zlib itself — and with
+    // it h5py's deflate filter — refuses a stream whose checksum does not match; k_lz_resolve holds the bytes and compares.
+    unsigned expect = 1u;
+    if (st == INF_OK && zlib_wrapped) {
+        (void)take(b, (int)(b.remaining & 7));
+        expect = 0;
+        for (int k = 0; k < 4; ++k) expect = (expect << 8) | take(b, 8);
+        if (b.over) st = INF_EINPUT;
+    }
+    adler[idx] = expect;
     ntok[idx] = st == INF_OK ? w.nt : 0;
     status[idx] = st;
 }
@@ -521,7 +531,7 @@ __device__ __forceinline__ int wave_scan_incl(int v) {
 // then resolved one after the other (a match may copy what an earlier match of the same batch produced), each in one step by all
 // 64 lanes.
 __global__ void __launch_bounds__(kLanes) k_lz_resolve(const unsigned* tokens, const long long* ntok, const InfDesc* desc, long long n,
-                                                       unsigned char* out, int* status, unsigned M, const PlaceArgs pa, int fused) {
+                                                       unsigned char* out, int* status, unsigned M, const PlaceArgs pa, int fused, const unsigned* adler, int check) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ring[];
     const long long idx = blockIdx.x;
     if (idx >= n || status[idx] != INF_OK) return;
@@ -531,12 +541,51 @@ __global__ void __launch_bounds__(kLanes) k_lz_resolve(const unsigned* tokens, c
     const long long nt = ntok[idx];
     unsigned char* dst = out + d.dst_off;
     long long o = 0, flushed = 0;
+    // Adler-32 of the output, block by block as the bytes become final: for a block of m bytes b_0..b_{m-1},
+    //   s1' = s1 + sum b_j,   s2' = s2 + m s1 + sum (m - j) b_j        (mod 65521)
+    // — both sums are plain sums over the block, so the lanes take 8 bytes each per step (v_sad_u8 / v_dot4 on the two words)
+    // and one wave reduction per block gives every lane the same (s1, s2).
+    unsigned s1 = 1u, s2 = 0u;
+    long long summed = 0;                     // bytes [0, summed) are in (s1, s2)
+    auto adler_to = [&](long long upto) {     // [summed, upto); summed is a multiple of 8
+        if (!check || upto <= summed) return;
+        const long long m = upto - summed;
+        unsigned long long a = 0, wsum = 0;
+        long long j = 8ll * lane;
+        for (; j + 8 <= m; j += 8ll * kLanes) {
+            const unsigned long long v = *reinterpret_cast<const unsigned long long*>(ring + ((unsigned)(summed + j) & M));
+            const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+            const unsigned sb = __builtin_amdgcn_sad_u8(lo, 0u, 0u) + __builtin_amdgcn_sad_u8(hi, 0u, 0u);
+            const unsigned si = __builtin_amdgcn_udot4(lo, 0x03020100u, 0u, false) + __builtin_amdgcn_udot4(hi, 0x07060504u, 0u, false);
+            a += sb;
+            wsum += (unsigned long long)(m - j) * sb - si;
+        }
+        if (j < m) {                          // the lane that holds the ragged end (at most 7 bytes)
+            for (long long k = j; k < m; ++k) {
+                const unsigned bb = ring[(unsigned)(summed + k) & M];
+                a += bb;
+                wsum += (unsigned long long)(m - k) * bb;
+            }
+        }
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) {
+            a += (unsigned long long)__shfl_xor((unsigned)a, sft) | ((unsigned long long)__shfl_xor((unsigned)(a >> 32), sft) << 32);
+            wsum += (unsigned long long)__shfl_xor((unsigned)wsum, sft) | ((unsigned long long)__shfl_xor((unsigned)(wsum >> 32), sft) << 32);
+        }
+        s2 = (unsigned)((s2 + (unsigned long long)(m % 65521) * s1 + wsum % 65521) % 65521);
+        s1 = (unsigned)((s1 + a) % 65521);
+        summed = upto;
+    };
     auto flush_to = [&](long long upto) {     // [flushed, upto), both multiples of 8
+        adler_to(upto);
         for (long long i = flushed + 8ll * lane; i < upto; i += 8ll * kLanes)
             *reinterpret_cast<unsigned long long*>(dst + i) = *reinterpret_cast<const unsigned long long*>(ring + ((unsigned)i & M));
         flushed = upto;
     };
-    if (nt <= 0) return;      // (an empty stream has no bytes either)
+    if (nt <= 0) {            // an empty stream has no bytes either: its Adler-32 is 1
+        if (check && adler[idx] != 1u && lane == 0) status[idx] = INF_ECHECK;
+        return;
+    }
     unsigned tk_next = tok[min((long long)lane, nt - 1)];
     for (long long t0 = 0; t0 < nt; t0 += kLanes) {
         const bool valid = t0 + lane < nt;
@@ -596,6 +645,13 @@ __global__ void __launch_bounds__(kLanes) k_lz_resolve(const unsigned* tokens, c
         o += total;
     }
     wave_sync();
+    if (check) {
+        adler_to(o);                          // (what has not been summed yet is still in the window, ragged end included)
+        if (((s2 << 16) | s1) != adler[idx]) {
+            if (lane == 0) status[idx] = INF_ECHECK;
+            return;
+        }
+    }
     if (fused) {
         // the whole chunk sits in LDS (M = ~0): place it straight into its frame — float64 -> float32 on the way when asked —
         // instead of writing the raw bytes out for k_place_chunks to read back
@@ -692,18 +748,18 @@ __global__ void k_place_chunks(const PlaceArgs a, long long n_chunks) {
 
 // streams per wavefront (see LdsT)
 inline void launch_tokens(hipStream_t stream, const unsigned char* comp, long long comp_len, const InfDesc* desc, long long n, unsigned* tok,
-                          long long* ntok, int* st, int wrapped) {
+                          long long* ntok, int* st, unsigned* adler, int wrapped) {
     static const int forced = getenv("TH_INFLATE_LPW") ? atoi(getenv("TH_INFLATE_LPW")) : 0;     // A/B: 8, 16 or 64
     // measured (gzip float64 frames, 17 KB chunks): a wavefront costs the same instruction slots with 8 active lanes as with 64,
     // and the streams in flight are bounded by LDS (580 B each) either way — 131 k streams ran 10.0 / 11.3 / 16.1 ms at LPW
     // 64 / 16 / 8 (before the predicated loop; 5.9 ms at 64 now).  Few streams: spread them over the CUs.
     const int lpw = forced ? forced : (n >= 16384 ? 64 : (n >= 2048 ? 16 : 8));
     if (lpw == 8)
-        hipLaunchKernelGGL(k_inflate_tokens<8>, dim3((unsigned)((n + 7) / 8)), dim3(kLanes), 0, stream, comp, comp_len, desc, n, tok, ntok, st, wrapped);
+        hipLaunchKernelGGL(k_inflate_tokens<8>, dim3((unsigned)((n + 7) / 8)), dim3(kLanes), 0, stream, comp, comp_len, desc, n, tok, ntok, st, adler, wrapped);
     else if (lpw == 16)
-        hipLaunchKernelGGL(k_inflate_tokens<16>, dim3((unsigned)((n + 15) / 16)), dim3(kLanes), 0, stream, comp, comp_len, desc, n, tok, ntok, st, wrapped);
+        hipLaunchKernelGGL(k_inflate_tokens<16>, dim3((unsigned)((n + 15) / 16)), dim3(kLanes), 0, stream, comp, comp_len, desc, n, tok, ntok, st, adler, wrapped);
     else
-        hipLaunchKernelGGL(k_inflate_tokens<64>, dim3((unsigned)((n + 63) / 64)), dim3(kLanes), 0, stream, comp, comp_len, desc, n, tok, ntok, st, wrapped);
+        hipLaunchKernelGGL(k_inflate_tokens<64>, dim3((unsigned)((n + 63) / 64)), dim3(kLanes), 0, stream, comp, comp_len, desc, n, tok, ntok, st, adler, wrapped);
 }
 
 // LDS window of k_lz_resolve for streams of at most max_len bytes
@@ -754,7 +810,7 @@ extern "C" int th_inflate_many(int device, const void* comp, int64_t comp_len, i
     unsigned char *d_comp = nullptr, *d_out = nullptr;
     InfDesc* d_desc = nullptr;
     int* d_st = nullptr;
-    unsigned* d_tok = nullptr;
+    unsigned *d_tok = nullptr, *d_ad = nullptr;
     long long* d_nt = nullptr;
     int rc = TH_OK;
     auto fail = [&](hipError_t e, const char* what) { th_set_error("th_inflate_many: %s: %s", what, hipGetErrorString(e)); rc = TH_EHIP; };
@@ -765,24 +821,25 @@ extern "C" int th_inflate_many(int device, const void* comp, int64_t comp_len, i
     if (!rc && (e = hipMalloc(&d_st, (size_t)n * sizeof(int))) != hipSuccess) fail(e, "hipMalloc");
     if (!rc && (e = hipMalloc(&d_tok, (size_t)(tok_total + 16) * sizeof(unsigned))) != hipSuccess) fail(e, "hipMalloc");
     if (!rc && (e = hipMalloc(&d_nt, (size_t)n * sizeof(long long))) != hipSuccess) fail(e, "hipMalloc");
+    if (!rc && (e = hipMalloc(&d_ad, (size_t)n * sizeof(unsigned))) != hipSuccess) fail(e, "hipMalloc");
     if (!rc && (e = hipMemcpy(d_comp, comp, (size_t)comp_len, hipMemcpyHostToDevice)) != hipSuccess) fail(e, "copy in");
     if (!rc && (e = hipMemcpy(d_desc, desc.data(), (size_t)n * sizeof(InfDesc), hipMemcpyHostToDevice)) != hipSuccess) fail(e, "copy in");
     if (!rc && (e = hipMemset(d_st, 0xff, (size_t)n * sizeof(int))) != hipSuccess) fail(e, "memset");
     if (!rc) {
-        launch_tokens(nullptr, d_comp, (long long)comp_len, d_desc, (long long)n, d_tok, d_nt, d_st, wrapped);
+        launch_tokens(nullptr, d_comp, (long long)comp_len, d_desc, (long long)n, d_tok, d_nt, d_st, d_ad, wrapped);
         if ((e = hipGetLastError()) != hipSuccess) fail(e, "launch");
     }
     if (!rc) {
         const RingGeom rg = ring_geom(max_len);
         if ((e = hipFuncSetAttribute((const void*)k_lz_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)) != hipSuccess) fail(e, "attribute");
-        hipLaunchKernelGGL(k_lz_resolve, dim3((unsigned)n), dim3(kLanes), rg.lds, 0, d_tok, d_nt, d_desc, (long long)n, d_out, d_st, rg.mask, PlaceArgs{}, 0);
+        hipLaunchKernelGGL(k_lz_resolve, dim3((unsigned)n), dim3(kLanes), rg.lds, 0, d_tok, d_nt, d_desc, (long long)n, d_out, d_st, rg.mask, PlaceArgs{}, 0, d_ad, wrapped ? 1 : 0);
         if (!rc && (e = hipGetLastError()) != hipSuccess) fail(e, "launch");
     }
     if (!rc && (e = hipDeviceSynchronize()) != hipSuccess) fail(e, "kernel");
     if (!rc && (e = hipMemcpy(out, d_out, (size_t)out_len, hipMemcpyDeviceToHost)) != hipSuccess) fail(e, "copy out");
     std::vector<int> st((size_t)n, 0);
     if (!rc && (e = hipMemcpy(st.data(), d_st, (size_t)n * sizeof(int), hipMemcpyDeviceToHost)) != hipSuccess) fail(e, "copy out");
-    for (void* p : {(void*)d_comp, (void*)d_out, (void*)d_desc, (void*)d_st, (void*)d_tok, (void*)d_nt})
+    for (void* p : {(void*)d_comp, (void*)d_out, (void*)d_desc, (void*)d_st, (void*)d_tok, (void*)d_nt, (void*)d_ad})
         if (p) (void)hipFree(p);
     if (rc) return rc;
     int64_t bad = 0;
@@ -807,7 +864,7 @@ int inflate_place_device(int device, hipStream_t stream, const void* span, int64
     // arena: 0.49 -> 1.09 s.  One set it is.)  `stream`: nullptr (the usual case) means "the set's own stream".
     struct Scratch {
         std::mutex mu;
-        DevBuf d_comp, d_raw, d_desc, d_st, d_ds, d_coff, d_tok, d_nt;
+        DevBuf d_comp, d_raw, d_desc, d_st, d_ds, d_coff, d_tok, d_nt, d_ad;
         void* h_st = nullptr; size_t h_st_cap = 0;
         hipStream_t own = nullptr;
     };
@@ -820,7 +877,7 @@ int inflate_place_device(int device, hipStream_t stream, const void* span, int64
     if (!sc->own) HIP_TRY(hipStreamCreateWithFlags(&sc->own, hipStreamNonBlocking));
     if (!stream) stream = sc->own;
     DevBuf &d_comp = sc->d_comp, &d_raw = sc->d_raw, &d_desc = sc->d_desc, &d_st = sc->d_st, &d_ds = sc->d_ds, &d_coff = sc->d_coff,
-           &d_tok = sc->d_tok, &d_nt = sc->d_nt;
+           &d_tok = sc->d_tok, &d_nt = sc->d_nt, &d_ad = sc->d_ad;
     void*& h_st = sc->h_st;
     size_t& h_st_cap = sc->h_st_cap;
     int64_t chunk_bytes = esz;
@@ -832,7 +889,8 @@ int inflate_place_device(int device, hipStream_t stream, const void* span, int64
     if ((rc = d_comp.ensure((size_t)span_len + 16)) || (rc = d_raw.ensure(fused ? 16 : (size_t)(n_chunks * cb8) + 16)) ||
         (rc = d_desc.ensure((size_t)n_chunks * sizeof(InfDesc))) || (rc = d_st.ensure((size_t)n_chunks * sizeof(int))) ||
         (rc = d_ds.ensure((size_t)n_chunks * sizeof(int))) || (rc = d_coff.ensure((size_t)n_chunks * 8 * sizeof(int))) ||
-        (rc = d_tok.ensure((size_t)(n_chunks * chunk_bytes + 16) * sizeof(unsigned))) || (rc = d_nt.ensure((size_t)n_chunks * sizeof(long long))))
+        (rc = d_tok.ensure((size_t)(n_chunks * chunk_bytes + 16) * sizeof(unsigned))) || (rc = d_nt.ensure((size_t)n_chunks * sizeof(long long))) ||
+        (rc = d_ad.ensure((size_t)n_chunks * sizeof(unsigned))))
         return rc;
     static const bool trace = getenv("TH_H5_TRACE") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
@@ -845,7 +903,7 @@ int inflate_place_device(int device, hipStream_t stream, const void* span, int64
     HIP_TRY(hipMemcpyAsync(d_ds.p, ds, (size_t)n_chunks * sizeof(int), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(d_coff.p, coff8, (size_t)n_chunks * 8 * sizeof(int), hipMemcpyHostToDevice, stream));
     launch_tokens(stream, (const unsigned char*)d_comp.p, (long long)span_len, (const InfDesc*)d_desc.p, (long long)n_chunks, (unsigned*)d_tok.p,
-                  (long long*)d_nt.p, (int*)d_st.p, 1);
+                  (long long*)d_nt.p, (int*)d_st.p, (unsigned*)d_ad.p, 1);
     HIP_TRY(hipGetLastError());
     PlaceArgs a;
     a.raw = (const unsigned char*)d_raw.p; a.chunk_bytes = cb8; a.ds = (const int*)d_ds.p; a.coff = (const int*)d_coff.p;
@@ -857,7 +915,8 @@ int inflate_place_device(int device, hipStream_t stream, const void* span, int64
         const RingGeom rg = ring_geom(chunk_bytes);
         HIP_TRY(hipFuncSetAttribute((const void*)k_lz_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
         hipLaunchKernelGGL(k_lz_resolve, dim3((unsigned)n_chunks), dim3(kLanes), rg.lds, stream, (const unsigned*)d_tok.p, (const long long*)d_nt.p,
-                           (const InfDesc*)d_desc.p, (long long)n_chunks, (unsigned char*)d_raw.p, (int*)d_st.p, rg.mask, a, fused ? 1 : 0);
+                           (const InfDesc*)d_desc.p, (long long)n_chunks, (unsigned char*)d_raw.p, (int*)d_st.p, rg.mask, a, fused ? 1 : 0,
+                           (const unsigned*)d_ad.p, 1);
         HIP_TRY(hipGetLastError());
     }
     if (!fused) {
