@@ -44,26 +44,34 @@ struct InfDesc { int64_t src_off, src_len, dst_off, dst_len, tok_off; };
 // status per chunk
 enum { INF_OK = 0, INF_EINPUT = 1, INF_EOUTPUT = 2, INF_EHEADER = 3, INF_ECODE = 4, INF_EDIST = 5, INF_ETABLE = 6, INF_ESTORED = 7, INF_ESHORT = 8, INF_ECHECK = 9 };
 
-// one wavefront, [entry][lane].  Packed so that four wavefronts share a CU (37 KB each): the kernel is bound by instruction
-// latency with every lane on its own data-dependent path, so resident wavefronts are what buys throughput.  Symbols are 9 bits
-// (0..287): the low byte in lsym, bit 8 in a bit array; code lengths are 4 bits, two per byte.
-// LPW = streams (active lanes) per wavefront.  A batch of 1 024 frames is ~30 000 streams: at 64 per wavefront that is 500
-// wavefronts for 1 024 SIMDs, each crawling through 64 unrelated streams in lockstep.  With 8 streams per wavefront there are 8x
-// more wavefronts (several per SIMD, hiding each other's latency), each waits only for the slowest of 8 paths, and its tables
-// take 4.6 KB of LDS.  The idle lanes cost nothing: this kernel is bound by latency, not by lanes.
+// Tables of one wavefront, [entry][lane]: the symbols of the two Huffman codes of the current block, sorted by (code length, symbol)
+// — 288 + 32 bytes per stream and NOTHING else, because 64 streams x 320 B = 20 KB is what lets EIGHT wavefronts share the 160 KB of
+// a CU: the kernel is bound by instruction latency with every lane on its own data-dependent path, and two wavefronts per SIMD hide
+// each other (measured with 32 streams per wavefront: 2 x as many wavefronts in 1.22 x the time).  Everything else lives in
+// registers or is not kept at all: bit 8 of the literal/length symbols (9 words), the per-length limits and bases of both codes
+// (struct Code), the code-length code of a dynamic header (19 x 3 bits of lengths, 19 x 5 bits of sorted symbols) — and the 316
+// code LENGTHS of a dynamic block are never stored: the header is decoded twice, once to count the codes per length (the counters
+// borrow the first 64 rows of lsym, dead at that point) and once more, from the saved bit position, to put every symbol in its place.
+// LPW = streams (active lanes) per wavefront: small batches use fewer, so that the streams spread over the CUs.
 template <int LPW>
 struct LdsT {
-    unsigned short lcnt[16][LPW];
     unsigned char lsym[kFixLCodes][LPW];
-    unsigned lhi[kFixLCodes / 32][LPW];
-    unsigned short dcnt[16][LPW];
     unsigned char dsym[32][LPW];
-    unsigned char lens[(kMaxLCodes + kMaxDCodes + 4) / 2][LPW];
 };
-template <class Lds> __device__ __forceinline__ int get_len(const Lds& L, int i, int lane) { return (L.lens[i >> 1][lane] >> ((i & 1) * 4)) & 15; }
-template <class Lds> __device__ __forceinline__ void set_len(Lds& L, int i, int lane, int v) {
-    const int sh = (i & 1) * 4;
-    L.lens[i >> 1][lane] = (unsigned char)((L.lens[i >> 1][lane] & ~(15 << sh)) | (v << sh));
+// bit 8 of the sorted literal/length symbols: 288 bits in nine NAMED registers (an array indexed per lane would live in scratch)
+struct Hi9 { unsigned h0, h1, h2, h3, h4, h5, h6, h7, h8; };
+__device__ __forceinline__ unsigned hi_bit(const Hi9& h, int idx) {       // idx in 0..287
+    const int k = idx >> 5;
+    const unsigned a = (k & 1) ? h.h1 : h.h0, bb = (k & 1) ? h.h3 : h.h2, c = (k & 1) ? h.h5 : h.h4, d = (k & 1) ? h.h7 : h.h6;
+    const unsigned ab = (k & 2) ? bb : a, cd = (k & 2) ? d : c;
+    const unsigned w = (k & 8) ? h.h8 : ((k & 4) ? cd : ab);
+    return (w >> (idx & 31)) & 1u;
+}
+__device__ __forceinline__ void hi_set(Hi9& h, int idx) {
+    const int k = idx >> 5;
+    const unsigned bit = 1u << (idx & 31);
+    h.h0 |= k == 0 ? bit : 0u; h.h1 |= k == 1 ? bit : 0u; h.h2 |= k == 2 ? bit : 0u; h.h3 |= k == 3 ? bit : 0u; h.h4 |= k == 4 ? bit : 0u;
+    h.h5 |= k == 5 ? bit : 0u; h.h6 |= k == 6 ? bit : 0u; h.h7 |= k == 7 ? bit : 0u; h.h8 |= k == 8 ? bit : 0u;
 }
 
 
@@ -162,33 +170,103 @@ __device__ __forceinline__ void code_from_counts(Code& c, const unsigned short (
         first = (first + count) << 1;
     }
 }
-template <bool WIDE, class Lds, int LPW>     // WIDE: the literal/length table (9-bit symbols: byte + bit array); else the byte table `sym`
-__device__ __forceinline__ int decode(Bits& b, const Code& c, const Lds& L, const unsigned char (*sym)[LPW], int lane) {
+// ---- dynamic block header ------------------------------------------------------------------------------------------------
+// The code-length code (RFC 1951 3.2.7): 19 symbols with 3-bit lengths.  Lengths, limits / bases and the sorted symbol table all fit
+// in registers (57 + 95 bits of table).
+struct ClCode { int lim[8]; int bas[8]; unsigned long long tlo, thi; };      // [1..7]; tlo: sorted symbols 0..11 (5 bits each), thi: 12..18
+__device__ __forceinline__ int cl_build(ClCode& c, unsigned long long cl) {   // cl: 3 bits per symbol; returns 0 or INF_ETABLE
+    int cnt[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cnt[k] = 0;
+    for (int sy = 0; sy < 19; ++sy) {
+        const int l = (int)(cl >> (3 * sy)) & 7;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cnt[k] += (l == k) ? 1 : 0;
+    }
+    int left = 1;
+    bool over_sub = false;
+#pragma unroll
+    for (int len = 1; len <= 7; ++len) {
+        left = (left << 1) - cnt[len];
+        over_sub = over_sub || left < 0;
+    }
+    // (no codes at all: every decode fails with INF_ECODE, as with any other code that lacks the symbol; an incomplete or
+    // over-subscribed code-length code is refused, as zlib does)
+    if (cnt[0] != 19 && (over_sub || left != 0)) return INF_ETABLE;
+    int first = 0, offs = 0, prev_base = 0;
+    int at[8];
+    at[0] = 0;
+#pragma unroll
+    for (int len = 1; len <= 7; ++len) {
+        c.lim[len] = (first + cnt[len]) << (kMaxBits - len);
+        c.bas[len] = (offs - first) - prev_base;
+        prev_base = offs - first;
+        at[len] = offs;
+        offs += cnt[len];
+        first = (first + cnt[len]) << 1;
+    }
+    c.tlo = 0; c.thi = 0;
+    for (int sy = 0; sy < 19; ++sy) {
+        const int l = (int)(cl >> (3 * sy)) & 7;
+        int pos = 0;
+#pragma unroll
+        for (int k = 1; k <= 7; ++k) {
+            const bool here = k == l;
+            pos += here ? at[k] : 0;
+            at[k] += here ? 1 : 0;
+        }
+        if (l != 0) {
+            if (pos < 12) c.tlo |= (unsigned long long)sy << (5 * pos);
+            else c.thi |= (unsigned long long)sy << (5 * (pos - 12));
+        }
+    }
+    return INF_OK;
+}
+__device__ __forceinline__ int cl_decode(Bits& b, const ClCode& c) {         // a symbol 0..18, or -1 (then b.over tells why)
     refill(b);
     const int v = (int)(__brev((unsigned)(b.buf & 0x7fff)) >> 17);
     int len = 1, base = c.bas[1];
 #pragma unroll
-    for (int l = 1; l < kMaxBits; ++l) {
+    for (int l = 1; l < 7; ++l) {
         const bool ge = v >= c.lim[l];
         len += ge ? 1 : 0;
         base += ge ? c.bas[l + 1] : 0;
     }
-    if (v >= c.lim[kMaxBits]) return -1;          // not a code of this (incomplete) set
+    if (v >= c.lim[7]) return -1;
     b.buf >>= len;
     b.cnt -= len;
     b.remaining -= len;
     if (b.remaining < 0) { b.over = true; return -1; }
-    const int idx = (v >> (kMaxBits - len)) + base;
-    if (WIDE) return (int)L.lsym[idx][lane] | (int)(((L.lhi[idx >> 5][lane] >> (idx & 31)) & 1u) << 8);
-    return sym[idx][lane];
+    const int idx = min(max((v >> (kMaxBits - len)) + base, 0), 18);
+    return (int)((idx < 12 ? c.tlo >> (5 * idx) : c.thi >> (5 * (idx - 12))) & 31);
 }
-
-// build count[] / symbol[] from the code lengths lens[base .. base + n); returns < 0 for an over-subscribed set, > 0 for an
-// incomplete one, 0 for a complete one
-template <bool WIDE, class Lds, int LPW>
-__device__ __forceinline__ int construct(Lds& L, unsigned short (*cnt)[LPW], unsigned char (*sym)[LPW], int base, int n, int lane) {
-    for (int len = 0; len <= kMaxBits; ++len) cnt[len][lane] = 0;
-    for (int s = 0; s < n; ++s) cnt[get_len(L, base + s, lane)][lane]++;
+// the nlen + ndist code lengths of a dynamic block, run-length coded with the code-length code: fn(i, length) for every one of
+// them, in order.  Called twice per block with the same bit position: the lengths themselves are never stored.
+template <class F>
+__device__ __forceinline__ int walk_lengths(Bits& b, const ClCode& c, int total, F&& fn) {
+    int i = 0, prev = 0;
+    while (i < total) {
+        const int sym = cl_decode(b, c);
+        if (sym < 0) return b.over ? INF_EINPUT : INF_ECODE;
+        int rep = 1, val = sym;
+        if (sym >= 16) {
+            if (sym == 16) {
+                if (i == 0) return INF_ETABLE;
+                val = prev;
+                rep = 3 + (int)take(b, 2);
+            } else if (sym == 17) { val = 0; rep = 3 + (int)take(b, 3); }
+            else { val = 0; rep = 11 + (int)take(b, 7); }
+            if (b.over) return INF_EINPUT;
+            if (i + rep > total) return INF_ETABLE;
+        }
+        for (int r = 0; r < rep; ++r) fn(i++, val);
+        prev = val;
+    }
+    return INF_OK;
+}
+// a code's counts per length (LDS, u16) checked like zlib's inflate_table: < 0 over-subscribed, > 0 incomplete, 0 complete
+template <int LPW>
+__device__ __forceinline__ int counts_left(const unsigned short (*cnt)[LPW], int n, int lane) {
     if (cnt[0][lane] == n) return 0;   // no codes: complete, but decoding will fail
     int left = 1;
     for (int len = 1; len <= kMaxBits; ++len) {
@@ -196,32 +274,25 @@ __device__ __forceinline__ int construct(Lds& L, unsigned short (*cnt)[LPW], uns
         left -= cnt[len][lane];
         if (left < 0) return left;
     }
-    // offs[len]: where the next symbol of that length goes — kept in LDS by reusing cnt[] after the counts were consumed would
-    // lose them (code_from_counts needs them), so: a running prefix in registers, one pass per length would be 15 passes; instead
-    // the offsets live in a small per-lane array that the compiler keeps in registers (all indices below are select chains)
-    int offs[kMaxBits + 1];
-    offs[0] = 0; offs[1] = 0;
-#pragma unroll
-    for (int len = 1; len < kMaxBits; ++len) offs[len + 1] = offs[len] + cnt[len][lane];
-    if (WIDE) {
-#pragma unroll
-        for (int w = 0; w < kFixLCodes / 32; ++w) L.lhi[w][lane] = 0;
-    }
-    for (int s = 0; s < n; ++s) {
-        const int l = get_len(L, base + s, lane);
-        if (l != 0) {
-            int at = 0;
-#pragma unroll
-            for (int k = 1; k <= kMaxBits; ++k) {
-                const bool here = k == l;
-                at += here ? offs[k] : 0;
-                offs[k] += here ? 1 : 0;
-            }
-            sym[at][lane] = (unsigned char)(s & 0xff);
-            if (WIDE && (s & 0x100)) L.lhi[at >> 5][lane] |= 1u << (at & 31);
-        }
-    }
     return left;
+}
+// where the symbols of each length start in the sorted table (registers; updated through select chains)
+struct Offs { int o[kMaxBits + 1]; };
+template <int LPW>
+__device__ __forceinline__ void offs_from_counts(Offs& f, const unsigned short (*cnt)[LPW], int lane) {
+    f.o[0] = 0; f.o[1] = 0;
+#pragma unroll
+    for (int len = 1; len < kMaxBits; ++len) f.o[len + 1] = f.o[len] + cnt[len][lane];
+}
+__device__ __forceinline__ int offs_take(Offs& f, int l) {      // l in 1..15: the next free slot of that length
+    int at = 0;
+#pragma unroll
+    for (int k = 1; k <= kMaxBits; ++k) {
+        const bool here = k == l;
+        at += here ? f.o[k] : 0;
+        f.o[k] += here ? 1 : 0;
+    }
+    return at;
 }
 
 // token sink of pass 1: literal = the byte; match = bit 31 | length << 16 | (distance - 1)
@@ -264,8 +335,8 @@ __device__ __forceinline__ unsigned take_nr(Bits& b, int n) {   // n <= 16, the 
     b.remaining -= n;
     return v;
 }
-template <bool WIDE, class Lds, int LPW>
-__device__ __forceinline__ int decode_p(Bits& b, const Code& c, const Lds& L, const unsigned char (*sym)[LPW], int lane, bool on) {
+template <int NSYM, class Look>
+__device__ __forceinline__ int decode_p(Bits& b, const Code& c, bool on, Look&& look) {
     const int v = (int)(__brev((unsigned)(b.buf & 0x7fff)) >> 17);
     int len = 1, base = c.bas[1];
 #pragma unroll
@@ -279,11 +350,8 @@ __device__ __forceinline__ int decode_p(Bits& b, const Code& c, const Lds& L, co
     b.buf >>= use;
     b.cnt -= use;
     b.remaining -= use;
-    int idx = (v >> (kMaxBits - len)) + base;
-    idx = min(max(idx, 0), (WIDE ? kFixLCodes : kMaxDCodes) - 1);
-    int s;
-    if (WIDE) s = (int)L.lsym[idx][lane] | (int)(((L.lhi[idx >> 5][lane] >> (idx & 31)) & 1u) << 8);
-    else s = sym[idx][lane];
+    const int idx = min(max((v >> (kMaxBits - len)) + base, 0), NSYM - 1);
+    const int s = look(idx);
     return bad ? -1 : s;
 }
 
@@ -316,8 +384,8 @@ __device__ __forceinline__ void refill_q(Bits& b, InQ& q) {     // branch-free: 
 // straight-line and PREDICATED: every lane runs the literal/length decode, the length extra bits (0 bits unless it holds a match),
 // the distance decode and its extra bits (consuming nothing unless it holds a match); what a lane found is sorted out with
 // selects at the end; the only branches are wave-uniform (no lane holds a match: skip the distance half; no lane is running: leave).
-template <class Lds>
-__device__ __forceinline__ int codes(Bits& b, Out& w, Lds& L, const Code& lc, const Code& dc, int lane) {
+template <class LitLook, class DistLook>
+__device__ __forceinline__ int codes(Bits& b, Out& w, const Code& lc, const Code& dc, LitLook&& lit, DistLook&& dist_sym) {
     InQ q;
     q.cur = b.cur; q.nxt = b.nxt; q.widx = b.widx;
     const uint4* last = b.blk_end - 1 > b.blk_first ? b.blk_end - 1 : b.blk_first;
@@ -341,7 +409,7 @@ __device__ __forceinline__ int codes(Bits& b, Out& w, Lds& L, const Code& lc, co
         }
         const bool run = st < 0;
         refill_q(b, q);                           // >= 33 bits: a literal/length code (15) and its extra bits (5)
-        const int s = decode_p<true>(b, lc, L, L.lsym, lane, run);
+        const int s = decode_p<kFixLCodes>(b, lc, run, lit);
         bool bad = s < 0;
         const bool is_m = s > 256, is_l = s >= 0 && s < 256, eob = s == 256;
         const int ms = s - 257;
@@ -353,7 +421,7 @@ __device__ __forceinline__ int codes(Bits& b, Out& w, Lds& L, const Code& lc, co
         long long dist = 0;
         if (__any(mrun)) {
             refill_q(b, q);                       // >= 33 bits again: a distance code (15) and its extra bits (13)
-            const int ds = decode_p<false>(b, dc, L, L.dsym, lane, mrun);
+            const int ds = decode_p<32>(b, dc, mrun, dist_sym);
             bad = bad || (mrun && (ds < 0 || ds >= 30));
             int dbase, dextra;
             dist_code(min(max(ds, 0), 29), &dbase, &dextra);
@@ -400,6 +468,11 @@ __global__ void __launch_bounds__(kLanes) k_inflate_tokens(const unsigned char* 
     Out w;
     w.tok = tokens + d.tok_off; w.nt = 0; w.o = 0; w.len = d.dst_len;
     Code lc, dc;                   // the current block's two Huffman codes (limits / bases per length, in registers)
+    Hi9 hi = Hi9{0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    // per-length counters of a block header: u16 [32][LPW] over the first 64 rows of lsym (dead while a header is being read)
+    unsigned short (*cnt)[LPW] = reinterpret_cast<unsigned short (*)[LPW]>(&L.lsym[0][0]);
+    auto lit = [&](int i) { return (int)L.lsym[i][lane] | (int)(hi_bit(hi, i) << 8); };
+    auto dist_sym = [&](int i) { return (int)L.dsym[i][lane]; };
     int st = INF_OK;
     if (zlib_wrapped) {
         if (d.src_len < 6) st = INF_EHEADER;
@@ -426,54 +499,62 @@ __global__ void __launch_bounds__(kLanes) k_inflate_tokens(const unsigned char* 
             }
             if (b.over) { st = INF_EINPUT; break; }
         } else if (type == 1) {
-            for (int s = 0; s < 144; ++s) set_len(L, s, lane, 8);
-            for (int s = 144; s < 256; ++s) set_len(L, s, lane, 9);
-            for (int s = 256; s < 280; ++s) set_len(L, s, lane, 7);
-            for (int s = 280; s < kFixLCodes; ++s) set_len(L, s, lane, 8);
-            construct<true>(L, L.lcnt, L.lsym, 0, kFixLCodes, lane);
-            for (int s = 0; s < kMaxDCodes; ++s) set_len(L, s, lane, 5);
-            construct<false>(L, L.dcnt, L.dsym, 0, kMaxDCodes, lane);
-            code_from_counts(lc, L.lcnt, lane);
-            code_from_counts(dc, L.dcnt, lane);
-            st = codes(b, w, L, lc, dc, lane);
+            // fixed codes (RFC 1951 3.2.6), written out sorted by (length, symbol): 256..279 (7 bits), 0..143 and 280..287 (8), 144..255 (9);
+            // 30 distance codes of 5 bits
+            for (int k = 0; k < 32; ++k) cnt[k][lane] = 0;
+            cnt[7][lane] = 24; cnt[8][lane] = 152; cnt[9][lane] = 112; cnt[16 + 5][lane] = kMaxDCodes;
+            code_from_counts(lc, cnt, lane);
+            code_from_counts(dc, cnt + 16, lane);
+            for (int k = 0; k < 24; ++k) L.lsym[k][lane] = (unsigned char)k;                    // 256 + k
+            for (int k = 0; k < 144; ++k) L.lsym[24 + k][lane] = (unsigned char)k;
+            for (int k = 0; k < 8; ++k) L.lsym[168 + k][lane] = (unsigned char)(24 + k);         // 280 + k
+            for (int k = 0; k < 112; ++k) L.lsym[176 + k][lane] = (unsigned char)(144 + k);
+            for (int k = 0; k < kMaxDCodes; ++k) L.dsym[k][lane] = (unsigned char)k;
+            hi = Hi9{0x00ffffffu, 0u, 0u, 0u, 0u, 0x0000ff00u, 0u, 0u, 0u};
+            st = codes(b, w, lc, dc, lit, dist_sym);
         } else if (type == 2) {
             const int nlen = (int)take(b, 5) + 257, ndist = (int)take(b, 5) + 1, ncode = (int)take(b, 4) + 4;
             if (b.over) { st = INF_EINPUT; break; }
             if (nlen > kMaxLCodes || ndist > kMaxDCodes) { st = INF_ETABLE; break; }
-            for (int i = 0; i < 19; ++i) set_len(L, i, lane, 0);
-            for (int i = 0; i < ncode; ++i) set_len(L, cl_order(i), lane, (int)take(b, 3));
+            unsigned long long cl = 0;
+            for (int i = 0; i < ncode; ++i) cl |= (unsigned long long)take(b, 3) << (3 * cl_order(i));
             if (b.over) { st = INF_EINPUT; break; }
-            if (construct<false>(L, L.lcnt, L.dsym, 0, 19, lane) != 0) { st = INF_ETABLE; break; }   // the code-length code must be complete (its 19 symbols borrow dsym)
-            code_from_counts(lc, L.lcnt, lane);
-            int i = 0;
-            while (i < nlen + ndist) {
-                int sym = decode<false>(b, lc, L, L.dsym, lane);
-                if (sym < 0) { st = b.over ? INF_EINPUT : INF_ECODE; break; }
-                if (sym < 16) {
-                    set_len(L, i++, lane, sym);
-                } else {
-                    int rep, val = 0;
-                    if (sym == 16) {
-                        if (i == 0) { st = INF_ETABLE; break; }
-                        val = get_len(L, i - 1, lane);
-                        rep = 3 + (int)take(b, 2);
-                    } else if (sym == 17) rep = 3 + (int)take(b, 3);
-                    else rep = 11 + (int)take(b, 7);
-                    if (b.over) { st = INF_EINPUT; break; }
-                    if (i + rep > nlen + ndist) { st = INF_ETABLE; break; }
-                    while (rep--) set_len(L, i++, lane, val);
-                }
-            }
+            ClCode clc;
+            if (cl_build(clc, cl) != INF_OK) { st = INF_ETABLE; break; }
+            // pass A: count the codes per length (literal/length: cnt[0..15], distance: cnt[16..31])
+            for (int k = 0; k < 32; ++k) cnt[k][lane] = 0;
+            const Bits at_lengths = b;
+            int eob_len = 0;
+            st = walk_lengths(b, clc, nlen + ndist, [&](int i, int len) {
+                cnt[(i < nlen ? 0 : 16) + len][lane]++;
+                eob_len = i == 256 ? len : eob_len;
+            });
             if (st != INF_OK) break;
-            if (get_len(L, 256, lane) == 0) { st = INF_ETABLE; break; }        // no end-of-block code
-            // (the code-length tables in lcnt/lsym are done with: build the real ones; lens[] is read, never written, here)
-            int err = construct<true>(L, L.lcnt, L.lsym, 0, nlen, lane);
-            if (err < 0 || (err > 0 && nlen - L.lcnt[0][lane] != 1)) { st = INF_ETABLE; break; }
-            err = construct<false>(L, L.dcnt, L.dsym, nlen, ndist, lane);
-            if (err < 0 || (err > 0 && ndist - L.dcnt[0][lane] != 1)) { st = INF_ETABLE; break; }
-            code_from_counts(lc, L.lcnt, lane);
-            code_from_counts(dc, L.dcnt, lane);
-            st = codes(b, w, L, lc, dc, lane);
+            if (eob_len == 0) { st = INF_ETABLE; break; }                      // no end-of-block code
+            int err = counts_left(cnt, nlen, lane);
+            if (err < 0 || (err > 0 && nlen - cnt[0][lane] != 1)) { st = INF_ETABLE; break; }
+            err = counts_left(cnt + 16, ndist, lane);
+            if (err < 0 || (err > 0 && ndist - cnt[16][lane] != 1)) { st = INF_ETABLE; break; }
+            code_from_counts(lc, cnt, lane);
+            code_from_counts(dc, cnt + 16, lane);
+            Offs ol, od;
+            offs_from_counts(ol, cnt, lane);
+            offs_from_counts(od, cnt + 16, lane);
+            // pass B: the same bits again; every symbol goes to its place (the counters' rows of lsym are overwritten from here on)
+            hi = Hi9{0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+            b = at_lengths;
+            (void)walk_lengths(b, clc, nlen + ndist, [&](int i, int len) {
+                if (len != 0) {
+                    if (i < nlen) {
+                        const int pos = offs_take(ol, len);
+                        L.lsym[pos][lane] = (unsigned char)(i & 0xff);
+                        if (i & 0x100) hi_set(hi, pos);
+                    } else {
+                        L.dsym[offs_take(od, len)][lane] = (unsigned char)(i - nlen);
+                    }
+                }
+            });
+            st = codes(b, w, lc, dc, lit, dist_sym);
         } else {
             st = INF_ECODE;
         }
@@ -756,6 +837,8 @@ inline void launch_tokens(hipStream_t stream, const unsigned char* comp, long lo
     const int lpw = forced ? forced : (n >= 16384 ? 64 : (n >= 2048 ? 16 : 8));
     if (lpw == 8)
         hipLaunchKernelGGL(k_inflate_tokens<8>, dim3((unsigned)((n + 7) / 8)), dim3(kLanes), 0, stream, comp, comp_len, desc, n, tok, ntok, st, adler, wrapped);
+    else if (lpw == 32)
+        hipLaunchKernelGGL(k_inflate_tokens<32>, dim3((unsigned)((n + 31) / 32)), dim3(kLanes), 0, stream, comp, comp_len, desc, n, tok, ntok, st, adler, wrapped);
     else if (lpw == 16)
         hipLaunchKernelGGL(k_inflate_tokens<16>, dim3((unsigned)((n + 15) / 16)), dim3(kLanes), 0, stream, comp, comp_len, desc, n, tok, ntok, st, adler, wrapped);
     else
