@@ -6,18 +6,21 @@
 // box's container has 16 usable cores -> 10-14 k frames/s in front of a GPU that consumes 226 k.  A
 // 100 k-frame dataset is ~10^6 independent deflate streams: there is no parallelism inside a stream, but there is all
 // the parallelism one could want across them.  So: the COMPRESSED bytes cross PCIe (8.7x fewer than the float64 frames),
-// every lane of every wavefront decodes its own stream into HBM, and a second kernel places the chunks into the
-// channels-last frame tensor (float64 -> float32 on the way: Keras' own cast).
+// every lane of every wavefront decodes its own stream, and the chunks are placed into the channels-last frame tensor
+// (float64 -> float32 on the way: Keras' own cast).
 //
 // Two kernels, because the two halves of DEFLATE parallelise differently:
 //   k_inflate_tokens   one LANE per stream: the Huffman layer (inherently serial per stream, so the parallelism is across
-//                      streams) — the textbook canonical decode by code length (zlib's contrib/puff): symbol tables per
-//                      lane in LDS (lane-interleaved, conflict-free), code counts in registers, the input fetched 16 bytes
-//                      per global load.  It does NOT produce bytes: it writes 32-bit tokens (a literal, or a match of
-//                      length L at distance D), so it never reads its own output back.
-//   k_lz_resolve       one WAVEFRONT per stream: the LZ77 layer in LDS — literals of 64 tokens land in parallel (wave
-//                      prefix sum of the lengths), matches are copied 64 bytes per step out of a 16-64 KB window of the
-//                      output that lives in LDS, and finished bytes leave for HBM in coalesced 8-byte stores.
+//                      streams) — canonical decode by code length without a data-dependent loop, the two sorted symbol tables
+//                      per lane in LDS (320 B per stream: eight wavefronts per CU), everything else in registers, a predicated
+//                      straight-line symbol loop, all memory traffic at wave-synchronous points.  It does NOT produce bytes:
+//                      it writes 32-bit tokens (a literal, or a match of length L at distance D), so it never reads its own
+//                      output back; it also hands the zlib trailer (Adler-32) to the second kernel.
+//   k_lz_resolve       one WAVEFRONT per stream: the LZ77 layer in LDS — literals of 64 tokens land in parallel (DPP prefix
+//                      sum of the lengths), every match is copied in one step by the whole wavefront, the stream's Adler-32
+//                      is verified, and a chunk that fits the LDS window whole is placed from there straight into its frame
+//                      (float64 -> float32 on the way); longer streams go round a 64 KB ring and leave in 8-byte stores for
+//                      k_place_chunks.
 // A first, single-kernel version (a lane emitting bytes into HBM and reading far matches back from there) spent 64 ms on
 // the 32 768 chunks of a 1 024-frame batch: every read-back of a lane's own earlier store waits for the wave's whole store
 // queue, and with 64 independent streams per wave some lane is always at such a point.
