@@ -693,17 +693,22 @@ __global__ void __launch_bounds__(kLanes) k_lz_resolve(const unsigned* tokens, c
         // matches, one after the other (a match may copy what an earlier one of the batch produced), each in ONE step by the
         // whole wavefront: byte k of a match is byte (k mod distance) of the `distance` bytes in front of it, which are final —
         // so all (at most 258) bytes are independent; lane l takes bytes l, l + 64, ... : every read is issued before any write
+        // what the serial loop needs of a match is worked out by its own lane, all 64 at once (the reciprocal above all), and
+        // fetched with v_readlane: nothing but the copy itself is left on the one-match-after-the-other chain
+        const int mdist_l = (int)(tk & 0x7fff) + 1;
+        const float inv_l = 1.0f / (float)mdist_l;
+        const unsigned to_l = (unsigned)pos;
         unsigned long long mm = __ballot(is_m);
         while (mm) {
             const int l = __ffsll((long long)mm) - 1;
             mm &= mm - 1;
             const int mlen = __builtin_amdgcn_readlane(len, l);
-            const int mdist = (__builtin_amdgcn_readlane((int)tk, l) & 0x7fff) + 1;
-            const unsigned to = (unsigned)(__builtin_amdgcn_readlane((int)(pos - o), l) + o);
+            const int mdist = __builtin_amdgcn_readlane(mdist_l, l);
+            const unsigned to = (unsigned)__builtin_amdgcn_readlane((int)to_l, l);
             const unsigned from = to - (unsigned)mdist;
             // (k mod mdist by a float reciprocal + one correction step: exact for k < 320, mdist <= 32768; the reads of lanes
             // beyond the match fetch some byte of the ring and are dropped — no branch between the reads, so they overlap)
-            const float inv = 1.0f / (float)mdist;
+            const float inv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inv_l), l));
             auto copy = [&](auto nb) {
                 constexpr int NB = decltype(nb)::value;
                 unsigned char v[NB];
