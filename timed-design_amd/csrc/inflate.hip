@@ -615,7 +615,7 @@ __device__ __forceinline__ int wave_scan_incl(int v) {
 // then resolved one after the other (a match may copy what an earlier match of the same batch produced), each in one step by all
 // 64 lanes.
 __global__ void __launch_bounds__(kLanes) k_lz_resolve(const unsigned* tokens, const long long* ntok, const InfDesc* desc, long long n,
-                                                       unsigned char* out, int* status, unsigned M, const PlaceArgs pa, int fused, const unsigned* adler, int check) {
+                                                       unsigned char* out, int* status, unsigned M, const PlaceArgs pa, int fused, const unsigned* adler, int check, unsigned dump_whole) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ring[];
     const long long idx = blockIdx.x;
     if (idx >= n || status[idx] != INF_OK) return;
@@ -709,26 +709,44 @@ __global__ void __launch_bounds__(kLanes) k_lz_resolve(const unsigned* tokens, c
             // (k mod mdist by a float reciprocal + one correction step: exact for k < 320, mdist <= 32768; the reads of lanes
             // beyond the match fetch some byte of the ring and are dropped — no branch between the reads, so they overlap)
             const float inv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inv_l), l));
-            auto copy = [&](auto nb) {
+            // lanes beyond the match write to a dump byte (one select) instead of being masked out (a compare, an exec save /
+            // restore and a branch per 64-byte block); a match that does not overlap itself (distance >= length: most matches
+            // that are not runs) needs no folding at all
+            // (ring: the batch ends at most 64 * 258 bytes after its start `o`, and nothing older than o - 32 776 is still
+            // unflushed: o + 20 480 is neither)
+            const unsigned dump = M == 0xffffffffu ? dump_whole : (((unsigned)o + 20480u) & M);
+            auto copy = [&](auto nb, auto wrap_c) {
                 constexpr int NB = decltype(nb)::value;
+                constexpr bool WRAP = decltype(wrap_c)::value;
                 unsigned char v[NB];
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
-                    const int k = lane + kLanes * j;
-                    int r = k - (int)((float)k * inv) * mdist;
-                    if (r < 0) r += mdist;
-                    if (r >= mdist) r -= mdist;
+                    const int k = min(lane + kLanes * j, mlen - 1);
+                    int r = k;
+                    if (WRAP) {
+                        r = k - (int)((float)k * inv) * mdist;
+                        if (r < 0) r += mdist;
+                        if (r >= mdist) r -= mdist;
+                    }
                     v[j] = ring[(from + (unsigned)r) & M];
                 }
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
                     const int k = lane + kLanes * j;
-                    if (k < mlen) ring[(to + (unsigned)k) & M] = v[j];
+                    ring[k < mlen ? ((to + (unsigned)k) & M) : dump] = v[j];
                 }
             };
-            if (mlen <= kLanes) copy(std::integral_constant<int, 1>{});
-            else if (mlen <= 2 * kLanes) copy(std::integral_constant<int, 2>{});
-            else copy(std::integral_constant<int, 5>{});
+            const std::true_type yes{};
+            const std::false_type no{};
+            if (mdist >= mlen) {
+                if (mlen <= kLanes) copy(std::integral_constant<int, 1>{}, no);
+                else if (mlen <= 2 * kLanes) copy(std::integral_constant<int, 2>{}, no);
+                else copy(std::integral_constant<int, 5>{}, no);
+            } else {
+                if (mlen <= kLanes) copy(std::integral_constant<int, 1>{}, yes);
+                else if (mlen <= 2 * kLanes) copy(std::integral_constant<int, 2>{}, yes);
+                else copy(std::integral_constant<int, 5>{}, yes);
+            }
             wave_sync();
         }
         o += total;
@@ -856,10 +874,10 @@ inline void launch_tokens(hipStream_t stream, const unsigned char* comp, long lo
 // LDS window of k_lz_resolve for streams of at most max_len bytes
 // (a stream that fits is kept whole — its LDS is its length and positions are used as they are, mask ~0 —, so 17 KB chunks
 // run 9 wavefronts per CU instead of the 5 a 32 KB power-of-two ring allows; longer streams go round a 64 KB ring)
-struct RingGeom { unsigned lds, mask; };
+struct RingGeom { unsigned lds, mask, spare; };      // spare: bytes behind the window (a whole stream gets a dump byte there)
 inline RingGeom ring_geom(int64_t max_len) {
-    if (max_len <= 61440) return {(unsigned)((std::max<int64_t>(max_len, 16) + 15) & ~15ll), 0xffffffffu};
-    return {65536u, 65535u};
+    if (max_len <= 61440) return {(unsigned)((std::max<int64_t>(max_len, 16) + 15) & ~15ll), 0xffffffffu, 16u};
+    return {65536u, 65535u, 0u};
 }
 
 struct DevBuf {
@@ -923,7 +941,7 @@ extern "C" int th_inflate_many(int device, const void* comp, int64_t comp_len, i
     if (!rc) {
         const RingGeom rg = ring_geom(max_len);
         if ((e = hipFuncSetAttribute((const void*)k_lz_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)) != hipSuccess) fail(e, "attribute");
-        hipLaunchKernelGGL(k_lz_resolve, dim3((unsigned)n), dim3(kLanes), rg.lds, 0, d_tok, d_nt, d_desc, (long long)n, d_out, d_st, rg.mask, PlaceArgs{}, 0, d_ad, wrapped ? 1 : 0);
+        hipLaunchKernelGGL(k_lz_resolve, dim3((unsigned)n), dim3(kLanes), rg.lds + rg.spare, 0, d_tok, d_nt, d_desc, (long long)n, d_out, d_st, rg.mask, PlaceArgs{}, 0, d_ad, wrapped ? 1 : 0, rg.lds);
         if (!rc && (e = hipGetLastError()) != hipSuccess) fail(e, "launch");
     }
     if (!rc && (e = hipDeviceSynchronize()) != hipSuccess) fail(e, "kernel");
@@ -1005,9 +1023,9 @@ int inflate_place_device(int device, hipStream_t stream, const void* span, int64
     {
         const RingGeom rg = ring_geom(chunk_bytes);
         HIP_TRY(hipFuncSetAttribute((const void*)k_lz_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-        hipLaunchKernelGGL(k_lz_resolve, dim3((unsigned)n_chunks), dim3(kLanes), rg.lds, stream, (const unsigned*)d_tok.p, (const long long*)d_nt.p,
+        hipLaunchKernelGGL(k_lz_resolve, dim3((unsigned)n_chunks), dim3(kLanes), rg.lds + rg.spare, stream, (const unsigned*)d_tok.p, (const long long*)d_nt.p,
                            (const InfDesc*)d_desc.p, (long long)n_chunks, (unsigned char*)d_raw.p, (int*)d_st.p, rg.mask, a, fused ? 1 : 0,
-                           (const unsigned*)d_ad.p, 1);
+                           (const unsigned*)d_ad.p, 1, rg.lds);
         HIP_TRY(hipGetLastError());
     }
     if (!fused) {
