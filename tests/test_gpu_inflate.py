@@ -361,3 +361,20 @@ def test_corrupt_chunk_in_an_hdf5_file_is_an_error_not_a_frame(gpu, tmp_path):
             good_rows = fmap[[0, 1, 3, 4]]                                      # the other residues are intact
             assert utils.load_batch_device(p, good_rows, device=gpu) is not None
     utils._H5_KEEP.clear()
+
+
+@pytest.mark.parametrize("lpw", [8, 16, 32, 64])
+def test_every_streams_per_wavefront_instantiation(gpu, lib, monkeypatch, lpw):
+    """k_inflate_tokens<8 | 16 | 32 | 64> (the batch size picks one; TH_INFLATE_LPW forces it): the same 150 streams of every
+    block type, partly filling the last wavefront, through each instantiation"""
+    monkeypatch.setenv("TH_INFLATE_LPW", str(lpw))
+    rng = np.random.default_rng(77)
+    payloads = _payloads(rng)
+    streams, sizes, want = [], [], []
+    for k in range(150):
+        p = payloads[k % len(payloads)]
+        c = zlib.compressobj([0, 1, 6, 9][k % 4], zlib.DEFLATED, 15, 8, zlib.Z_FIXED if k % 7 == 0 else zlib.Z_DEFAULT_STRATEGY)
+        streams.append(c.compress(p) + c.flush()); sizes.append(len(p)); want.append(p)
+    rc, status, got, _ = _inflate(lib, gpu, streams, sizes)
+    assert rc == 0 and not status.any()
+    assert all(a == b for a, b in zip(got, want))

@@ -856,11 +856,12 @@ __global__ void k_place_chunks(const PlaceArgs a, long long n_chunks) {
 // streams per wavefront (see LdsT)
 inline void launch_tokens(hipStream_t stream, const unsigned char* comp, long long comp_len, const InfDesc* desc, long long n, unsigned* tok,
                           long long* ntok, int* st, unsigned* adler, int wrapped) {
-    static const int forced = getenv("TH_INFLATE_LPW") ? atoi(getenv("TH_INFLATE_LPW")) : 0;     // A/B: 8, 16 or 64
-    // measured (gzip float64 frames, 17 KB chunks): a wavefront costs the same instruction slots with 8 active lanes as with 64,
-    // and the streams in flight are bounded by LDS (580 B each) either way — 131 k streams ran 10.0 / 11.3 / 16.1 ms at LPW
-    // 64 / 16 / 8 (before the predicated loop; 5.9 ms at 64 now).  Few streams: spread them over the CUs.
-    const int lpw = forced ? forced : (n >= 16384 ? 64 : (n >= 2048 ? 16 : 8));
+    const char* env = getenv("TH_INFLATE_LPW");     // A/B and tests: 8, 16, 32 or 64 (read at every call)
+    const int forced = env ? atoi(env) : 0;
+    // measured (gzip float64 frames, 17 KB chunks, after the LDS diet): 64 streams per wavefront are the fastest or tied at every
+    // batch size — 8 192 streams: 5.5 / 3.9 / 3.3 / 3.2 ms at LPW 8 / 16 / 32 / 64 (the chain of one stream is ~3.2 ms);
+    // 32 768 streams: 6.5 / 3.7 / 3.7 / 3.2 ms; 131 072 streams: 3.9 ms at 64.  Fewer only when there are hardly any streams.
+    const int lpw = forced ? forced : (n >= 512 ? 64 : (n >= 64 ? 16 : 8));
     if (lpw == 8)
         hipLaunchKernelGGL(k_inflate_tokens<8>, dim3((unsigned)((n + 7) / 8)), dim3(kLanes), 0, stream, comp, comp_len, desc, n, tok, ntok, st, adler, wrapped);
     else if (lpw == 32)
