@@ -238,7 +238,9 @@ int th_h5_read_contiguous_as(const void* file, int64_t file_len, int64_t base, i
  * COMPRESSED chunk bytes are copied to the GPU as they lie in the file, inflated there one lane per chunk, and placed into d_out —
  * device memory on `device`, [n_datasets][shape...] of float32 when conv = 1 (float64 data: the cast Keras applies) or of the
  * stored element type when conv = 0.  Supports the pipeline aposteriori writes (n_filters = 1, filter id 1 = deflate, every chunk
- * compressed); TH_EUNSUP for anything else (use th_h5_read_chunked_as).  Never-allocated chunks read as zeros.  Synchronous. */
+ * compressed) and shuffle + deflate (filter ids {2, 1}: h5py's compression="gzip", shuffle=True; chunks up to 60 KB); TH_EUNSUP
+ * for anything else (use th_h5_read_chunked_as).  Every chunk's Adler-32 is verified as zlib does: a chunk that does not inflate
+ * to its declared size or fails the check is TH_EIO.  Never-allocated chunks read as zeros.  Synchronous. */
 int th_h5_decode_device(const void* file, int64_t file_len, int64_t base, int64_t n_datasets, const int64_t* btree_addrs, int rank,
                         const int64_t* shape, const int64_t* chunk, int esz, int n_filters, const int* filter_ids, int conv, int device,
                         void* d_out);

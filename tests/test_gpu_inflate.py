@@ -378,3 +378,29 @@ def test_every_streams_per_wavefront_instantiation(gpu, lib, monkeypatch, lpw):
     rc, status, got, _ = _inflate(lib, gpu, streams, sizes)
     assert rc == 0 and not status.any()
     assert all(a == b for a, b in zip(got, want))
+
+
+@pytest.mark.parametrize("name", ["frames_tiny.hdf5", "frames_tiny_bool.hdf5"])
+def test_shuffle_plus_deflate_residues_of_the_h5py_fixtures_decode_on_the_gpu(gpu, name):
+    """the real-h5py fixtures hold residues written with shuffle=True + gzip (filter pipeline 2, 1) and with gzip alone: both
+    pipelines are decoded on the device (the unshuffle happens while the chunk is placed from LDS) and equal the host reader,
+    which test_host_utils.py pins to h5py's own read; float32 Gaussian frames are placed as they are"""
+    import os
+    import warnings
+    from design_utils import utils
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    path = os.path.join(G, name)
+    shuffled = np.array([("1ubq", "A", "3", "ALA"), ("1ubq", "A", "9", "ALA"), ("2xyz_0", "A", "3", "ALA"), ("2xyz_0", "B", "3", "ALA"),
+                         ("2xyz_0", "B", "9", "ALA")])
+    plain = np.array([("1ubq", "A", "11", "ALA"), ("1ubq", "A", "13", "ALA"), ("2xyz_0", "B", "5", "ALA"), ("2xyz_0", "B", "7", "ALA")])
+    utils._H5_KEEP.clear()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for rows in (shuffled, plain):
+            X, y = utils.load_batch(path, rows, dtype=np.float32)
+            got = utils.load_batch_device(path, rows, device=gpu)
+            assert got is not None, "deflate and shuffle + deflate residues must take the device path"
+            dev, yd = got
+            assert dev.shape == X.shape and np.array_equal(yd, y)
+            assert np.array_equal(dev.buffer.download(dev.shape, dev.dtype).astype(X.dtype), X)
+    utils._H5_KEEP.clear()

@@ -283,7 +283,7 @@ bool collect(const Geometry& g, uint64_t addr, int ds, std::vector<ChunkRec>* ou
 
 int inflate_place_device(int device, hipStream_t stream, const void* span, int64_t span_len, int64_t n_chunks, const int64_t* src_off,
                          const int64_t* csize, const int* ds, const int* coff8, int rank, const int64_t* shape, const int64_t* chunk, int esz,
-                         int conv, void* d_out, int64_t* n_bad);
+                         int conv, void* d_out, int64_t* n_bad, int shuffle);
 
 extern "C" int th_h5_decode_device(const void* file, int64_t file_len, int64_t base, int64_t n_datasets, const int64_t* btree_addrs, int rank,
                                    const int64_t* shape, const int64_t* chunk, int esz, int n_filters, const int* filter_ids, int conv,
@@ -291,7 +291,10 @@ extern "C" int th_h5_decode_device(const void* file, int64_t file_len, int64_t b
     if (!file || file_len <= 0 || n_datasets < 0 || (n_datasets && (!btree_addrs || !d_out)) || !shape || !chunk)
         TH_FAIL(TH_EINVAL, "th_h5_decode_device: null argument");
     if (rank < 1 || rank > 7 || esz < 1) TH_FAIL(TH_EUNSUP, "th_h5_decode_device: rank %d / element size %d not supported", rank, esz);
-    if (n_filters != 1 || !filter_ids || filter_ids[0] != 1) TH_FAIL(TH_EUNSUP, "th_h5_decode_device: only the deflate-only pipeline is decoded on the device");
+    // pipelines decoded on the device: deflate, or shuffle + deflate (what h5py writes for compression="gzip"[, shuffle=True])
+    const bool plain = n_filters == 1 && filter_ids && filter_ids[0] == 1;
+    const bool shuffled = n_filters == 2 && filter_ids && filter_ids[0] == 2 && filter_ids[1] == 1;
+    if (!plain && !shuffled) TH_FAIL(TH_EUNSUP, "th_h5_decode_device: only deflate and shuffle + deflate pipelines are decoded on the device");
     if (conv != 0 && !(conv == 1 && esz == 8)) TH_FAIL(TH_EINVAL, "th_h5_decode_device: conversion %d needs float64 elements", conv);
     if (n_datasets == 0) return TH_OK;
     static const bool trace = getenv("TH_H5_TRACE") != nullptr;
@@ -380,7 +383,7 @@ extern "C" int th_h5_decode_device(const void* file, int64_t file_len, int64_t b
     const double t_prep = since();
     int64_t bad = 0;
     int rc = inflate_place_device(device, nullptr, span, span_len, (int64_t)nch, src_off.data(), csize.data(), ds.data(), coff.data(), rank,
-                                  shape, chunk, esz, conv, d_out, &bad);
+                                  shape, chunk, esz, conv, d_out, &bad, shuffled ? 1 : 0);
     if (trace)
         fprintf(stderr, "[h5 decode] %lld datasets, %zu chunks, span %.1f MB (%s): B-trees %.2f ms, memset + descriptors %.2f ms, copy + kernels %.2f ms\n",
                 (long long)n_datasets, nch, span_len / 1e6, gathered.empty() ? "direct" : "gathered", t_walk, t_prep - t_walk, since() - t_prep);

@@ -586,6 +586,7 @@ struct PlaceArgs {
     int rank; int shape[8]; int cdim[8]; int esz; int conv;
     unsigned char* out; long long out_elems;   // elements per dataset in the output
     unsigned celems;                           // elements per chunk
+    int shuffle;                               // HDF5 shuffle filter under the deflate: byte b of element e is raw[b * celems + e]
 };
 // k_lz_resolve's workgroup IS one wavefront: the LDS executes a wavefront's operations in issue order, so what one lane wrote
 // is visible to the next read of any lane — all that is needed is that the compiler keeps the order.  (__syncthreads() would
@@ -791,7 +792,18 @@ __global__ void __launch_bounds__(kLanes) k_lz_resolve(const unsigned* tokens, c
                 }
                 if (inside) {
                     if (pa.conv == 1) {
-                        reinterpret_cast<float*>(dd)[oidx] = (float)*reinterpret_cast<const double*>(ring + 8ull * e);
+                        double v;
+                        if (pa.shuffle) {              // the 8 bytes of element e lie one in each byte plane
+                            unsigned long long u = 0;
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) u |= (unsigned long long)ring[(unsigned)k * pa.celems + e] << (8 * k);
+                            v = __builtin_bit_cast(double, u);
+                        } else {
+                            v = *reinterpret_cast<const double*>(ring + 8ull * e);
+                        }
+                        reinterpret_cast<float*>(dd)[oidx] = (float)v;
+                    } else if (pa.shuffle) {
+                        for (int k = 0; k < pa.esz; ++k) dd[oidx * pa.esz + k] = ring[(unsigned)k * pa.celems + e];
                     } else {
                         for (int k = 0; k < pa.esz; ++k) dd[oidx * pa.esz + k] = ring[(unsigned long long)e * pa.esz + k];
                     }
@@ -967,7 +979,7 @@ extern "C" int th_inflate_many(int device, const void* comp, int64_t comp_len, i
 // and placed into d_out [n_datasets][shape...] (float32 when conv = 1 and the data is float64, the stored type otherwise).
 int inflate_place_device(int device, hipStream_t stream, const void* span, int64_t span_len, int64_t n_chunks, const int64_t* src_off,
                          const int64_t* csize, const int* ds, const int* coff8, int rank, const int64_t* shape, const int64_t* chunk, int esz,
-                         int conv, void* d_out, int64_t* n_bad) {
+                         int conv, void* d_out, int64_t* n_bad, int shuffle) {
     // Scratch memory with its own (non-blocking) stream, one caller at a time per device.  (Measured with TWO sets per device and
     // two loader threads in predict.py, so that the pageable upload of one batch runs under the kernels of the other: each call then
     // took twice as long — the same 0.38 s for 40 k frames warm — and the first call of a process paid for a second 9 GB token
@@ -996,6 +1008,7 @@ int inflate_place_device(int device, hipStream_t stream, const void* span, int64
     int rc;
     // a chunk that fits the LDS window whole is placed by k_lz_resolve itself: no raw bytes in HBM, no placement kernel
     const bool fused = ring_geom(chunk_bytes).mask == 0xffffffffu && chunk_bytes / esz < (1ll << 31);
+    if (shuffle && !fused) TH_FAIL(TH_EUNSUP, "inflate: a shuffled chunk of %lld bytes does not fit the LDS window", (long long)chunk_bytes);
     if ((rc = d_comp.ensure((size_t)span_len + 16)) || (rc = d_raw.ensure(fused ? 16 : (size_t)(n_chunks * cb8) + 16)) ||
         (rc = d_desc.ensure((size_t)n_chunks * sizeof(InfDesc))) || (rc = d_st.ensure((size_t)n_chunks * sizeof(int))) ||
         (rc = d_ds.ensure((size_t)n_chunks * sizeof(int))) || (rc = d_coff.ensure((size_t)n_chunks * 8 * sizeof(int))) ||
@@ -1021,6 +1034,7 @@ int inflate_place_device(int device, hipStream_t stream, const void* span, int64
     for (int d = 0; d < 8; ++d) { a.shape[d] = d < rank ? (int)shape[d] : 1; a.cdim[d] = d < rank ? (int)chunk[d] : 1; }
     for (int d = 0; d < rank; ++d) a.out_elems *= shape[d];
     a.celems = (unsigned)(chunk_bytes / esz);
+    a.shuffle = shuffle;
     {
         const RingGeom rg = ring_geom(chunk_bytes);
         HIP_TRY(hipFuncSetAttribute((const void*)k_lz_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));

@@ -419,6 +419,8 @@ def _load_batch_device(dataset, data_point_batch, n, device):
         cls, esz = int(g[16]), int(g[15])
         if gaussian and cls == 1 and esz == 8:
             dtype, as_f32 = np.float32, True
+        elif gaussian and cls == 1 and esz == 4:          # frames stored as float32: placed as they are
+            dtype, as_f32 = np.float32, False
         elif not gaussian and esz == 1 and cls in (0, 8):
             dtype, as_f32 = np.uint8, False
         else:

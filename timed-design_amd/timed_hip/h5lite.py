@@ -864,7 +864,7 @@ def decode_resolved_device(f: File, resolved: dict, d_out: int, device: int, as_
     if int(g[27]) != 2 or rank < 1 or cls not in (0, 1, 8) or (as_float32 and not (cls == 1 and esz == 8)):
         return False
     filters = [int(x) for x in g[19:19 + nf]]
-    if filters != [1]:
+    if filters not in ([1], [2, 1]):            # deflate, or shuffle + deflate
         return False
     shape, chunk = [int(x) for x in g[1:1 + rank]], [int(x) for x in g[8:8 + rank]]
     n = len(resolved["btree"])
@@ -872,8 +872,8 @@ def decode_resolved_device(f: File, resolved: dict, d_out: int, device: int, as_
     whole = np.frombuffer(f._m, dtype=np.uint8)
     try:
         rc = lib.th_h5_decode_device(whole.ctypes.data_as(C.c_void_p), whole.size, f._base, n, addrs.ctypes.data_as(C.POINTER(C.c_int64)), rank,
-                                     (C.c_int64 * rank)(*shape), (C.c_int64 * rank)(*chunk), esz, 1, (C.c_int * 1)(1),
-                                     1 if as_float32 else 0, int(device), C.c_void_p(int(d_out)))
+                                     (C.c_int64 * rank)(*shape), (C.c_int64 * rank)(*chunk), esz, len(filters),
+                                     (C.c_int * len(filters))(*filters), 1 if as_float32 else 0, int(device), C.c_void_p(int(d_out)))
     finally:
         del whole
     if rc == -4:            # TH_EUNSUP: not an error, just not this path
