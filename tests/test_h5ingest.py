@@ -459,3 +459,51 @@ def test_native_map_path_does_not_depend_on_h5py_being_absent(monkeypatch):
     with pytest.raises(RuntimeError, match="h5py.File was called"):
         utils.create_flat_dataset_map(bogus)
     utils._H5_KEEP.clear()
+
+
+def test_fletcher32_is_verified_by_both_host_readers(tmp_path):
+    """tests/golden/frames_fletcher.hdf5 (real h5py: fletcher32 alone, over gzip, over shuffle + gzip, and on a multi-chunk
+    dataset): HDF5 checks the checksum on every read and fails the read on a mismatch.  Both readers here reproduce the
+    library's checksums (the intact file reads back exactly) and refuse a chunk with one flipped data byte."""
+    import struct
+    z = np.load(os.path.join(G, "frames_fletcher_expected.npz"))["frames"]
+    path = os.path.join(G, "frames_fletcher.hdf5")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fmap, _ = utils.create_flat_dataset_map(path)
+        X, y = utils.load_batch(path, fmap, dtype=np.float32)                      # the native threaded reader
+    assert np.array_equal(X, z) and [r[2] for r in fmap] == ["1", "2", "3", "4"]
+    with h5lite.File(path) as f:                                                   # the pure-Python reader
+        for r in range(4):
+            assert np.array_equal(np.asarray(f["1abc"]["A"][str(r + 1)][()]), z[r])
+        btree, _shape, chunk, _esz, filters = f["1abc"]["A"]["1"].chunked_geometry()
+        assert filters == (3,)
+        a = f._base + btree
+        csize = struct.unpack_from("<I", f._m, a + 24)[0]
+        child = struct.unpack_from("<Q", f._m, a + 24 + 8 + 8 * (len(chunk) + 1))[0] + f._base
+    data = bytearray(open(path, "rb").read())
+    data[child + csize // 2] ^= 0x04
+    bad = tmp_path / "bad.hdf5"
+    bad.write_bytes(bytes(data))
+    with h5lite.File(str(bad)) as f:
+        with pytest.raises(h5lite.H5FormatError, match="fletcher32"):
+            f["1abc"]["A"]["1"][()]
+        assert np.array_equal(np.asarray(f["1abc"]["A"]["2"][()]), z[1])          # the other datasets are intact
+    from timed_hip import _lib
+    lib = _lib.load()
+    with h5lite.File(str(bad)) as f:                                               # the native reader declines the chunk ...
+        ds = f["1abc"]["A"]["1"]
+        geo = ds.chunked_geometry()
+        dest = np.empty(ds.shape, np.float32)
+        import ctypes as C
+        whole = np.frombuffer(f._m, dtype=np.uint8)
+        rc = lib.th_h5_read_chunked(whole.ctypes.data_as(C.c_void_p), whole.size, f._base, 1, (C.c_int64 * 1)(geo[0]),
+                                    (C.c_void_p * 1)(dest.ctypes.data), 4, (C.c_int64 * 4)(*geo[1]), (C.c_int64 * 4)(*geo[2]), 4, 1,
+                                    (C.c_int * 1)(3), 1)
+        del whole
+        assert rc != 0 and b"fletcher32" in lib.th_last_error()
+    with warnings.catch_warnings():                                                # ... and load_batch as a whole raises
+        warnings.simplefilter("ignore")
+        with pytest.raises(h5lite.H5FormatError, match="fletcher32"):
+            utils.load_batch(str(bad), fmap, dtype=np.float32)
+    utils._H5_KEEP.clear()

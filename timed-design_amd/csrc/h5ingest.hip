@@ -66,6 +66,35 @@ template <typename T> inline T rd(const uint8_t* p) { T v; std::memcpy(&v, p, si
 
 struct Scratch { std::vector<uint8_t> a, b; };
 
+// The checksum of HDF5's fletcher32 filter: two sums over big-endian 16-bit words, folded with end-around carry every 360 words
+// (so that 32-bit accumulators cannot overflow), an odd last byte counted as the high byte of a word.  `swapped`: the variant over
+// byte-swapped words that libraries before 1.6.3 wrote — the library accepts either when it reads.
+uint32_t h5_fletcher32(const uint8_t* data, size_t nbytes, bool swapped) {
+    size_t len = nbytes / 2;
+    uint32_t sum1 = 0, sum2 = 0;
+    const int hi = swapped ? 1 : 0, lo = swapped ? 0 : 1;
+    while (len) {
+        size_t tlen = len > 360 ? 360 : len;
+        len -= tlen;
+        do {
+            sum1 += ((uint32_t)data[hi] << 8) | (uint32_t)data[lo];
+            data += 2;
+            sum2 += sum1;
+        } while (--tlen);
+        sum1 = (sum1 & 0xffff) + (sum1 >> 16);
+        sum2 = (sum2 & 0xffff) + (sum2 >> 16);
+    }
+    if (nbytes % 2) {
+        sum1 += (uint32_t)*data << 8;
+        sum2 += sum1;
+        sum1 = (sum1 & 0xffff) + (sum1 >> 16);
+        sum2 = (sum2 & 0xffff) + (sum2 >> 16);
+    }
+    sum1 = (sum1 & 0xffff) + (sum1 >> 16);
+    sum2 = (sum2 & 0xffff) + (sum2 >> 16);
+    return (sum2 << 16) | sum1;
+}
+
 // undo the filter pipeline of one chunk; returns a pointer to chunk_bytes of data or nullptr
 const uint8_t* unfilter(const Geometry& g, const uint8_t* src, size_t len, uint32_t mask, Scratch& s, std::string* err) {
     const uint8_t* cur = src;
@@ -75,10 +104,16 @@ const uint8_t* unfilter(const Geometry& g, const uint8_t* src, size_t len, uint3
         if (mask & (1u << i)) continue;
         std::vector<uint8_t>& dst = use_a ? s.a : s.b;
         switch (g.filters[i]) {
-            case 3:   // fletcher32: checksum appended
+            case 3: {  // fletcher32: checksum appended (little-endian); HDF5 fails the read when it does not match
                 if (cur_len < 4) { *err = "fletcher32 chunk shorter than its checksum"; return nullptr; }
                 cur_len -= 4;
+                const uint32_t stored = rd<uint32_t>(cur + cur_len);
+                if (stored != h5_fletcher32(cur, cur_len, false) && stored != h5_fletcher32(cur, cur_len, true)) {
+                    *err = "fletcher32 checksum of a chunk does not match its data";
+                    return nullptr;
+                }
                 break;
+            }
             case 1: {  // deflate
                 dst.resize((size_t)g.chunk_bytes + 8);
                 uLongf out_len = (uLongf)dst.size();

@@ -37,6 +37,14 @@ def open_frame_dataset(path):
         return h5lite.File(str(path))
 
 
+def _have_h5py() -> bool:
+    try:
+        import h5py  # type: ignore  # noqa: F401
+        return True
+    except ImportError:
+        return False
+
+
 def _as_str(v) -> str:
     if isinstance(v, bytes):
         return v.decode()
@@ -98,9 +106,7 @@ def create_flat_dataset_map(
         try:
             return _flat_map_of(kept, filter_list, remove_blacklist_silently, uncommon)
         except (h5lite.H5Unsupported, h5lite.H5FormatError):
-            try:                         # a file feature h5lite does not read: h5py's job, when it is there
-                import h5py  # noqa: F401
-            except ImportError:
+            if not _have_h5py():         # a file feature h5lite does not read: h5py's job, when it is there
                 raise
     with open_frame_dataset(frame_dataset) as dataset_file:
         return _flat_map_of(dataset_file, filter_list, remove_blacklist_silently, uncommon)
@@ -256,9 +262,7 @@ def load_batch(dataset_path: Path, data_point_batch: t.List[t.Tuple], dtype=None
         try:
             return _load_batch_from(kept, data_point_batch, dtype, out)
         except (h5lite.H5Unsupported, h5lite.H5FormatError):
-            try:
-                import h5py  # noqa: F401
-            except ImportError:
+            if not _have_h5py():
                 raise
     with open_frame_dataset(dataset_path) as dataset:
         return _load_batch_from(dataset, data_point_batch, dtype, out)

@@ -334,6 +334,35 @@ class _Object:
         return self._attrs
 
 
+def fletcher32(data: bytes) -> Tuple[int, int]:
+    """The checksum of HDF5's fletcher32 filter over ``data`` — two 16-bit one's-complement style sums over big-endian 16-bit
+    words, an odd last byte taken as the high byte of a word — and the variant over byte-swapped words that libraries before
+    1.6.3 wrote; the library accepts either on read (and fails the read otherwise), so do the readers here."""
+    def run(words: np.ndarray, tail: Optional[int]) -> int:
+        s1 = s2 = 0
+        w = words.astype(np.uint64)
+        for lo in range(0, len(w), 360):                       # the library folds every 360 words; folding is exact mod 65535,
+            blk = w[lo:lo + 360]                                # so the blocks only have to be small enough not to overflow
+            n = len(blk)
+            s2 += n * s1 + int((blk * np.arange(n, 0, -1, dtype=np.uint64)).sum())
+            s1 += int(blk.sum())
+            s1 = (s1 & 0xffff) + (s1 >> 16)
+            s2 = (s2 & 0xffff) + (s2 >> 16)
+        if tail is not None:
+            s1 += tail << 8
+            s2 += s1
+            s1 = (s1 & 0xffff) + (s1 >> 16)
+            s2 = (s2 & 0xffff) + (s2 >> 16)
+        s1 = (s1 & 0xffff) + (s1 >> 16)
+        s2 = (s2 & 0xffff) + (s2 >> 16)
+        return ((s2 & 0xffff) << 16) | (s1 & 0xffff)
+    buf = np.frombuffer(data, dtype=np.uint8)
+    n2 = len(buf) // 2
+    pairs = buf[:2 * n2].reshape(n2, 2).astype(np.uint16)
+    tail = int(buf[-1]) if len(buf) % 2 else None
+    return run((pairs[:, 0] << 8) | pairs[:, 1], tail), run((pairs[:, 1] << 8) | pairs[:, 0], tail)
+
+
 class Group(_Object):
     def __init__(self, f, addr, name):
         super().__init__(f, addr, name)
@@ -581,7 +610,12 @@ class Dataset(_Object):
                 n = len(raw) // elsize
                 raw = np.frombuffer(raw[:n * elsize], dtype=np.uint8).reshape(elsize, n).T.tobytes() + raw[n * elsize:]
             elif fid == 3:
+                if len(raw) < 4:
+                    raise H5FormatError(f"{self.name}: fletcher32 chunk shorter than its checksum")
+                stored = int.from_bytes(raw[-4:], "little")
                 raw = raw[:-4]
+                if stored not in fletcher32(raw):
+                    raise H5FormatError(f"{self.name}: fletcher32 checksum of a chunk does not match its data")
             else:
                 raise H5Unsupported(f"{self.name}: filter id {fid}")
         return raw
