@@ -404,3 +404,27 @@ def test_shuffle_plus_deflate_residues_of_the_h5py_fixtures_decode_on_the_gpu(gp
             assert dev.shape == X.shape and np.array_equal(yd, y)
             assert np.array_equal(dev.buffer.download(dev.shape, dev.dtype).astype(X.dtype), X)
     utils._H5_KEEP.clear()
+
+
+def test_never_allocated_chunks_are_zeros_on_the_gpu_too(gpu):
+    """tests/golden/frames_partial.hdf5: a residue whose dataset was written only in part (its other chunks were never
+    allocated).  The device path zeroes the batch when chunks are missing — decoded into a dirty, reused device buffer here —
+    and skips the memset when every chunk is there (the first residue alone)"""
+    import os
+    import warnings
+    from design_utils import utils
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    z = np.load(os.path.join(G, "frames_partial_expected.npz"))["frames32"]
+    path = os.path.join(G, "frames_partial.hdf5")
+    utils._H5_KEEP.clear()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fmap = np.array(utils.create_flat_dataset_map(path)[0])
+        for rows, want in ((fmap, z), (fmap[:1], z[:1]), (fmap[1:], z[1:]), (fmap, z)):
+            got = utils.load_batch_device(path, rows, device=gpu)
+            assert got is not None
+            dev = got[0]
+            assert np.array_equal(dev.buffer.download(dev.shape, dev.dtype), want)
+            dev.buffer.upload(np.full(dev.shape, 7.0, np.float32))        # leave the pooled buffer dirty for the next round
+            del dev, got
+    utils._H5_KEEP.clear()

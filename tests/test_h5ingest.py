@@ -507,3 +507,17 @@ def test_fletcher32_is_verified_by_both_host_readers(tmp_path):
         with pytest.raises(h5lite.H5FormatError, match="fletcher32"):
             utils.load_batch(str(bad), fmap, dtype=np.float32)
     utils._H5_KEEP.clear()
+
+
+def test_never_allocated_chunks_read_as_zeros():
+    """tests/golden/frames_partial.hdf5 (real h5py): one residue was written only in part, its other chunks do not exist in the
+    file — they read as zeros, as h5py returns them (the .npz)"""
+    z = np.load(os.path.join(G, "frames_partial_expected.npz"))["frames32"]
+    path = os.path.join(G, "frames_partial.hdf5")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fmap, _ = utils.create_flat_dataset_map(path)
+        out = np.full((2, 21, 21, 21, 6), 7.0, np.float32)            # a reused, dirty batch buffer
+        X, _y = utils.load_batch(path, fmap, dtype=np.float32, out=out)
+    assert np.array_equal(X, z) and np.count_nonzero(z[1][6:]) == 0
+    utils._H5_KEEP.clear()
