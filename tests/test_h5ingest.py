@@ -521,3 +521,23 @@ def test_never_allocated_chunks_read_as_zeros():
         X, _y = utils.load_batch(path, fmap, dtype=np.float32, out=out)
     assert np.array_equal(X, z) and np.count_nonzero(z[1][6:]) == 0
     utils._H5_KEEP.clear()
+
+
+def test_decode_device_refuses_bad_arguments_before_touching_a_gpu():
+    """th_h5_decode_device validates its arguments (null pointers, rank, element size, filter pipeline, conversion) before any
+    HIP call: the refusals are testable without a GPU, and an unsupported pipeline is TH_EUNSUP (-4: "use the host reader")"""
+    import ctypes as C
+    from timed_hip import _lib
+    lib = _lib.load()
+    buf = np.zeros(4096, np.uint8)
+    shape, chunk = (C.c_int64 * 2)(4, 4), (C.c_int64 * 2)(2, 2)
+    one = (C.c_int64 * 1)(128)
+
+    def call(n=1, addrs=one, rank=2, esz=8, nf=1, filt=(1,), conv=0, out=1):
+        return lib.th_h5_decode_device(buf.ctypes.data_as(C.c_void_p), buf.size, 0, n, addrs, rank, shape, chunk, esz, nf,
+                                       (C.c_int * max(1, len(filt)))(*filt), conv, 0, C.c_void_p(out))
+    assert call(filt=(32000,)) == -4 and call(nf=2, filt=(1, 2)) == -4 and call(nf=3, filt=(2, 1, 3)) == -4     # TH_EUNSUP
+    assert call(rank=0) == -4 and call(rank=9) == -4 and call(esz=0) == -4
+    assert call(conv=1, esz=4) == -1 and call(conv=7) == -1                                                      # TH_EINVAL
+    assert call(addrs=None) == -1 and call(out=0) == -1
+    assert call(n=0, addrs=None, out=0) == 0                                                                     # nothing to do
