@@ -428,3 +428,37 @@ def test_never_allocated_chunks_are_zeros_on_the_gpu_too(gpu):
             dev.buffer.upload(np.full(dev.shape, 7.0, np.float32))        # leave the pooled buffer dirty for the next round
             del dev, got
     utils._H5_KEEP.clear()
+
+
+def test_sharded_rccl_path_with_gpu_inflated_frames(gpu, tmp_path, monkeypatch):
+    """the one-process-per-GPU path of predict.py (here: a 1-rank RCCL communicator) on a gzip .hdf5: the frames of every group
+    are inflated on the GPU (DeviceFrames), predicted into the device shard buffer (TH_PREDICT_IN_DEVICE | TH_PREDICT_OUT_DEVICE),
+    gathered with th_comm_gather_rows — and every file equals the plain host-reader run byte for byte"""
+    import os
+    import warnings
+    import predict
+    from design_utils import utils
+    from timed_hip import distributed as td, pack, synth
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    data = os.path.join(G, "frames_chunked.hdf5")                 # real h5py, 32 chunks per frame
+    cfg, weights = synth.timed_synth(20, widths=(8, 16), side=21, in_channels=6, seed=5)
+    mp = tmp_path / "M.pack"
+    mp.write_bytes(pack.keras_to_pack(cfg, weights))
+    a, b = tmp_path / "a", tmp_path / "b"
+    a.mkdir(); b.mkdir()
+    calls = []
+    real = utils.load_batch_device
+    monkeypatch.setattr(utils, "load_batch_device", lambda *x, **k: (calls.append(1), real(*x, **k))[1])
+    comm = td.RcclGather(td.RcclGather.new_unique_id(), 1, 0, gpu)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        predict.load_dataset_and_predict([mp], data, batch_size=2, dataset_map_path=b / "datasetmap.txt", path_to_output=b,
+                                         frames_per_call=2, gather=comm)
+        assert len(calls) == 3                                    # 5 frames in groups of 2: every group decoded on the GPU
+        monkeypatch.setenv("TIMED_GPU_INFLATE", "0")
+        predict.load_dataset_and_predict([mp], data, batch_size=2, dataset_map_path=a / "datasetmap.txt", path_to_output=a)
+        assert len(calls) == 3
+    comm.close()
+    for fn in sorted(x.name for x in a.iterdir()):
+        assert (a / fn).read_bytes() == (b / fn).read_bytes(), fn
+    utils._H5_KEEP.clear()
