@@ -290,6 +290,7 @@ def main():
             line["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                 "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
                                 "kernel": dom["label"], "avg_launch_ms": avg_ms, "launches": dom["launches"],
+                                "frames_per_launch": frames_per_launch, "algorithmic_flops_per_launch": dom["flops"] * frames_per_launch,
                                 "measured": "HIP events around every launch of this kernel inside the timed region",
                                 "exec_tflops": dom["exec_flops"] * frames_per_launch / (avg_ms * 1e-3) / 1e12}
             if warm_steps:
@@ -334,8 +335,25 @@ def main():
             line["other_configs"] = [bench_legs.topology_rate(t, device, d_frames.ptr, min(n, args.other_frames), args.chunk,
                                                               traffic=pmc.get(t), cpu_baseline=base) for t in others]
             line["extras_wall_s"] = time.perf_counter() - t_legs
+        # the full record (per-kernel tables of every topology, all e2e/sampler legs) goes to a side file and stderr;
+        # stdout gets ONE compact line (tools/bench_line.py, < 4 KB) — the driver only reads the tail of stdout
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_line
+        detail = os.environ.get("TH_BENCH_DETAIL", os.path.join(ROOT, "bench_detail.json"))
+        try:
+            with open(detail, "w") as f:
+                json.dump(line, f, indent=1)
+            scratch = os.path.join(ROOT, "gpurun_out")
+            if os.path.isdir(scratch):
+                with open(os.path.join(scratch, "bench_detail.json"), "w") as f:
+                    json.dump(line, f, indent=1)
+        except OSError as e:
+            print(f"[bench] could not write {detail}: {e}", file=sys.stderr)
+            detail = None
+        print("[bench] full record:\n" + json.dumps(line, indent=1), file=sys.stderr)
+        sys.stderr.flush()
         sys.stdout.flush()
-        os.write(json_fd, (json.dumps(line) + "\n").encode())
+        os.write(json_fd, (bench_line.dumps(line, os.path.basename(detail) if detail else None) + "\n").encode())
     if comm is not None:
         comm.close()
     if rdzv is not None:

@@ -1,0 +1,66 @@
+"""The stdout line of bench.py must stay parseable by the driver: one JSON line, well under 8 KB, contract keys present.
+Round 3's line grew to 28.9 KB (per-kernel tables inline) and the driver's stdout tail cut it: `parsed: null`.
+Canned records are the full bench records of earlier rounds kept under profiles/."""
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import bench_line  # noqa: E402
+
+CANNED = ["profiles/r03_d_bench_default.json", "profiles/r02_e_bench_default.json",
+          "profiles/r03_a_bench_2ranks_1gpu_fallback.json", "profiles/r01_f_bench_default.json"]
+
+
+@pytest.mark.parametrize("path", CANNED)
+def test_line_is_small_valid_and_complete(path):
+    full = json.load(open(os.path.join(ROOT, path)))
+    s = bench_line.dumps(full, "bench_detail.json")
+    assert "\n" not in s
+    assert len(s.encode()) <= bench_line.MAX_LINE_BYTES < 8192
+    line = json.loads(s)
+    for k in bench_line.REQUIRED:
+        assert k in line, k
+    assert line["metric"] == full["metric"] and line["unit"] == "frames/s"
+    assert abs(line["value"] - full["value"]) <= 1e-6 * full["value"]
+    assert abs(line["ms_per_step"] - full["ms_per_step"]) <= 1e-5 * full["ms_per_step"]
+    assert "workload" in line["config"] and "model" not in line["config"]
+    if "roofline" in full:
+        rl = line["roofline"]
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms", "launches"):
+            assert k in rl, k
+        assert rl["bound"] in ("hbm", "mfma") and 0 < rl["frac"] <= 1.0
+        assert abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-3
+        assert len(rl["kernel"]) <= 96
+    if "cpu_baseline" in full:
+        cb = line["cpu_baseline"]
+        assert set(cb) == {"value", "unit", "cores", "kind", "sample"} and cb["kind"] in ("port", "reference")
+    assert "kernels" not in line
+
+
+def test_other_configs_are_scalars_only():
+    full = json.load(open(os.path.join(ROOT, "profiles/r03_d_bench_default.json")))
+    line = bench_line.compact(full)
+    assert [o["topology"] for o in line["other_configs"]] == ["densecpd", "timed_rotamer"]
+    for o in line["other_configs"]:
+        assert all(not isinstance(v, (list, dict)) for v in o.values())
+        assert o["frames_per_s"] > 0 and 0 < o["model_frac"] <= 1
+
+
+def test_oversized_record_sheds_optional_blocks_not_contract_keys():
+    full = json.load(open(os.path.join(ROOT, "profiles/r03_d_bench_default.json")))
+    full["other_configs"] = full["other_configs"] * 40          # a pathological record
+    s = bench_line.dumps(full)
+    line = json.loads(s)
+    assert len(s) <= bench_line.MAX_LINE_BYTES
+    for k in bench_line.REQUIRED + ("roofline", "cpu_baseline"):
+        assert k in line
+
+
+def test_short_kernel_names():
+    lab = "conv3d_4: conv_mfma<w4,4x2,nt4,ci16,stream,pool0> FB2 ZB5/5 rows128 lds58K [k_conv_mfma<4,4,2,4,16,2,0,7>]"
+    assert bench_line.short_kernel(lab) == "conv3d_4 k_conv_mfma<4,4,2,4,16,2,0,7>"
+    assert bench_line.short_kernel("dense: k_dense") == "dense k_dense"

@@ -1,0 +1,126 @@
+"""The ONE stdout line of bench.py, kept small.
+
+bench.py gathers a large record (per-kernel tables for three topologies, e2e legs, sampler legs).  The driver
+reads only the tail of stdout, so the contract line must stay well under 8 KB: `compact()` keeps the contract
+keys and scalars, everything else goes to the side file (`bench_detail.json`) and to stderr.
+tests/test_bench_line.py guards the size and the required keys on canned records.
+"""
+from __future__ import annotations
+
+import json
+import re
+
+MAX_LINE_BYTES = 4096
+
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config")
+
+
+def _r(x, nd=4):
+    """Round floats to `nd` significant digits (ints and None pass through)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    try:
+        return float(f"{float(x):.{nd}g}")
+    except (TypeError, ValueError):
+        return x
+
+
+def short_kernel(label: str) -> str:
+    """'conv3d_4: conv_mfma<...> FB2 ... [k_conv_mfma<4,4,2,4,16,2,0,7>]' -> 'conv3d_4 k_conv_mfma<4,4,2,4,16,2,0,7>'."""
+    if not label:
+        return label
+    layer = label.split(":", 1)[0].strip()
+    m = re.search(r"\[([^\]]+)\]\s*$", label)
+    kern = m.group(1) if m else label.split(":", 1)[-1].strip().split(" ")[0]
+    return f"{layer} {kern}"[:96]
+
+
+def _roofline(rl: dict) -> dict:
+    out = {"bound": rl.get("bound"), "achieved": _r(rl.get("achieved"), 5), "peak": rl.get("peak"), "unit": rl.get("unit"),
+           "frac": _r(rl.get("frac")), "traffic": rl.get("traffic"), "kernel": short_kernel(rl.get("kernel", "")),
+           "avg_launch_ms": _r(rl.get("avg_launch_ms"), 5), "launches": rl.get("launches")}
+    for k in ("algorithmic_bytes", "traffic_frames", "algorithmic_flops_per_launch", "frames_per_launch"):
+        if rl.get(k) is not None:
+            out[k] = rl[k]
+    if rl.get("share_of_device_time") is not None:
+        out["share_of_device_time"] = _r(rl["share_of_device_time"], 3)
+    return out
+
+
+def _cpu(cb: dict, sample_chars: int = 150) -> dict:
+    return {"value": _r(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+            "sample": (cb.get("sample") or "")[:sample_chars]}
+
+
+def _other(o: dict) -> dict:
+    mr, rl = o.get("model_roofline") or {}, o.get("roofline") or {}
+    out = {"topology": o.get("topology"), "frames": o.get("frames"), "frames_per_s": _r(o.get("frames_per_s"), 5),
+           "model_frac": _r(mr.get("frac")), "dominant": short_kernel(rl.get("kernel", "")), "dominant_frac": _r(rl.get("frac"))}
+    if mr.get("traffic") and mr.get("algorithmic_bytes"):
+        out["traffic_over_algorithmic"] = _r(mr["traffic"] / mr["algorithmic_bytes"], 3)
+    if o.get("cpu_baseline"):
+        out["cpu_frames_per_s"] = _r(o["cpu_baseline"].get("value"))
+    return out
+
+
+_E2E_KEYS = ("device_resident_fps", "th_predict_sync_pageable_fps", "th_predict_async_pinned_fps",
+             "predict_py_framepack_f32_fps", "predict_py_framepack_u8_fps", "predict_py_rotamer_fps",
+             "predict_py_hdf5_gzip_f64_first_call_fps", "predict_py_hdf5_gzip_f64_fps", "config1_predict_py_from_pdb_s",
+             "config1_cpu_oracle_forward_s")
+
+
+def _sampler(s: dict) -> dict:
+    out = {"n_residues": s.get("n_residues"), "n_samples": s.get("n_samples")}
+    for t, v in (s.get("temperatures") or {}).items():
+        out[f"T{t}"] = {"api_ms": _r(v.get("api_ms")), "kernel_ms": _r(v.get("kernel_ms")),
+                        "seq_per_s": _r(v.get("api_sequences_per_s")), "cpu_numpy_ms": _r(v.get("cpu_numpy_ms")),
+                        "bit_exact": v.get("indices_bit_exact_vs_oracle")}
+    return out
+
+
+def compact(full: dict, detail_path: str | None = None) -> dict:
+    """The driver-facing record: contract keys + roofline + cpu_baseline + scalars of the secondary legs."""
+    line = {k: full[k] for k in REQUIRED if k in full}
+    line["value"] = _r(full["value"], 7)
+    line["ms_per_step"] = _r(full["ms_per_step"], 6)
+    cfg = dict(full.get("config") or {})
+    for k in ("algo_mflop_per_frame", "exec_mflop_per_frame"):
+        if k in cfg:
+            cfg[k] = _r(cfg[k], 6)
+    if isinstance(cfg.get("exchange"), str):
+        cfg["exchange"] = cfg["exchange"][:120]
+    line["config"] = cfg
+    for k in ("model_tflops", "model_frac_of_fp32_mfma_peak"):
+        if k in full:
+            line[k] = _r(full[k])
+    if "hbm" in full:
+        line["hbm"] = {k: _r(v) if isinstance(v, float) and k in ("achieved_GBps", "frac") else v for k, v in full["hbm"].items()}
+    if "roofline" in full:
+        line["roofline"] = _roofline(full["roofline"])
+    if "cpu_baseline" in full:
+        line["cpu_baseline"] = _cpu(full["cpu_baseline"])
+    if "other_configs" in full:
+        line["other_configs"] = [_other(o) for o in full["other_configs"]]
+    if "e2e" in full:
+        line["e2e"] = {k: _r(full["e2e"][k]) for k in _E2E_KEYS if k in full["e2e"]}
+    if "sampler" in full:
+        line["sampler"] = _sampler(full["sampler"])
+    if "pmc" in full and full["pmc"].get("error"):
+        line["pmc_error"] = str(full["pmc"]["error"])[:120]
+    if "extras_wall_s" in full:
+        line["extras_wall_s"] = _r(full["extras_wall_s"], 3)
+    if detail_path:
+        line["detail"] = detail_path
+    # last resort: shed optional blocks rather than ever exceed the budget
+    for drop in ("sampler", "e2e", "other_configs", "hbm"):
+        if len(json.dumps(line)) <= MAX_LINE_BYTES:
+            break
+        line.pop(drop, None)
+    return line
+
+
+def dumps(full: dict, detail_path: str | None = None) -> str:
+    s = json.dumps(compact(full, detail_path))
+    assert "\n" not in s and len(s) <= MAX_LINE_BYTES, f"bench line is {len(s)} bytes"
+    return s
