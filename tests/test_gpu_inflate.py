@@ -207,6 +207,41 @@ def test_multi_chunk_h5py_file_decoded_on_the_gpu_equals_h5py(gpu):
         assert np.array_equal(d2.buffer.download(d2.shape, d2.dtype), z["frames32"][order])
 
 
+def test_chunks_longer_than_the_deflate_window_but_whole_in_lds(gpu):
+    """tests/golden/frames_midchunk.hdf5 (real h5py): 40 656-byte chunks, gzip alone (residues 3, 4) and shuffle + gzip (5, 6).
+    Such a chunk is kept whole in LDS and placed from there (the fused path, d_raw is 16 bytes): the mid-stream flush of the
+    ring mode must not run (it once wrote the stream's first bytes far outside d_raw).  Decoded into a poisoned neighbour-rich
+    pool, against h5py's own read; also raw streams of 33-60 KB through th_inflate_many."""
+    import os
+    import warnings
+    from design_utils import utils
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    z = np.load(os.path.join(G, "frames_midchunk_expected.npz"))["frames32"]
+    path = os.path.join(G, "frames_midchunk.hdf5")
+    utils._H5_KEEP.clear()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fmap = np.array(utils.create_flat_dataset_map(path)[0])
+        for order in ([0, 1, 2, 3], [3, 1], [2, 0, 1, 3, 2]):
+            got = utils.load_batch_device(path, fmap[order], device=gpu)
+            assert got is not None, "deflate / shuffle + deflate float64 residues must take the device path"
+            dev, _y = got
+            assert np.array_equal(dev.buffer.download(dev.shape, dev.dtype), z[order])
+    utils._H5_KEEP.clear()
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    raws = []
+    for n in (32769, 32776, 32777, 40000, 49152, 61440):
+        a = rng.integers(0, 256, n, dtype=np.uint8)
+        a[rng.random(n) < 0.7] = 0                                   # long zero runs between literals
+        raws.append(a.tobytes())
+        raws.append(bytes(rng.integers(0, 4, n, dtype=np.uint8)))    # short alphabet: matches everywhere
+    streams = [zlib.compress(r, 6) for r in raws]
+    rc, status, got, _raw = _inflate(lib, gpu, streams, [len(r) for r in raws])
+    assert rc == 0 and not status.any()
+    assert all(g == r for g, r in zip(got, raws))
+
+
 def test_boolean_h5py_fixture_decoded_on_the_gpu(gpu):
     """the deflate-only residues of tests/golden/frames_tiny_bool.hdf5 (real h5py, 1-byte elements: the non-converting placement)"""
     import os

@@ -434,6 +434,21 @@ def test_multi_chunk_float64_frames_equal_h5py(tmp_path):
     assert geo[2] == (6, 11, 11, 3) and geo[4] == (1,)
 
 
+def test_mid_size_chunks_equal_h5py():
+    """tests/golden/frames_midchunk.hdf5 (real h5py): 40 656-byte chunks — longer than the DEFLATE window, shorter than the GPU
+    decoder's whole-stream limit — gzip alone and shuffle + gzip, on the host reader (the GPU twin is in test_gpu_inflate.py)"""
+    z = np.load(os.path.join(G, "frames_midchunk_expected.npz"))["frames32"]
+    path = os.path.join(G, "frames_midchunk.hdf5")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fmap, _ = utils.create_flat_dataset_map(path)
+        X32, _y = utils.load_batch(path, fmap, dtype=np.float32)
+    assert np.array_equal(X32, z)
+    with h5lite.File(path) as f:
+        assert f["1abc"]["A"]["3"].chunked_geometry()[2] == (7, 11, 11, 6)
+        assert f["1abc"]["A"]["3"].chunked_geometry()[4] == (1,) and f["1abc"]["A"]["5"].chunked_geometry()[4] == (2, 1)
+
+
 def test_native_map_path_does_not_depend_on_h5py_being_absent(monkeypatch):
     """the reference's users HAVE h5py installed: the native map path (and with it load_batch_device's GPU decode, which shares
     the kept h5lite handle) must not switch itself off because `import h5py` works.  A stand-in h5py whose File refuses to open

@@ -680,8 +680,10 @@ __global__ void __launch_bounds__(kLanes) k_lz_resolve(const unsigned* tokens, c
         const int incl = wave_scan_incl(len);
         const int total = __builtin_amdgcn_readlane(incl, kLanes - 1);
         const long long pos = o + incl - len;
-        // make room: everything older than the 32 KB window goes out
-        if (o - flushed > 32768 + 8) {
+        // make room: everything older than the 32 KB window goes out.  Ring mode only: a whole-window stream (M = ~0) stays in LDS
+        // until the end — on the fused path `dst` is not even a chunk-sized buffer (d_raw is 16 bytes there), and the final
+        // adler_to(o) + placement / flush cover every byte
+        if (M != 0xffffffffu && o - flushed > 32768 + 8) {
             wave_sync();
             flush_to((o - 32768) & ~7ll);
             wave_sync();
