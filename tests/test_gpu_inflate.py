@@ -222,7 +222,7 @@ def test_chunks_longer_than_the_deflate_window_but_whole_in_lds(gpu):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         fmap = np.array(utils.create_flat_dataset_map(path)[0])
-        for order in ([0, 1, 2, 3], [3, 1], [2, 0, 1, 3, 2]):
+        for order in ([0, 1], [1, 0, 1], [2, 3], [3, 2, 2]):        # one filter pipeline per batch (a mixed batch goes to the host reader)
             got = utils.load_batch_device(path, fmap[order], device=gpu)
             assert got is not None, "deflate / shuffle + deflate float64 residues must take the device path"
             dev, _y = got
