@@ -244,6 +244,10 @@ int th_h5_read_contiguous_as(const void* file, int64_t file_len, int64_t base, i
 int th_h5_decode_device(const void* file, int64_t file_len, int64_t base, int64_t n_datasets, const int64_t* btree_addrs, int rank,
                         const int64_t* shape, const int64_t* chunk, int esz, int n_filters, const int* filter_ids, int conv, int device,
                         void* d_out);
+/* th_h5_decode_device keeps per-device scratch memory between calls (compressed span, token arena: ~5 bytes per uncompressed
+ * byte of the largest batch so far).  When an allocation fails it frees that scratch and returns TH_ENOMEM — decode fewer
+ * datasets per call or read through th_h5_read_chunked_as; th_h5_release_scratch frees it on request (end of a run). */
+int th_h5_release_scratch(int device);
 /* n independent zlib (wrapped = 1) or raw DEFLATE (wrapped = 0) streams inflated on `device`: stream i is
  * comp[src_off[i] .. + src_len[i]) and decodes to exactly dst_len[i] bytes at out[dst_off[i]] (8-byte aligned).  comp / out are
  * host buffers.  status_out[i] (optional): 0, or why stream i failed (1 input exhausted, 2 output overrun, 3 bad zlib header,

@@ -29,12 +29,13 @@ def test_shard_bounds_cover_exactly():
 WORKER = textwrap.dedent("""
     import os, sys
     import numpy as np
-    sys.path.insert(0, os.path.join({root!r}, "timed-design_amd"))
+    sys.path.insert(0, os.path.join({root!r}, "timed-design_amd")); sys.path.insert(0, os.path.join({root!r}, "tests"))
     import torch.distributed as dist
     from timed_hip import distributed as td
+    from _gloo_transport import GlooGather
 
     dist.init_process_group(backend="gloo")
-    g = td.GlooGather()
+    g = GlooGather()
     n_total, width = {n_total}, 20
 
     class FakeModel:  # stands in for HipFrameModel: row i of the map -> a row that encodes i
@@ -82,12 +83,13 @@ PREDICT_WORKER = textwrap.dedent("""
     import torch.distributed as dist
     from timed_hip import distributed as td
     import predict, _oracle_model
+    from _gloo_transport import GlooGather
     warnings.simplefilter("ignore")
     dist.init_process_group(backend="gloo")
     out = Path({out!r})
     res = predict.load_dataset_and_predict([Path({model!r})], {data!r}, batch_size={bs}, start_batch={start}, dataset_map_path=out / "datasetmap.txt",
                                            path_to_output=out, frames_per_call={fpc}, model_loader=_oracle_model.load_model,
-                                           gather=td.GlooGather())
+                                           gather=GlooGather())
     rank = dist.get_rank()
     lo, hi = td.shard_bounds(26 - {start} * {bs}, 2)[rank]
     assert sum(n for _d, n in _oracle_model.OracleModel.calls) == hi - lo, _oracle_model.OracleModel.calls

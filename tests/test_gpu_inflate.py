@@ -465,6 +465,90 @@ def test_never_allocated_chunks_are_zeros_on_the_gpu_too(gpu):
     utils._H5_KEEP.clear()
 
 
+def test_duplicated_chunk_record_does_not_leave_stale_data(gpu, tmp_path):
+    """a malformed chunk B-tree that lists chunk 1 twice and chunk 0 not at all has the full NUMBER of records: the count alone
+    must not switch the zero-fill off — the region of the missing chunk reads as zeros (as for a never-allocated chunk), not as
+    what the pooled device buffer held before.  A chunk offset that is not a multiple of the chunk size is refused."""
+    import os
+    import struct
+    import warnings
+    from design_utils import utils
+    from timed_hip import h5lite
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    src = os.path.join(G, "frames_chunked.hdf5")
+    z = np.load(os.path.join(G, "frames_chunked_expected.npz"))["frames32"]
+    data = bytearray(open(src, "rb").read())
+    with h5lite.File(src) as f:
+        btree, _shape, chunk, _esz, _filters = f["1abc"]["A"]["5"].chunked_geometry()
+        a = f._base + btree
+        assert bytes(f._m[a:a + 4]) == b"TREE" and f._m[a + 5] == 0 and struct.unpack_from("<H", f._m, a + 6)[0] == 32
+    rank1 = len(chunk) + 1
+    ksz = 8 + 8 * rank1 + 8                                     # key (size, mask, offsets) + child pointer
+    key0, key1 = a + 24, a + 24 + ksz
+    offs0 = struct.unpack_from(f"<{rank1}Q", data, key0 + 8)
+    offs1 = struct.unpack_from(f"<{rank1}Q", data, key1 + 8)
+    assert offs0[:4] == (0, 0, 0, 0) and offs1[:4] == (0, 0, 0, 3)
+    dup = bytearray(data)
+    struct.pack_into(f"<{rank1}Q", dup, key0 + 8, *offs1)       # record 0 now claims to be chunk (0, 0, 0, 3) as well
+    p = tmp_path / "dup.hdf5"
+    p.write_bytes(bytes(dup))
+    utils._H5_KEEP.clear()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fmap = np.array(utils.create_flat_dataset_map(src)[0])
+        row = fmap[[2]]                                          # residue "5"
+        got = utils.load_batch_device(src, row, device=gpu)      # the intact file: leaves the right values in the pooled buffer
+        assert np.array_equal(got[0].buffer.download(got[0].shape, got[0].dtype), z[[2]])
+        assert np.count_nonzero(z[2, 0:6, 0:11, 0:11, 0:3]) > 10
+        del got
+        got = utils.load_batch_device(p, row, device=gpu)
+        assert got is not None
+        frame = got[0].buffer.download(got[0].shape, got[0].dtype)[0]
+        assert not frame[0:6, 0:11, 0:11, 0:3].any(), "the chunk that is missing from the tree must read as zeros"
+        assert np.array_equal(frame[6:], z[2, 6:])               # the chunks that are there once are placed as usual
+        del got
+        mis = bytearray(data)
+        struct.pack_into(f"<{rank1}Q", mis, key1 + 8, 0, 0, 0, 2, 0)     # offset 2 along a dimension chunked by 3
+        q = tmp_path / "misaligned.hdf5"
+        q.write_bytes(bytes(mis))
+        with pytest.raises(RuntimeError, match="multiple of the chunk size"):
+            utils.load_batch_device(q, row, device=gpu)
+    utils._H5_KEEP.clear()
+
+
+def test_decoder_scratch_is_released_and_comes_back(gpu):
+    """th_h5_release_scratch / design_utils.utils.release_device_memory: the decoder's device scratch and the pooled batch buffers are
+    given back (free device memory grows), and the next decode allocates again and is still right"""
+    import ctypes as C
+    import os
+    import warnings
+    from design_utils import utils
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    path = os.path.join(G, "frames_chunked.hdf5")
+    z = np.load(os.path.join(G, "frames_chunked_expected.npz"))["frames32"]
+    hip = C.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        fr, tot = C.c_size_t(), C.c_size_t()
+        assert hip.hipSetDevice(gpu) == 0 and hip.hipMemGetInfo(C.byref(fr), C.byref(tot)) == 0
+        return fr.value
+    utils._H5_KEEP.clear()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fmap = np.array(utils.create_flat_dataset_map(path)[0])
+        got = utils.load_batch_device(path, fmap, device=gpu)
+        assert np.array_equal(got[0].buffer.download(got[0].shape, got[0].dtype), z)
+        del got
+        held = free_bytes()
+        utils.release_device_memory([gpu])
+        assert free_bytes() > held
+        assert _lib.load().th_h5_release_scratch(gpu) == 0       # nothing left to free: still fine
+        assert _lib.load().th_h5_release_scratch(99) == -1
+        got = utils.load_batch_device(path, fmap, device=gpu)
+        assert np.array_equal(got[0].buffer.download(got[0].shape, got[0].dtype), z)
+    utils._H5_KEEP.clear()
+
+
 def test_sharded_rccl_path_with_gpu_inflated_frames(gpu, tmp_path, monkeypatch):
     """the one-process-per-GPU path of predict.py (here: a 1-rank RCCL communicator) on a gzip .hdf5: the frames of every group
     are inflated on the GPU (DeviceFrames), predicted into the device shard buffer (TH_PREDICT_IN_DEVICE | TH_PREDICT_OUT_DEVICE),

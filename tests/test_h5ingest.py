@@ -556,3 +556,59 @@ def test_decode_device_refuses_bad_arguments_before_touching_a_gpu():
     assert call(conv=1, esz=4) == -1 and call(conv=7) == -1                                                      # TH_EINVAL
     assert call(addrs=None) == -1 and call(out=0) == -1
     assert call(n=0, addrs=None, out=0) == 0                                                                     # nothing to do
+
+
+def test_gpu_decode_retries_in_pieces_when_the_device_is_out_of_memory(monkeypatch):
+    """h5lite.decode_resolved_device: TH_ENOMEM from th_h5_decode_device (its token arena did not fit) splits the batch in halves
+    down to MIN_DECODE datasets; every piece lands at its own offset of the output; below that the error surfaces and
+    load_batch_device turns it into "use the host reader" (None + a warning) instead of aborting predict.py.  The native call is
+    replaced by a recorder: no GPU needed."""
+    from timed_hip import _lib
+    path = os.path.join(G, "frames_chunked.hdf5")
+    real = _lib.load()
+    calls = []
+
+    class Fake:
+        limit = 1
+
+        def __getattr__(self, name):
+            return getattr(real, name)
+
+        def th_h5_decode_device(self, file, file_len, base, n, addrs, rank, shape, chunk, esz, nf, filters, conv, device, d_out):
+            calls.append((int(n), int(d_out.value)))
+            return _lib.TH_ENOMEM if n > self.limit else 0
+    fake = Fake()
+    monkeypatch.setattr(_lib, "load", lambda: fake)
+    monkeypatch.setattr(h5lite, "MIN_DECODE", 1)
+    utils._H5_KEEP.clear()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fmap = np.array(utils.create_flat_dataset_map(path)[0])
+    with h5lite.File(path) as f:
+        links = f["1abc"]["A"]._load()
+        addrs = np.array([links[r[2]] for r in fmap], dtype=np.int64)
+        res = h5lite.resolve_many(f, addrs, num_attr="encoded_residue", num_len=20)
+        assert h5lite.decode_resolved_device(f, res, 1 << 20, 0, as_float32=True)
+        frame_bytes = 21 * 21 * 21 * 6 * 4
+        done = sorted((off - (1 << 20)) // frame_bytes for n, off in calls if n == 1)
+        assert done == [0, 1, 2, 3, 4] and calls[0] == (5, 1 << 20)
+        assert all((off - (1 << 20)) % frame_bytes == 0 for _n, off in calls)
+        calls.clear()
+        monkeypatch.setattr(h5lite, "MIN_DECODE", 64)             # 5 datasets cannot be split: the error surfaces ...
+        with pytest.raises(_lib.TimedHipError) as e:
+            h5lite.decode_resolved_device(f, res, 1 << 20, 0, as_float32=True)
+        assert e.value.code == _lib.TH_ENOMEM and calls == [(5, 1 << 20)]
+    # ... and load_batch_device hands the batch to the host reader
+    class FakeBuf:
+        ptr = 1 << 20
+        device = 0
+        nbytes = 1 << 40
+
+        def free(self):
+            pass
+    monkeypatch.setattr(utils._DEVICE_POOL, "acquire", lambda nbytes, device: FakeBuf())
+    monkeypatch.setattr(utils._DEVICE_POOL, "release", lambda buf: None)
+    utils._H5_KEEP.clear()
+    with pytest.warns(UserWarning, match="host reader"):
+        assert utils.load_batch_device(path, fmap, device=0) is None
+    utils._H5_KEEP.clear()

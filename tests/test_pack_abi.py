@@ -231,3 +231,35 @@ def test_keras_pinning_tool_dry_runs_without_tensorflow():
     assert "391.0 MFLOP/frame" in r.stdout and "keras_real_" in r.stdout
     r = subprocess.run([sys.executable, tool, "--dry-run"], capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "exactly one of" in r.stderr
+
+
+def test_nested_model_weight_aliases_never_shadow_a_top_level_layer(tmp_path):
+    """timed_hip.h5model: a nested model's layers are exposed as "<outer>/<inner>"; the bare "<inner>" alias only where it is
+    unambiguous — a top-level layer of the same name keeps its own 2 arrays (they once grew to 4), and two nested models that both
+    hold a "conv3d" get no bare alias at all"""
+    from timed_hip import h5model, h5write
+    rng = np.random.default_rng(3)
+    arr = lambda *s: rng.normal(size=s).astype(np.float32)
+    p = tmp_path / "nested.h5"
+    with h5write.File(p) as f:
+        f.attrs["model_config"] = json.dumps({"class_name": "Functional", "config": {"layers": []}})
+        g = f.create_group("model_weights")
+        g.attrs["layer_names"] = ["conv3d", "trunk", "head"]
+        top = g.create_group("conv3d")
+        top.attrs["weight_names"] = ["conv3d/kernel:0", "conv3d/bias:0"]
+        tc = top.create_group("conv3d")
+        tc.create_dataset("kernel:0", arr(3, 3, 3, 2, 4)); tc.create_dataset("bias:0", arr(4))
+        for outer, inner in (("trunk", ["conv3d", "dense"]), ("head", ["conv3d", "batch_normalization"])):
+            og = g.create_group(outer)
+            names = []
+            for lname in inner:
+                lg = og.create_group(lname)
+                for wn, shape in (("kernel:0", (1, 1, 1, 4, 4)), ("bias:0", (4,))):
+                    lg.create_dataset(wn, arr(*shape))
+                    names.append(f"{lname}/{wn}")
+            og.attrs["weight_names"] = names
+    _cfg, w = h5model.read_keras_h5(str(p))
+    assert len(w["conv3d"]) == 2 and w["conv3d"][0].shape == (3, 3, 3, 2, 4)          # the top-level layer, untouched
+    assert len(w["trunk/conv3d"]) == 2 and len(w["head/conv3d"]) == 2 and w["trunk/conv3d"][0].shape == (1, 1, 1, 4, 4)
+    assert len(w["dense"]) == 2 and len(w["batch_normalization"]) == 2                 # unambiguous inner names keep their alias
+    assert not np.array_equal(w["trunk/conv3d"][0], w["head/conv3d"][0])

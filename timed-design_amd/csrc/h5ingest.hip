@@ -299,6 +299,7 @@ bool collect(const Geometry& g, uint64_t addr, int ds, std::vector<ChunkRec>* ou
         for (int d = 0; d < g.rank; ++d) {
             const int64_t o = (int64_t)rd<uint64_t>(g.file + p + 8 + 8 * d);
             if (o < 0 || o >= g.shape[d]) { *err = "chunk offset outside the dataset"; return false; }
+            if (o % g.chunk[d] != 0) { *err = "chunk offset is not a multiple of the chunk size"; return false; }
             r.coff[d] = (int)o;
         }
         const uint64_t child = rd<uint64_t>(g.file + p + ksz);
@@ -382,7 +383,21 @@ extern "C" int th_h5_decode_device(const void* file, int64_t file_len, int64_t b
     // element and the 0.9 GB memset of a 4 096-frame batch is skipped
     int64_t chunks_per_dataset = 1;
     for (int d = 0; d < rank; ++d) chunks_per_dataset *= (shape[d] + chunk[d] - 1) / chunk[d];
-    if ((int64_t)nch != n_datasets * chunks_per_dataset) {
+    // (a malformed tree may list one chunk twice and another not at all: the count alone does not prove coverage — every
+    // (dataset, chunk index) must be there exactly once; offsets are chunk-aligned, collect() checked that)
+    bool covered = (int64_t)nch == n_datasets * chunks_per_dataset;
+    if (covered) {
+        std::vector<bool> seen(nch, false);
+        for (auto& v : parts)
+            for (const ChunkRec& r : v) {
+                int64_t lin = 0;
+                for (int d = 0; d < rank; ++d) lin = lin * ((shape[d] + chunk[d] - 1) / chunk[d]) + r.coff[d] / chunk[d];
+                const size_t at = (size_t)((int64_t)r.ds * chunks_per_dataset + lin);
+                if (seen[at]) covered = false;
+                seen[at] = true;
+            }
+    }
+    if (!covered) {
         HIP_TRY(hipMemsetAsync(d_out, 0, (size_t)n_datasets * elems * out_esz, nullptr));
         HIP_TRY(hipStreamSynchronize(nullptr));
     }

@@ -901,10 +901,19 @@ struct DevBuf {
         if (bytes <= cap) return TH_OK;
         if (p) (void)hipFree(p);
         p = nullptr; cap = 0;
-        const size_t want = bytes + bytes / 4 + 4096;
-        HIP_TRY(hipMalloc(&p, want));
-        cap = want;
-        return TH_OK;
+        // 25 % of slack so that batches of slowly growing size do not re-allocate; the exact size when the slack does not fit
+        for (const size_t want : {bytes + bytes / 4 + 4096, bytes}) {
+            const hipError_t e = hipMalloc(&p, want);
+            if (e == hipSuccess) { cap = want; return TH_OK; }
+            p = nullptr;
+            (void)hipGetLastError();
+            if (e != hipErrorOutOfMemory) TH_FAIL(TH_EHIP, "hipMalloc(%zu): %s", want, hipGetErrorString(e));
+        }
+        TH_FAIL(TH_ENOMEM, "inflate: no device memory for a %zu-byte scratch buffer (decode fewer datasets per call)", bytes);
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
     }
 };
 
@@ -975,6 +984,36 @@ extern "C" int th_inflate_many(int device, const void* comp, int64_t comp_len, i
     return TH_OK;
 }
 
+namespace {
+struct Scratch {
+    std::mutex mu;
+    DevBuf d_comp, d_raw, d_desc, d_st, d_ds, d_coff, d_tok, d_nt, d_ad;
+    void* h_st = nullptr; size_t h_st_cap = 0;
+    hipStream_t own = nullptr;
+    void release_device() {
+        for (DevBuf* b : {&d_comp, &d_raw, &d_desc, &d_st, &d_ds, &d_coff, &d_tok, &d_nt, &d_ad}) b->release();
+    }
+};
+constexpr int kMaxDevices = 16;         // one set per device (`predict.py --devices 0,1,...` decodes on the GPU that predicts)
+Scratch sets[kMaxDevices];
+}  // namespace
+
+// th_h5_release_scratch: give back the decoder's device scratch of `device` (token arena: 5 bytes per uncompressed byte of the
+// largest batch decoded so far) — predict.py calls it when a run ends; the next decode allocates again.
+extern "C" int th_h5_release_scratch(int device) {
+    if (device < 0 || device >= kMaxDevices) TH_FAIL(TH_EINVAL, "th_h5_release_scratch: device %d outside 0..%d", device, kMaxDevices - 1);
+    Scratch* sc = &sets[device];
+    std::unique_lock<std::mutex> lock(sc->mu);
+    bool any = sc->h_st != nullptr;
+    for (DevBuf* b : {&sc->d_comp, &sc->d_raw, &sc->d_desc, &sc->d_st, &sc->d_ds, &sc->d_coff, &sc->d_tok, &sc->d_nt, &sc->d_ad}) any = any || b->p;
+    if (!any) return TH_OK;                 // nothing was ever decoded on this device: no HIP call at all
+    HIP_TRY(hipSetDevice(device));
+    sc->release_device();
+    if (sc->h_st) (void)hipHostFree(sc->h_st);
+    sc->h_st = nullptr; sc->h_st_cap = 0;
+    return TH_OK;
+}
+
 // ---- HDF5 chunks -> device-resident frames (used by h5ingest.hip: th_h5_decode_device) -----------------------------------
 // comp: host pointer to a byte span of the file that contains every chunk (chunk i at span offset src_off[i], csize[i]
 // bytes); chunk i belongs to dataset ds[i] at element offsets coff[i][rank].  Everything is inflated into a scratch buffer
@@ -986,14 +1025,6 @@ int inflate_place_device(int device, hipStream_t stream, const void* span, int64
     // two loader threads in predict.py, so that the pageable upload of one batch runs under the kernels of the other: each call then
     // took twice as long — the same 0.38 s for 40 k frames warm — and the first call of a process paid for a second 9 GB token
     // arena: 0.49 -> 1.09 s.  One set it is.)  `stream`: nullptr (the usual case) means "the set's own stream".
-    struct Scratch {
-        std::mutex mu;
-        DevBuf d_comp, d_raw, d_desc, d_st, d_ds, d_coff, d_tok, d_nt, d_ad;
-        void* h_st = nullptr; size_t h_st_cap = 0;
-        hipStream_t own = nullptr;
-    };
-    constexpr int kMaxDevices = 16;         // one set per device (`predict.py --devices 0,1,...` decodes on the GPU that predicts)
-    static Scratch sets[kMaxDevices];
     if (device < 0 || device >= kMaxDevices) TH_FAIL(TH_EINVAL, "inflate: device %d outside 0..%d", device, kMaxDevices - 1);
     Scratch* sc = &sets[device];
     std::unique_lock<std::mutex> lock(sc->mu);
@@ -1015,8 +1046,12 @@ int inflate_place_device(int device, hipStream_t stream, const void* span, int64
         (rc = d_desc.ensure((size_t)n_chunks * sizeof(InfDesc))) || (rc = d_st.ensure((size_t)n_chunks * sizeof(int))) ||
         (rc = d_ds.ensure((size_t)n_chunks * sizeof(int))) || (rc = d_coff.ensure((size_t)n_chunks * 8 * sizeof(int))) ||
         (rc = d_tok.ensure((size_t)(n_chunks * chunk_bytes + 16) * sizeof(unsigned))) || (rc = d_nt.ensure((size_t)n_chunks * sizeof(long long))) ||
-        (rc = d_ad.ensure((size_t)n_chunks * sizeof(unsigned))))
+        (rc = d_ad.ensure((size_t)n_chunks * sizeof(unsigned)))) {
+        // out of device memory (TH_ENOMEM) or a failed allocation: keep nothing — the caller retries with fewer datasets or reads
+        // through the host, and the model's arenas / the pooled batch buffers get the memory back
+        sc->release_device();
         return rc;
+    }
     static const bool trace = getenv("TH_H5_TRACE") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };

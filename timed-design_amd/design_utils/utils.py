@@ -341,7 +341,26 @@ class _DevicePool:
         buf.free()
 
 
+    def drain(self):
+        with self.lock:
+            bufs, self.free = self.free, []
+        for b in bufs:
+            b.free()
+
+
 _DEVICE_POOL = _DevicePool()
+
+
+def release_device_memory(devices=None) -> None:
+    """Give back what load_batch_device keeps between calls so that the next call is fast: the pooled batch buffers (up to six of
+    frames_per_call frames each) and the GPU decoder's scratch (token arena, ~5 bytes per uncompressed byte of a batch).  predict.py's
+    CLI calls it when its run ends; a long-lived process (the UI) calls it when it is done predicting.  No reference counterpart
+    (the reference holds no device memory)."""
+    from timed_hip import _lib
+    _DEVICE_POOL.drain()
+    lib = _lib.load()
+    for d in (range(16) if devices is None else devices):
+        lib.th_h5_release_scratch(int(d))
 _H5_KEEP: dict = {}      # path -> (mtime, size, h5lite.File): the dataset load_batch_device read last stays mapped
 
 
@@ -379,7 +398,7 @@ def load_batch_device(dataset_path: Path, data_point_batch, device: int = 0):
     pipeline other than deflate, mixed geometries ...; the caller then uses load_batch).  The gzip chunks are inflated ON THE
     GPU (libtimedhip th_h5_decode_device, one lane per chunk): only the compressed bytes cross PCIe — 8.7x fewer than the float64
     frames — and no host core spends a millisecond per frame in zlib."""
-    from timed_hip import engine, framepack, h5lite
+    from timed_hip import _lib, engine, framepack, h5lite
     if framepack.is_pack(dataset_path) or framepack.is_structure(dataset_path):
         return None
     n = len(data_point_batch)
@@ -391,6 +410,14 @@ def load_batch_device(dataset_path: Path, data_point_batch, device: int = 0):
     try:
         return _load_batch_device(dataset, data_point_batch, n, device)
     except (h5lite.H5Unsupported, h5lite.H5FormatError, KeyError):      # a file feature h5lite does not read: the host reader's job
+        return None
+    except _lib.TimedHipError as e:
+        # no device memory left for the decoder (TH_ENOMEM, after decode_resolved_device already tried smaller pieces) or a HIP call
+        # failed: the host reader does not need the device at all — use it instead of aborting the run.  A corrupt chunk (TH_EIO) or
+        # a bad argument stays an error: the host reader would refuse the same file.
+        if e.code not in (_lib.TH_ENOMEM, _lib.TH_EHIP):
+            raise
+        warnings.warn(f"GPU decode of {n} frames failed ({e}); reading this batch through the host reader")
         return None
 
 

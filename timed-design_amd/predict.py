@@ -453,7 +453,7 @@ def _predict_sharded(model, gather, rank, world, dataset_path, flat_dataset_map,
             d_all = engine.DeviceBuffer(max(1, n * width * 4), model.device) if rank == 0 else None
             gather.gather_rows_device(d_local.ptr, counts, width, 0, d_all.ptr if d_all else 0)
             probs = d_all.download((n, width), np.float32) if rank == 0 else None
-        else:                     # host transport (GlooGather, the CPU tests): rows are on the host already
+        else:                     # host transport (tests/_gloo_transport.GlooGather, the CPU tests): rows are on the host already
             local = np.zeros((len(shard), model.n_classes), dtype=np.float32)
             cursor = [0]
 
@@ -515,6 +515,13 @@ def main(args):
         assert path.exists(), f"No {what} at {path}"
     assert args.batch_size > 0, f"--batch_size must be positive, got {args.batch_size}"
     devices = [int(d) for d in args.devices.split(",")] if getattr(args, "devices", None) else None
+    try:
+        return _main_predict(args, required, devices)
+    finally:
+        du.release_device_memory()           # pooled batch buffers + the GPU decoder's scratch: a CLI run keeps nothing
+
+
+def _main_predict(args, required, devices):
     return load_dataset_and_predict(
         [required["model"]], required["dataset"], batch_size=args.batch_size, start_batch=0,
         dataset_map_path=Path(args.path_to_datasetmap), blacklist=required.get("blacklist"),

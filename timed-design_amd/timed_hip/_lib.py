@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TIMED_HIP_LIB", os.path.join(_HERE, "libtimedhip.so"))
 
 TH_OK = 0
+TH_EINVAL, TH_EIO, TH_EHIP, TH_EUNSUP, TH_ENOMEM, TH_ECOMM, TH_EBUSY = -1, -2, -3, -4, -5, -6, -7      # include/timed_hip.h
 TH_F32, TH_F64, TH_U8, TH_BOOL, TH_F16 = 0, 1, 2, 3, 4
 TH_LOAD_DEFAULT, TH_LOAD_NO_FUSE, TH_LOAD_NO_MFMA, TH_LOAD_KEEP_ALL = 0, 1, 2, 4
 TH_PREDICT_DEFAULT, TH_PREDICT_LOGITS, TH_PREDICT_OUT_DEVICE, TH_PREDICT_IN_DEVICE = 0, 1, 2, 4
@@ -71,6 +72,7 @@ PROTOTYPES = {
     "th_h5_read_chunked_as": (_i, [_vp, _i64, _i64, _i64, _pi64, C.POINTER(_vp), _i, _pi64, _pi64, _i, _i, _pi, _i, _i]),
     "th_h5_read_contiguous_as": (_i, [_vp, _i64, _i64, _i64, _pi64, C.POINTER(_vp), _i64, _i, _i]),
     "th_h5_decode_device": (_i, [_vp, _i64, _i64, _i64, _pi64, _i, _pi64, _pi64, _i, _i, _pi, _i, _i, _vp]),
+    "th_h5_release_scratch": (_i, [_i]),
     "th_inflate_many": (_i, [_i, _vp, _i64, _i64, _pi64, _pi64, _pi64, _pi64, _vp, _i64, _i, _pi]),
     "th_h5_group_links": (_i, [_vp, _i64, _i64, _i64, _i64, _i64, _vp, _i64, _pi64, _i64, _pi64, _pi64]),
     "th_h5_resolve": (_i, [_vp, _i64, _i64, _i64, _pi64, C.c_char_p, _vp, _i, C.c_char_p, _vp, _i, _pi64, _pi64, _pi, _i]),

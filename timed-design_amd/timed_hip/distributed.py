@@ -17,8 +17,9 @@ Two transports for the single exchange step:
                     (th_comm_gather_rows) — the production path on a GPU node.  Its control plane (the
                     128-byte RCCL id, "did every rank come up", text sizes) is ``timed_hip.rendezvous``:
                     plain TCP sockets, NO PyTorch anywhere in the product's N > 1 path;
-  * ``GlooGather``  host arrays through torch.distributed's gloo backend — TEST transport: the CPU
-                    suite drives the real predict.py control flow on 2 and 8 gloo ranks with it.
+  * any object with the same three methods over host arrays — the CPU suite drives the real predict.py control flow
+                    on 2 and 8 gloo ranks with ``tests/_gloo_transport.GlooGather`` (torch.distributed lives in tests/
+                    only: nothing in this package imports PyTorch).
 Both present ``gather_rows(local, counts, root) -> ndarray | None`` plus the small control-plane calls
 ``allgather_ints(values) -> [[...] per rank]`` and ``barrier()``.
 """
@@ -46,44 +47,6 @@ def shard_counts(n: int, world: int) -> List[int]:
 
 def env_rank_world() -> Tuple[int, int, int]:
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
-
-
-class GlooGather:
-    """Row gather of host arrays over an initialised torch.distributed (gloo) group."""
-
-    def __init__(self, group=None):
-        import torch.distributed as dist
-        if not dist.is_initialized():
-            raise RuntimeError("torch.distributed is not initialised (init_process_group(backend='gloo'))")
-        self.dist, self.group = dist, group
-        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
-
-    def gather_rows(self, local: np.ndarray, counts: Sequence[int], root: int = 0) -> Optional[np.ndarray]:
-        import torch
-        local = np.ascontiguousarray(local, dtype=np.float32)
-        if local.shape[0] != counts[self.rank]:
-            raise ValueError(f"rank {self.rank}: local block has {local.shape[0]} rows, expected {counts[self.rank]}")
-        width = local.shape[1]
-        # gloo's gather wants equal sizes: pad every block to the largest shard, trim at the root
-        mx = max(counts) if counts else 0
-        buf = torch.zeros((mx, width), dtype=torch.float32)
-        buf[: local.shape[0]] = torch.from_numpy(local)
-        if self.rank == root:
-            parts = [torch.empty((mx, width), dtype=torch.float32) for _ in range(self.world)]
-            self.dist.gather(buf, parts, dst=root, group=self.group)
-            return np.concatenate([p[:c].numpy() for p, c in zip(parts, counts)], axis=0)
-        self.dist.gather(buf, None, dst=root, group=self.group)
-        return None
-
-    def allgather_ints(self, values: Sequence[int]) -> List[List[int]]:
-        import torch
-        mine = torch.tensor([int(v) for v in values], dtype=torch.int64)
-        parts = [torch.empty_like(mine) for _ in range(self.world)]
-        self.dist.all_gather(parts, mine, group=self.group)
-        return [[int(x) for x in p.tolist()] for p in parts]
-
-    def barrier(self):
-        self.dist.barrier(group=self.group)
 
 
 class RcclGather:
@@ -170,7 +133,7 @@ def predict_sharded(model, frames_for_range, n_total: int, gather, root: int = 0
     """Predict this rank's contiguous shard and gather the probability rows to ``root``.
 
     ``frames_for_range(lo, hi) -> ndarray[hi-lo, D,H,W,C]`` loads the frames of map rows [lo, hi)
-    (e.g. ``lambda lo, hi: load_batch(path, flat_map[lo:hi])[0]``); ``gather`` is a GlooGather (host)
+    (e.g. ``lambda lo, hi: load_batch(path, flat_map[lo:hi])[0]``); ``gather`` is a host transport (tests/_gloo_transport.GlooGather)
     transport.  Returns the full [n_total, n_classes] matrix in map order on ``root``, None elsewhere.
     """
     counts = shard_counts(n_total, gather.world)

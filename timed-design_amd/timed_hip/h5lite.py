@@ -885,6 +885,9 @@ def read_resolved(f: File, resolved: dict, rows, dests, as_float32: bool = False
     return rc == 0
 
 
+MIN_DECODE = 64          # datasets per th_h5_decode_device call below which an out-of-memory batch is not split further
+
+
 def decode_resolved_device(f: File, resolved: dict, d_out: int, device: int, as_float32: bool = False) -> bool:
     """Every dataset of a resolve_many result (all with status bit 1: one shared chunked geometry) inflated ON THE GPU
     straight into device memory at ``d_out`` — [n, *shape] float32 when ``as_float32`` (float64 data) or the stored element
@@ -903,11 +906,29 @@ def decode_resolved_device(f: File, resolved: dict, d_out: int, device: int, as_
     shape, chunk = [int(x) for x in g[1:1 + rank]], [int(x) for x in g[8:8 + rank]]
     n = len(resolved["btree"])
     addrs = np.ascontiguousarray(resolved["btree"], dtype=np.int64)
+    frame_bytes = int(np.prod(shape)) * (4 if as_float32 else esz)
     whole = np.frombuffer(f._m, dtype=np.uint8)
+
+    def decode(lo: int, hi: int) -> int:
+        part = addrs[lo:hi]
+        return lib.th_h5_decode_device(whole.ctypes.data_as(C.c_void_p), whole.size, f._base, hi - lo, part.ctypes.data_as(C.POINTER(C.c_int64)),
+                                       rank, (C.c_int64 * rank)(*shape), (C.c_int64 * rank)(*chunk), esz, len(filters),
+                                       (C.c_int * len(filters))(*filters), 1 if as_float32 else 0, int(device),
+                                       C.c_void_p(int(d_out) + lo * frame_bytes))
     try:
-        rc = lib.th_h5_decode_device(whole.ctypes.data_as(C.c_void_p), whole.size, f._base, n, addrs.ctypes.data_as(C.POINTER(C.c_int64)), rank,
-                                     (C.c_int64 * rank)(*shape), (C.c_int64 * rank)(*chunk), esz, len(filters),
-                                     (C.c_int * len(filters))(*filters), 1 if as_float32 else 0, int(device), C.c_void_p(int(d_out)))
+        # the decoder's token arena is ~5 bytes per uncompressed byte of the batch (9 GB for 4096 float64 frames): when the device
+        # has no room for it (TH_ENOMEM; its scratch is freed then) the batch is decoded in halves, quarters, ... — never below
+        # MIN_DECODE datasets per call, where the host reader is the better path
+        pieces = [(0, n)]
+        while pieces:
+            lo, hi = pieces.pop()
+            rc = decode(lo, hi)
+            if rc == _lib.TH_ENOMEM and hi - lo >= 2 * MIN_DECODE:
+                mid = (lo + hi) // 2
+                pieces += [(mid, hi), (lo, mid)]
+                continue
+            if rc != 0:
+                break
     finally:
         del whole
     if rc == -4:            # TH_EUNSUP: not an error, just not this path

@@ -47,17 +47,24 @@ def read_keras_h5(path) -> Tuple[dict, Dict[str, List[np.ndarray]]]:
             raise ValueError(f"{path}: no model_weights group")
         g = f["model_weights"]
         weights: Dict[str, List[np.ndarray]] = {}
+        top = set(_names(g.attrs["layer_names"]))
+        bare: Dict[str, Dict[str, List[np.ndarray]]] = {}       # inner layer name -> {outer model: its arrays}
         for lname in _names(g.attrs["layer_names"]):
             lg = g[lname]
             wn = _names(lg.attrs["weight_names"]) if "weight_names" in lg.attrs else []
             weights[lname] = [np.asarray(lg[w][()], dtype=np.float32) for w in wn]
             # a nested model used as a layer keeps its layers' weights in ITS group as "<inner layer>/kernel:0" ... in
-            # `layer.weights` order (trainable first): expose them under "<outer>/<inner>" and "<inner>" as well, each in
+            # `layer.weights` order (trainable first): expose them under "<outer>/<inner>" (and "<inner>" where that is unambiguous) as well, each in
             # Keras' per-layer order (kernel, bias / gamma, beta, moving_mean, moving_variance — which that order keeps)
             for w, arr in zip(wn, weights[lname]):
                 parts = w.split("/")
                 if len(parts) >= 2 and parts[0] != lname:
                     inner = "/".join(parts[:-1])
                     weights.setdefault(f"{lname}/{inner}", []).append(arr)
-                    weights.setdefault(parts[-2], []).append(arr)
+                    bare.setdefault(parts[-2], {}).setdefault(lname, []).append(arr)
+        # the bare "<inner>" alias exists only where it is unambiguous: not when a top-level layer has that name (its own list
+        # would grow to 4 arrays), not when two nested models both hold a layer of that name — the qualified key always works
+        for name, owners in bare.items():
+            if name not in top and len(owners) == 1:
+                weights[name] = next(iter(owners.values()))
     return cfg, weights

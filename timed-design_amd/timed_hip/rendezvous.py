@@ -62,7 +62,11 @@ class HostRendezvous:
         base = int(os.environ.get("MASTER_PORT", "29500"))
         fixed = port if port is not None else (int(os.environ["TIMED_RDZV_PORT"]) if os.environ.get("TIMED_RDZV_PORT") else None)
         ports = [fixed] if fixed is not None else [base + 1 + k for k in range(_PORT_SPAN) if base + 1 + k < 65536]
-        token = "|".join([addr, str(base), os.environ.get("TORCHELASTIC_RUN_ID", ""), str(world)]).encode()
+        # what a peer must present: the job's coordinates plus, when the launcher exports one, a shared secret
+        # (TIMED_RDZV_SECRET) — the coordinates alone are guessable from outside the job
+        token = "|".join([addr, str(base), os.environ.get("TORCHELASTIC_RUN_ID", ""), str(world),
+                          os.environ.get("TIMED_RDZV_SECRET", "")]).encode()
+        self._bind_addr = addr
         deadline = time.monotonic() + timeout
         if rank == 0:
             self._serve(ports, token, deadline)
@@ -76,7 +80,14 @@ class HostRendezvous:
             s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             try:
-                s.bind(("", p))
+                # listen on MASTER_ADDR only (loopback for a one-node job), not on every interface; an address that is not
+                # local to this host (a name that resolves elsewhere, a NAT'd address) falls back to the wildcard
+                try:
+                    s.bind((self._bind_addr, p))
+                except (OSError, socket.gaierror) as e:
+                    if getattr(e, "errno", None) == 98:          # EADDRINUSE: this port is taken, try the next one
+                        raise
+                    s.bind(("", p))
                 s.listen(self.world + 8)
                 srv = s
                 break
