@@ -37,9 +37,12 @@ def _logits_oracle(cfg, weights, frames):
 
 
 @pytest.mark.parametrize("name", CASES)
-@pytest.mark.parametrize("flags", [0, _lib.TH_LOAD_NO_MFMA, _lib.TH_LOAD_NO_FUSE | _lib.TH_LOAD_NO_MFMA, _lib.TH_LOAD_NO_FUSE],
-                         ids=["fused_mfma", "fused_direct", "unfused_direct", "unfused_mfma"])
-def test_forward_matches_oracle_and_golden(gpu, cnn_golden, name, flags):
+@pytest.mark.parametrize("flags", [0, -1, _lib.TH_LOAD_NO_MFMA, _lib.TH_LOAD_NO_FUSE | _lib.TH_LOAD_NO_MFMA, _lib.TH_LOAD_NO_FUSE],
+                         ids=["fused_mfma", "fused_mfma_no_winograd", "fused_direct", "unfused_direct", "unfused_mfma"])
+def test_forward_matches_oracle_and_golden(gpu, cnn_golden, monkeypatch, name, flags):
+    if flags == -1:          # the default plan with the Cook-Toom path off: the wide 5^3 layers on the direct MFMA kernels
+        monkeypatch.setenv("TH_WINOGRAD", "0")
+        flags = 0
     z, meta = cnn_golden
     cfg, weights, frames = _build(meta, name)
     m = next(x for x in meta if x["name"] == name)

@@ -233,10 +233,12 @@ def test_nan_and_extreme_inputs_propagate_like_numpy(gpu):
     (5, 64, 20, None, 3, ",7>]"),       # k_conv_n16<4,4,0,4,7> (20-class head)
     (2, 32, 16, None, 19, ",4>]"),      # k_conv_n16<4,4,0,0,4>, 16 frames per workgroup + 3
 ])
-def test_compile_time_geometry_kernels_with_preactivation(gpu, side, cmid, cout, pool, n, tag):
+def test_compile_time_geometry_kernels_with_preactivation(gpu, monkeypatch, side, cmid, cout, pool, n, tag):
     """The instantiations with the staged row geometry fixed at compile time (tap offsets as ds_read immediates; chunks
     after the first re-stage real voxels only): BN -> ReLU in front of the convolution, several Cin chunks, ragged last
-    workgroup; the plan label must name the specialised kernel."""
+    workgroup; the plan label must name the specialised kernel.  (TH_WINOGRAD=0: these are the DIRECT kernels — the wide
+    5^3 layers go to conv_wino.hip by default, tests/test_gpu_wino.py.)"""
+    monkeypatch.setenv("TH_WINOGRAD", "0")
     def build(b, x):
         x = b.conv3d(x, cmid, 1, padding="same")
         y = b.relu(b.batchnorm(x))
@@ -265,7 +267,8 @@ TAIL = [
 def test_heterogeneous_cout_blocks(gpu, shape, cin, cout, pool, post, n, kernels, monkeypatch):
     """the last Cout block of a wide layer on a narrower instantiation (conv_mfma_plan_tail): weights, bias and the
     per-channel BatchNorm vectors of the tail start at its first channel; per-element against the oracle, and
-    bit-identical to the run with the tail switched off (same fmaf chains per output)"""
+    bit-identical to the run with the tail switched off (same fmaf chains per output).  Direct kernels: TH_WINOGRAD=0."""
+    monkeypatch.setenv("TH_WINOGRAD", "0")
     def build(b, x):
         x = b.conv3d(x, cout, 3, padding="same")
         if post == "elu_bn":

@@ -1,0 +1,106 @@
+"""Cook-Toom / Winograd path of the 3x3x3 'same' convolutions on 5^3 volumes (csrc/conv_wino.hip; the default, TH_WINOGRAD=0
+switches it off) against the
+float64 oracle and the torch-fp64 fixtures, through the C ABI.  Same bounds as the direct kernels (tests/test_gpu_cnn.py): the
+transforms are integer / power-of-two matrices and the products run on the fp32 matrix pipe, so the error is accumulation-order
+noise (tools/microbench/winograd_numerics.py: 6.8e-7 on the logits of TIMED-synth against 7.7e-7 for the direct form)."""
+import numpy as np
+import pytest
+
+from oracle import cnn_oracle
+from timed_hip import _lib, engine, synth
+
+pytestmark = pytest.mark.gpu
+TIGHT = 5e-6
+# single layers on DENSE standard-normal inputs (sums of up to 27 x 256 products of magnitude ~1: values around 50 before the
+# BatchNorm): the direct kernel's own worst element is 1.0e-5 x max|y| there (a serial fp32 chain over K = 6912), the Winograd
+# path's 3.3e-5 x (rms 1.6e-6 against 5.9e-7; tools/microbench/wino_layer_error.py) — both accumulation noise at that scale
+LAYER = 1e-5
+
+
+def _one_layer(cin, cout, seed, pre=False, bias=True):
+    b = synth.KerasGraphBuilder((5, 5, 5, cin), seed=seed)
+    x = b.input_name
+    if pre:                                   # DenseNet-style pre-activation: BN -> ReLU -> Conv
+        x = b.batchnorm(x)
+        x = b.relu(x)
+    x = b.conv3d(x, cout, 3, padding="same", use_bias=bias)
+    x = b.elu(x)
+    x = b.batchnorm(x)
+    name = x
+    x = b.gap(x)
+    x = b.softmax(x)
+    cfg, w = b.finish(x)
+    if bias:                                  # the builder's biases are zero: make them count
+        rng = np.random.default_rng(seed + 1)
+        for k, arrs in w.items():
+            if k.startswith("conv3d") and len(arrs) == 2:
+                arrs[1] = rng.normal(0, 0.2, arrs[1].shape).astype(np.float32)
+    return cfg, w, name
+
+
+@pytest.mark.parametrize("cin,cout,n,pre", [(32, 64, 1, False), (64, 128, 3, False), (128, 128, 64, False), (128, 256, 65, False),
+                                            (256, 338, 5, False), (32, 96, 130, True), (64, 64, 7, True)])
+def test_single_layer_matches_the_float64_oracle(gpu, monkeypatch, cin, cout, n, pre):
+    """one Conv -> ELU -> BN block (with and without a BN -> ReLU prologue), frame counts around the 64-frame GEMM row block,
+    Cout that is not a multiple of the 128-column block (96, 338): the layer's tensor against the oracle in float64"""
+    monkeypatch.setenv("TH_WINOGRAD", "1")
+    cfg, w, layer = _one_layer(cin, cout, seed=cin + cout, pre=pre)
+    rng = np.random.default_rng(n)
+    frames = (rng.standard_normal((n, 5, 5, 5, cin)) * (rng.random((n, 5, 5, 5, cin)) < 0.5)).astype(np.float32)
+    model = engine.HipFrameModel.from_keras(cfg, w, device=gpu)       # (the block's last tensor is materialised: fetch works)
+    assert any("conv_wino" in s["label"] for s in model.steps()), [s["label"] for s in model.steps()]
+    probs = model.predict(frames)
+    ref = cnn_oracle.forward(cfg, w, frames[: min(n, 8)], np.float64, return_all=True)
+    got = model.fetch(layer, min(n, 8), (5, 5, 5, cout))
+    want = ref[layer]
+    np.testing.assert_allclose(got, want, atol=LAYER * max(1.0, float(np.abs(want).max())), rtol=0)
+    assert float(np.sqrt(np.mean((got - want) ** 2))) < 3e-6
+    last = list(ref)[-1]
+    np.testing.assert_allclose(probs[: min(n, 8)], ref[last], atol=TIGHT, rtol=0)
+    if n > 8:                                 # every row block and the ragged last one: against the direct kernels
+        model.close()
+        monkeypatch.setenv("TH_WINOGRAD", "0")
+        direct = engine.HipFrameModel.from_keras(cfg, w, device=gpu)
+        assert not any("conv_wino" in s["label"] for s in direct.steps())
+        np.testing.assert_allclose(probs, direct.predict(frames), atol=TIGHT, rtol=0)
+        direct.close()
+    else:
+        model.close()
+
+
+@pytest.mark.parametrize("name", ["timed20", "timed338", "timed20_c5_bias", "timed20_bool"])
+def test_timed_fixtures_with_winograd(gpu, cnn_golden, monkeypatch, name):
+    """the torch-fp64 fixtures of tests/test_gpu_cnn.py with the 5^3 layers on the Winograd path: same 5e-6 bound on
+    probabilities and logits, same argmax; small and large chunks (one launch, and launches of 1-3 frames)"""
+    monkeypatch.setenv("TH_WINOGRAD", "1")
+    z, meta = cnn_golden
+    m = next(x for x in meta if x["name"] == name)
+    cfg, weights = getattr(synth, m["builder"])(**m["kwargs"])
+    frames = synth.synthetic_frames(m["n"], **m["frame_kwargs"])
+    model = engine.HipFrameModel.from_keras(cfg, weights, device=gpu)
+    assert sum("conv_wino" in s["label"] for s in model.steps()) >= 3
+    for chunk in (1024, 3):
+        model.set_chunk(chunk)
+        probs = model.predict(frames)
+        np.testing.assert_allclose(probs, z[f"{name}__torch64"], atol=TIGHT, rtol=0)
+        assert np.array_equal(probs.argmax(1), z[f"{name}__torch64"].argmax(1))
+        logits = model.predict(frames, logits=True)
+        np.testing.assert_allclose(logits, z[f"{name}__logits64"], atol=TIGHT, rtol=0)
+    model.close()
+
+
+def test_winograd_is_not_taken_where_it_does_not_apply(gpu, monkeypatch):
+    """valid padding, 10^3 volumes, strides, narrow heads and 1x1x1 layers stay on the direct kernels"""
+    monkeypatch.setenv("TH_WINOGRAD", "1")
+    cfg, w = synth.densecpd_synth(20)
+    model = engine.HipFrameModel.from_keras(cfg, w, device=gpu)
+    labels = [s["label"] for s in model.steps()]
+    assert not any("conv_wino" in l for l in labels)         # growth convs are 16 wide, bottlenecks 1x1x1
+    model.close()
+    cfg, w = synth.timed_synth(20)
+    model = engine.HipFrameModel.from_keras(cfg, w, device=gpu)
+    labels = [s["label"] for s in model.steps()]
+    conv = [l for l in labels if l.startswith("conv3d") and "wino_in" not in l and "wino_out" not in l]
+    assert [("k_wino_gemm" in l) for l in conv] == [False, False, True, True, True, False]
+    assert sum("k_wino_in" in l for l in labels) == 3 and sum("k_wino_out" in l for l in labels) == 3
+    model.close()

@@ -76,6 +76,7 @@ struct Step {
     std::string label;
     std::function<int(hipStream_t, int64_t)> run;
     double flops = 0, exec_flops = 0, bytes = 0;  // per frame
+    double direct_flops = -1;     // >= 0: this step's share of the model's direct-form FLOP count when it differs from `flops` (Winograd)
     double ms = 0;
     int64_t launches = 0;
     int out_node = -1;
@@ -103,6 +104,8 @@ struct th_model {
     std::vector<float*> dev_allocs;  // weights & derived tensors (freed at th_model_free)
     std::vector<Buffer> bufs;
     std::vector<Step> steps;
+    int wino_v_buf = -1, wino_m_buf = -1;   // scratch arenas of the Winograd layers (shared: the layers run one after the other)
+    int winograd = 1;                       // eligible 3x3x3 'same' layers on 5^3 volumes run on conv_wino.hip (TH_WINOGRAD=0: direct kernels)
     int input_node = -1, output_node = -1, logits_node = -1;
     int in_dims[4] = {0, 0, 0, 0};
     int n_classes = 0;
@@ -515,7 +518,49 @@ int plan(th_model* m) {
                     if (M->blob_count[n.w[0]] != wcount) TH_FAIL(TH_EIO, "%s: kernel size mismatch", n.name.c_str());
                     st.flops = 2.0 * n.D * n.H * n.W * (double)g.kd * g.kh * g.kw * Cin * Cout;
                     st.bytes = 4.0 * ((double)sn.D * sn.H * sn.W * Cin + (double)N[dst].D * N[dst].H * N[dst].W * N[dst].C);
-                    if (mplans.count(i) && mplans[i].cfg == 100) {
+                    ConvWinoPlan wp;
+                    TView wiv; wiv.D = sn.D; wiv.H = sn.H; wiv.W = sn.W; wiv.C = sn.C;
+                    TView wov; wov.D = n.D; wov.H = n.H; wov.W = n.W; wov.C = n.C;
+                    if (M->winograd && use_mfma && fuse && f.pool < 0 && !split_softmax && conv_wino_plan(wiv, wov, g, Cin, Cout, &wp)) {
+                        std::vector<float> packed(wp.wpk_floats);
+                        conv_wino_pack_weights(wp, hw, packed.data());
+                        float* dw;
+                        if ((rc = upload(M, packed.data(), packed.size(), &dw))) return rc;
+                        if (M->wino_v_buf < 0) {
+                            Buffer b;
+                            M->bufs.push_back(b); M->wino_v_buf = (int)M->bufs.size() - 1;
+                            M->bufs.push_back(b); M->wino_m_buf = (int)M->bufs.size() - 1;
+                        }
+                        M->bufs[M->wino_v_buf].floats_per_frame = std::max(M->bufs[M->wino_v_buf].floats_per_frame, wp.v_fpf);
+                        M->bufs[M->wino_m_buf].floats_per_frame = std::max(M->bufs[M->wino_m_buf].floats_per_frame, wp.m_fpf);
+                        // three steps, one kernel each.  `direct_flops` (the SURVEY §8d count of the direct form) stays with the
+                        // GEMM step for the model total; the per-step `flops` are what the kernels really compute: the GEMM's own
+                        // multiply-adds, nothing for the two bandwidth-bound transforms (their bytes are V / M traffic)
+                        const double direct = st.flops, act_bytes = st.bytes;
+                        const int64_t vf = wp.v_fpf, mf = wp.m_fpf;
+                        auto Vp = [=]() { const Buffer& b = M->bufs[M->wino_v_buf]; return b.dev + M->lane_off * b.floats_per_frame; };
+                        auto Mp = [=]() { const Buffer& b = M->bufs[M->wino_m_buf]; return b.dev + M->lane_off * b.floats_per_frame; };
+                        Step a;
+                        a.out_node = st.out_node;
+                        a.label = n.name + ": wino_in (25 voxels -> 81 points per plane) [k_wino_in]";
+                        a.bytes = 4.0 * ((double)sn.D * sn.H * sn.W * Cin + (double)vf);
+                        a.run = [=](hipStream_t s, int64_t cnt) { return launch_wino_in(s, cnt, wp, M->view(src), Vp(), pre); };
+                        add_step(a);
+                        st.flops = wp.gemm_flops;
+                        st.direct_flops = direct;
+                        st.exec_flops = wp.exec_flops;
+                        st.bytes = 4.0 * ((double)vf + (double)mf);
+                        st.label = n.name + ": " + wp.label + " [k_wino_gemm]";
+                        st.run = [=](hipStream_t s, int64_t cnt) { return launch_wino_gemm(s, cnt, wp, Vp(), Mp(), dw); };
+                        add_step(st);
+                        Step o;
+                        o.out_node = st.out_node;
+                        o.label = n.name + ": wino_out (81 points -> 25 voxels per plane, bias + epilogue) [k_wino_out]";
+                        o.bytes = 4.0 * ((double)mf / wp.Coutp * Cout + (act_bytes / 4.0 - (double)sn.D * sn.H * sn.W * Cin));
+                        o.run = [=](hipStream_t s, int64_t cnt) { return launch_wino_out(s, cnt, wp, Mp(), M->view(dst), dbias, po); };
+                        add_step(o);
+                        continue;
+                    } else if (mplans.count(i) && mplans[i].cfg == 100) {
                         const ConvMfmaPlan mp = mplans[i];
                         std::vector<float> packed(mp.wpk_floats);
                         conv_first_pack_weights(Cin, Cout, hw, packed.data());
@@ -723,7 +768,7 @@ int plan(th_model* m) {
         }
         add_step(st);
     }
-    for (const Step& s : m->steps) { m->algo_flops += s.flops; m->exec_flops += s.exec_flops; }
+    for (const Step& s : m->steps) { m->algo_flops += s.direct_flops >= 0 ? s.direct_flops : s.flops; m->exec_flops += s.exec_flops; }
     (void)V;
     return TH_OK;
 }
@@ -734,7 +779,8 @@ int ensure_buffers(th_model* m) {
         if (b.dev) { HIP_TRY(hipFree(b.dev)); b.dev = nullptr; }
     }
     for (Buffer& b : m->bufs) {
-        const size_t bytes = (size_t)b.floats_per_frame * m->chunk * sizeof(float) + 256;
+        // (chunk rounded up to 64 frames: the Winograd scratch is addressed in 64-frame GEMM row blocks)
+        const size_t bytes = (size_t)b.floats_per_frame * ((m->chunk + 63) / 64 * 64) * sizeof(float) + 256;
         HIP_TRY(hipMalloc(&b.dev, bytes));
         // channel-padding lanes of the input arena and unused concat lanes must hold finite values
         HIP_TRY(hipMemsetAsync(b.dev, 0, bytes, m->stream));
@@ -867,6 +913,7 @@ int load_common(th_model* m) {
     HIP_TRY(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
     if (const char* e = getenv("TH_LANES")) m->lanes = atoi(e) == 2 ? 2 : 1;
+    if (const char* e = getenv("TH_WINOGRAD")) m->winograd = atoi(e) != 0;
     if (const char* e = getenv("TH_LANE_LAG")) m->lane_lag = std::max(0, atoi(e));
     for (int r = 0; r < th_model::kRing; ++r) {
         HIP_TRY(hipEventCreateWithFlags(&m->ev_h2d[r], hipEventDisableTiming));
@@ -1189,10 +1236,16 @@ int th_model_profile(th_model* m, int enable) {
     if (!m) TH_FAIL(TH_EINVAL, "null model");
     if (enable < 0 || enable > 2) TH_FAIL(TH_EINVAL, "profile mode must be 0, 1 or 2");
     m->profiling = enable;
+    // mode 2 brackets the DOMINANT step only: the one that took the most device time in a preceding mode-1 run (bench.py's
+    // warm-up), else the one with the most FLOPs
     m->dominant_step = -1;
     double best = -1;
-    for (size_t i = 0; i < m->steps.size(); ++i)
-        if (m->steps[i].flops > best) { best = m->steps[i].flops; m->dominant_step = (int)i; }
+    bool timed = false;
+    for (const Step& s : m->steps) timed = timed || s.launches > 0;
+    for (size_t i = 0; i < m->steps.size(); ++i) {
+        const double v = timed ? m->steps[i].ms : m->steps[i].flops;
+        if (v > best) { best = v; m->dominant_step = (int)i; }
+    }
     for (Step& s : m->steps) { s.ms = 0; s.launches = 0; }
     return TH_OK;
 }

@@ -416,10 +416,12 @@ def topology_rate(name, device, d_frames_ptr, n, chunk, steps=2, traffic=None, c
     algo_bytes = D * H * W * Cc * 4 + 4 * model.n_classes
     fps = n / dt
     dom = max(table, key=lambda s: s["ms"])
+    kflops = sum(s["flops"] for s in model.steps())        # what the kernels compute (Winograd layers: their own, fewer, FLOPs)
     res = {"topology": name, "frames": n, "chunk": chunk, "n_classes": model.n_classes, "frames_per_s": fps, "rows_verified": n,
-           "algo_mflop_per_frame": cost["algo_flops"] / 1e6, "model_tflops": fps * cost["algo_flops"] / 1e12,
-           "model_roofline": {"bound": "mfma", "achieved": fps * cost["algo_flops"] / 1e12, "peak": 157.3, "unit": "TFLOP/s",
-                              "frac": fps * cost["algo_flops"] / 1e12 / 157.3,
+           "algo_mflop_per_frame": cost["algo_flops"] / 1e6, "kernel_mflop_per_frame": kflops / 1e6, "model_tflops": fps * kflops / 1e12,
+           "model_direct_equiv_tflops": fps * cost["algo_flops"] / 1e12,
+           "model_roofline": {"bound": "mfma", "achieved": fps * kflops / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                              "frac": fps * kflops / 1e12 / 157.3,
                               "traffic": (traffic or {}).get("model"), "traffic_frames": (traffic or {}).get("chunk"),
                               "algorithmic_bytes": algo_bytes * ((traffic or {}).get("chunk") or 0) or None},
            "hbm": {"algo_bytes_per_frame": algo_bytes, "achieved_GBps": fps * algo_bytes / 1e9, "frac": fps * algo_bytes / 1e9 / 8000.0},

@@ -85,13 +85,13 @@ def compact(full: dict, detail_path: str | None = None) -> dict:
     line["value"] = _r(full["value"], 7)
     line["ms_per_step"] = _r(full["ms_per_step"], 6)
     cfg = dict(full.get("config") or {})
-    for k in ("algo_mflop_per_frame", "exec_mflop_per_frame"):
+    for k in ("algo_mflop_per_frame", "exec_mflop_per_frame", "kernel_mflop_per_frame"):
         if k in cfg:
             cfg[k] = _r(cfg[k], 6)
     if isinstance(cfg.get("exchange"), str):
         cfg["exchange"] = cfg["exchange"][:120]
     line["config"] = cfg
-    for k in ("model_tflops", "model_frac_of_fp32_mfma_peak"):
+    for k in ("model_tflops", "model_frac_of_fp32_mfma_peak", "model_direct_equiv_tflops"):
         if k in full:
             line[k] = _r(full[k])
     if "hbm" in full:

@@ -58,7 +58,20 @@ def cook_toom(m: int, r: int = 3, points=None):
     AT = [[evalm(m)[i][j] for i in range(a)] for j in range(m)]
     G = evalm(r)
     BT = [[Vi[j][i] for j in range(a)] for i in range(a)]
-    # balance: scale row i of BT by s_i and row i of G by 1 / s_i so that BT has small integers where it can
+    # balance: row i of BT times s_i, row i of G by 1 / s_i, with s_i the smallest factor that makes the BT row integer: the data
+    # transform then multiplies by small integers only (exact products), and the fractions go into the weights, which are
+    # transformed once on the host in double precision
+    from math import gcd
+    for i in range(a):
+        den = 1
+        for v in BT[i]:
+            den = den * v.denominator // gcd(den, v.denominator)
+        num = 0
+        for v in BT[i]:
+            num = gcd(num, abs(int(v * den)))
+        sc = Fraction(den, num or 1)
+        BT[i] = [v * sc for v in BT[i]]
+        G[i] = [v / sc for v in G[i]]
     f = lambda M: np.array([[float(v) for v in row] for row in M], dtype=np.float64)
     return f(AT), f(G), f(BT)
 
@@ -104,11 +117,58 @@ def winograd_conv3d_same(x, kernel, bias, segments, dtype=np.float32):
     return y.astype(dtype)
 
 
+def winograd_inplane_conv3d_same(x, kernel, bias, segments, dtype=np.float32):
+    """what csrc/conv_wino.hip computes: Cook-Toom in the two in-plane axes, the three z taps summed directly —
+    M[z][a][b] = sum_dz V[z + dz - 1][a][b] . U[dz][a][b] (P^2 positions x 13 valid (z, dz) pairs for n = 5)"""
+    n = x.shape[1]
+    BTc, Gc, ATc = composite(n, segments)
+    U = np.einsum("bj,ck,ijkmo->ibcmo", Gc, Gc, kernel.astype(np.float64)).astype(dtype)              # [dz][a][b][ci][co]
+    xr = x.astype(dtype)
+    B = BTc[:, 1:n + 1].astype(dtype)
+    A = ATc.astype(dtype)
+    v = np.einsum("bj,nzjkm->nzbkm", B, xr)
+    v = np.einsum("ck,nzbkm->nzbcm", B, v)                   # V[n][z][a][b][ci]
+    vp = np.pad(v, [(0, 0), (1, 1), (0, 0), (0, 0), (0, 0)])
+    m_ = np.zeros(v.shape[:4] + (kernel.shape[-1],), dtype=dtype)
+    for dz in range(3):
+        m_ = m_ + np.einsum("nzbcm,bcmo->nzbco", vp[:, dz:dz + n], U[dz]).astype(dtype)
+    y = np.einsum("jb,nzbco->nzjco", A, m_)
+    y = np.einsum("kc,nzjco->nzjko", A, y)
+    if bias is not None:
+        y = y + bias.astype(dtype)
+    return y.astype(dtype)
+
+
+def emit_header(path, n=5, segments=(3, 2)):
+    """csrc/wino_tables.h: the per-axis composite matrices of the [3, 2] cut of a 5-wide 'same' axis, for the HIP kernels and the
+    host-side weight transform"""
+    BTc, Gc, ATc = composite(n, list(segments))
+    P = BTc.shape[0]
+    def arr(name, M, typ):
+        rows = ",\n    ".join("{" + ", ".join(repr(float(v)) if typ == "double" else (f"{v:.10g}f" if v != int(v) else f"{int(v)}.f") for v in r) + "}" for r in M)
+        dev = "__device__ " if typ == "float" else ""      # the float tables are read by the kernels (folded after unrolling)
+        return f"static {dev}constexpr {typ} {name}[{M.shape[0]}][{M.shape[1]}] = {{\n    {rows}}};\n"
+    txt = ("// GENERATED by tools/microbench/winograd_numerics.py --emit-header — do not edit.\n"
+           f"// Cook-Toom minimal filtering F(m, 3) for a 'same' 3-tap axis of {n} outputs cut into segments {list(segments)}:\n"
+           f"// {P} products per axis instead of {3 * n}.  y = AT [(G g) * (BT d)], d = the axis WITHOUT its zero halo (the two halo\n"
+           "// columns of BT multiply zeros and are dropped).  BT is integer (exact products); the fractions live in G, applied to the\n"
+           "// weights once on the host in double precision.\n#pragma once\n"
+           f"#define WINO_N {n}\n#define WINO_P {P}\n")
+    txt += arr("kWinoBT", BTc[:, 1:n + 1], "float") + arr("kWinoAT", ATc, "float") + arr("kWinoG", Gc, "double")
+    open(path, "w").write(txt)
+    print("wrote", path)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=32)
     ap.add_argument("--classes", type=int, default=20)
+    ap.add_argument("--only", default="", help="substring of the plan names to run")
+    ap.add_argument("--emit-header", action="store_true", help="write timed-design_amd/csrc/wino_tables.h and exit")
     args = ap.parse_args()
+    if args.emit_header:
+        emit_header(os.path.join(ROOT, "timed-design_amd", "csrc", "wino_tables.h"))
+        return
     from oracle import cnn_oracle
     from timed_hip import synth
 
@@ -135,7 +195,10 @@ def main():
     print(f"logits: max |x| = {scale:.3f}; direct fp32 oracle: max |dlogit| = {np.abs(direct[logit_layer] - ref64[logit_layer]).max():.3e}")
 
     real_conv = cnn_oracle.conv3d
+    got = winograd_inplane_conv3d_same(xs, ks, None, [3, 2], np.float64)
+    assert np.abs(got - want).max() < 1e-9
     plans = {
+        "5^3 in-plane [3,2], z direct": {5: ("inplane", [3, 2])},
         "5^3 layers [2,2,1]": {5: [2, 2, 1]},
         "5^3 layers [3,2]": {5: [3, 2]},
         "5^3 layers [5]": {5: [5]},
@@ -145,10 +208,14 @@ def main():
         "5^3 [5] + 10^3 [5,5]": {5: [5], 10: [5, 5]},
     }
     for name, plan in plans.items():
+        if args.only and args.only not in name:
+            continue
         def conv(x, kernel, bias, strides, dilation, padding, acc_dtype):
             n = x.shape[1]
             if (acc_dtype == np.float32 and kernel.shape[:3] == (3, 3, 3) and padding == "same" and n in plan
                     and cnn_oracle._t3(strides) == (1, 1, 1) and x.shape[1:4] == (n, n, n)):
+                if isinstance(plan[n], tuple):
+                    return winograd_inplane_conv3d_same(x, kernel, bias, plan[n][1])
                 return winograd_conv3d_same(x, kernel, bias, plan[n])
             return real_conv(x, kernel, bias, strides, dilation, padding, acc_dtype)
         cnn_oracle.conv3d = conv

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Per-kernel averages of every counter found in rocprofv3 rocpd .db files (conv kernels only)."""
 import collections, re, sqlite3, sys
+MIN_US = 100
 for db in sys.argv[1:]:
     c = sqlite3.connect(db)
     names = dict(c.execute("select id,name from rocpd_info_pmc"))
@@ -10,14 +11,18 @@ for db in sys.argv[1:]:
         vals[ev][names[pid]] = vals[ev].get(names[pid], 0) + v
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for ev, name, st, en, wgs, lds in disp:
-        if "conv" not in name: continue
-        key = (re.sub(r".*(k_conv_[a-z0-9]+<[^>]*>).*", r"\1", name), wgs, lds)
+        if "conv" not in name and "wino" not in name: continue
+        key = (re.sub(r".*(k_(?:conv|wino)_[a-z0-9]+(?:<[^>]*>)?).*", r"\1", name), wgs, lds)
         for k, v in vals[ev].items(): agg[key][k].append(v)
         agg[key]["dur_us"].append((en - st) / 1e3)
     for key, d in sorted(agg.items(), key=lambda kv: -sum(kv[1]["dur_us"])):
         m = {k: sum(v) / len(v) for k, v in d.items()}
         print(key, "dur_us=%.1f" % m["dur_us"])
-        if "GRBM_GUI_ACTIVE" in m:
+        if "GRBM_GUI_ACTIVE" in m and m["dur_us"] < MIN_US:
+            # the derived clock of such short dispatches reads 2.8-3.5 GHz (the counter window is wider than the kernel):
+            # MFMA-busy / TF/s computed from it are artefacts and are not printed
+            print("    (shorter than %d us: derived clock / MFMA-busy / TF/s not meaningful, omitted)" % MIN_US)
+        elif "GRBM_GUI_ACTIVE" in m:
             cyc = m["GRBM_GUI_ACTIVE"] / 8  # summed over 8 XCDs
             print("    clock %.3f GHz  MFMA-busy %.1f%%  exec TF/s %.1f" % (cyc / m["dur_us"] / 1e3, 100 * m["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024), m.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0) * 512 / m["dur_us"] / 1e6))
             wc = m["SQ_WAVE_CYCLES"]
