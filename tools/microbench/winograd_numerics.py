@@ -199,6 +199,8 @@ def main():
     assert np.abs(got - want).max() < 1e-9
     plans = {
         "5^3 in-plane [3,2], z direct": {5: ("inplane", [3, 2])},
+        "5^3 in-plane [5], z direct": {5: ("inplane", [5])},
+        "5^3 in-plane [4,1], z direct": {5: ("inplane", [4, 1])},
         "5^3 layers [2,2,1]": {5: [2, 2, 1]},
         "5^3 layers [3,2]": {5: [3, 2]},
         "5^3 layers [5]": {5: [5]},
