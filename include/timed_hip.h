@@ -244,6 +244,11 @@ int th_h5_read_contiguous_as(const void* file, int64_t file_len, int64_t base, i
 int th_h5_decode_device(const void* file, int64_t file_len, int64_t base, int64_t n_datasets, const int64_t* btree_addrs, int rank,
                         const int64_t* shape, const int64_t* chunk, int esz, int n_filters, const int* filter_ids, int conv, int device,
                         void* d_out);
+/* th_model_free keeps a model's device blocks (weights, arenas, rings) in a per-process cache for the next th_model_load
+ * (hipFree synchronises the device: ~13 ms per TIMED handle, paid by every predict.py call that loads and frees a model as
+ * reference predict.py:114-121 does); at most 24 GB are kept.  th_dev_trim returns the cached blocks of `device` (all devices
+ * when negative) to HIP. */
+int th_dev_trim(int device);
 /* th_h5_decode_device keeps per-device scratch memory between calls (compressed span, token arena: ~5 bytes per uncompressed
  * byte of the largest batch so far).  When an allocation fails it frees that scratch and returns TH_ENOMEM — decode fewer
  * datasets per call or read through th_h5_read_chunked_as; th_h5_release_scratch frees it on request (end of a run). */

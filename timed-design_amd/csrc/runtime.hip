@@ -33,6 +33,93 @@ void th_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// ---- device block cache ---------------------------------------------------------------------------------------------------
+// predict.py loads and frees a model per call (the reference does: predict.py:114-121); a TIMED handle is ~50 device blocks —
+// weights, activation arenas, rings — and hipFree synchronises the device each time: 13 ms per close, 10 ms per load.  Blocks a
+// model gives back are kept here (exact-size reuse, at most kCacheBytes per process) and returned to HIP by th_dev_trim or when
+// the cap is reached.  Callers synchronise the streams that used a block before they release it.
+namespace {
+struct DevCache {
+    std::mutex mu;
+    std::multimap<std::pair<int, size_t>, void*> free_blocks;   // (device, bytes) -> block
+    std::map<void*, std::pair<int, size_t>> live;               // blocks handed out
+    size_t cached_bytes = 0;
+    static constexpr size_t kCacheBytes = 24ull << 30;
+    static constexpr size_t kCacheBlocks = 1024;
+};
+DevCache g_cache;
+
+int cached_malloc(void** out, size_t bytes, int device) {
+    if (!bytes) bytes = 4;
+    {
+        std::lock_guard<std::mutex> lock(g_cache.mu);
+        auto it = g_cache.free_blocks.find({device, bytes});
+        if (it != g_cache.free_blocks.end()) {
+            *out = it->second;
+            g_cache.free_blocks.erase(it);
+            g_cache.cached_bytes -= bytes;
+            g_cache.live[*out] = {device, bytes};
+            return TH_OK;
+        }
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e == hipErrorOutOfMemory) {                 // give the cache back and try once more
+        (void)hipGetLastError();
+        std::vector<void*> drop;
+        {
+            std::lock_guard<std::mutex> lock(g_cache.mu);
+            for (auto& kv : g_cache.free_blocks) drop.push_back(kv.second);
+            g_cache.free_blocks.clear();
+            g_cache.cached_bytes = 0;
+        }
+        for (void* p : drop) (void)hipFree(p);
+        e = hipMalloc(out, bytes);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        TH_FAIL(e == hipErrorOutOfMemory ? TH_ENOMEM : TH_EHIP, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    }
+    std::lock_guard<std::mutex> lock(g_cache.mu);
+    g_cache.live[*out] = {device, bytes};
+    return TH_OK;
+}
+
+void cached_free(void* p) {
+    if (!p) return;
+    std::pair<int, size_t> key;
+    {
+        std::lock_guard<std::mutex> lock(g_cache.mu);
+        auto it = g_cache.live.find(p);
+        if (it == g_cache.live.end()) { (void)hipFree(p); return; }
+        key = it->second;
+        g_cache.live.erase(it);
+        if (g_cache.cached_bytes + key.second <= DevCache::kCacheBytes && g_cache.free_blocks.size() < DevCache::kCacheBlocks) {
+            g_cache.free_blocks.insert({key, p});
+            g_cache.cached_bytes += key.second;
+            return;
+        }
+    }
+    (void)hipFree(p);
+}
+}  // namespace
+
+extern "C" int th_dev_trim(int device) {
+    std::vector<void*> drop;
+    {
+        std::lock_guard<std::mutex> lock(g_cache.mu);
+        for (auto it = g_cache.free_blocks.begin(); it != g_cache.free_blocks.end();) {
+            if (device < 0 || it->first.first == device) {
+                drop.push_back(it->second);
+                g_cache.cached_bytes -= it->first.second;
+                it = g_cache.free_blocks.erase(it);
+            } else ++it;
+        }
+    }
+    if (drop.empty()) return TH_OK;                 // nothing cached: no HIP call at all
+    for (void* p : drop) (void)hipFree(p);
+    return TH_OK;
+}
+
 namespace {
 
 // ---- pack (mirrors timed_hip/pack.py) -----------------------------------------------------------
@@ -173,7 +260,7 @@ namespace {
 
 int upload(th_model* m, const float* h, size_t count, float** out) {
     float* d = nullptr;
-    HIP_TRY(hipMalloc(&d, (count ? count : 1) * sizeof(float)));
+    if (int rc = cached_malloc((void**)&d, (count ? count : 1) * sizeof(float), m->device)) return rc;
     m->dev_allocs.push_back(d);
     if (count) HIP_TRY(hipMemcpy(d, h, count * sizeof(float), hipMemcpyHostToDevice));
     *out = d;
@@ -776,12 +863,12 @@ int plan(th_model* m) {
 int ensure_buffers(th_model* m) {
     if (m->chunk_alloc >= m->chunk) return TH_OK;
     for (Buffer& b : m->bufs) {
-        if (b.dev) { HIP_TRY(hipFree(b.dev)); b.dev = nullptr; }
+        if (b.dev) { cached_free(b.dev); b.dev = nullptr; }
     }
     for (Buffer& b : m->bufs) {
         // (chunk rounded up to 64 frames: the Winograd scratch is addressed in 64-frame GEMM row blocks)
         const size_t bytes = (size_t)b.floats_per_frame * ((m->chunk + 63) / 64 * 64) * sizeof(float) + 256;
-        HIP_TRY(hipMalloc(&b.dev, bytes));
+        if (int rc = cached_malloc((void**)&b.dev, bytes, m->device)) return rc;
         // channel-padding lanes of the input arena and unused concat lanes must hold finite values
         HIP_TRY(hipMemsetAsync(b.dev, 0, bytes, m->stream));
     }
@@ -988,15 +1075,15 @@ void th_model_free(th_model* m) {
     if (m->copy_stream) (void)hipStreamSynchronize(m->copy_stream);
     if (m->d2h_stream) (void)hipStreamSynchronize(m->d2h_stream);
     if (m->stream2) (void)hipStreamSynchronize(m->stream2);
-    for (float* p : m->dev_allocs) (void)hipFree(p);
-    for (Buffer& b : m->bufs) if (b.dev) (void)hipFree(b.dev);
+    for (float* p : m->dev_allocs) cached_free(p);
+    for (Buffer& b : m->bufs) if (b.dev) cached_free(b.dev);
     for (int r = 0; r < th_model::kRing; ++r) {
-        if (m->d_in_ring[r]) (void)hipFree(m->d_in_ring[r]);
+        if (m->d_in_ring[r]) cached_free(m->d_in_ring[r]);
         if (m->ev_h2d[r]) (void)hipEventDestroy(m->ev_h2d[r]);
         if (m->ev_free[r]) (void)hipEventDestroy(m->ev_free[r]);
     }
     for (th_model::Ticket& t : m->tickets) {
-        if (t.d_out) (void)hipFree(t.d_out);
+        if (t.d_out) cached_free(t.d_out);
         if (t.h_out) (void)hipHostFree(t.h_out);
         if (t.computed) (void)hipEventDestroy(t.computed);
         if (t.done) (void)hipEventDestroy(t.done);
@@ -1089,20 +1176,21 @@ static int predict_async_locked(th_model* m, const void* frames, int dtype, int6
         HIP_TRY(hipStreamSynchronize(m->copy_stream));
         HIP_TRY(hipStreamSynchronize(m->stream));
         for (int r = 0; r < th_model::kRing; ++r) {
-            if (m->d_in_ring[r]) HIP_TRY(hipFree(m->d_in_ring[r]));
+            if (m->d_in_ring[r]) cached_free(m->d_in_ring[r]);
             m->d_in_ring[r] = nullptr;
             m->ring_used[r] = false;
         }
         m->in_ring_bytes = 0;
-        for (int r = 0; r < th_model::kRing; ++r) HIP_TRY(hipMalloc(&m->d_in_ring[r], need_in));
+        for (int r = 0; r < th_model::kRing; ++r)
+            if (int rc = cached_malloc(&m->d_in_ring[r], need_in, m->device)) return rc;
         m->in_ring_bytes = need_in;
     }
     const size_t floats = (size_t)n * width;
     const bool out_on_device = (flags & TH_PREDICT_OUT_DEVICE) != 0;   // probs_out is device memory: no copy back
     if (!out_on_device && t.d_out_floats < floats) {
-        if (t.d_out) HIP_TRY(hipFree(t.d_out));
+        if (t.d_out) cached_free(t.d_out);
         t.d_out = nullptr; t.d_out_floats = 0;
-        HIP_TRY(hipMalloc(&t.d_out, std::max<size_t>(floats, 1024) * sizeof(float)));
+        if (int rc = cached_malloc((void**)&t.d_out, std::max<size_t>(floats, 1024) * sizeof(float), m->device)) return rc;
         t.d_out_floats = std::max<size_t>(floats, 1024);
     }
     if (!out_on_device && t.h_out_floats < floats) {

@@ -353,7 +353,8 @@ _DEVICE_POOL = _DevicePool()
 
 def release_device_memory(devices=None) -> None:
     """Give back what load_batch_device keeps between calls so that the next call is fast: the pooled batch buffers (up to six of
-    frames_per_call frames each) and the GPU decoder's scratch (token arena, ~5 bytes per uncompressed byte of a batch).  predict.py's
+    frames_per_call frames each), the GPU decoder's scratch (token arena, ~5 bytes per uncompressed byte of a batch) and the device
+    blocks of closed models (weights / arenas kept for the next load).  predict.py's
     CLI calls it when its run ends; a long-lived process (the UI) calls it when it is done predicting.  No reference counterpart
     (the reference holds no device memory)."""
     from timed_hip import _lib
@@ -361,6 +362,7 @@ def release_device_memory(devices=None) -> None:
     lib = _lib.load()
     for d in (range(16) if devices is None else devices):
         lib.th_h5_release_scratch(int(d))
+        lib.th_dev_trim(int(d))              # device blocks of closed models, kept for the next load
 _H5_KEEP: dict = {}      # path -> (mtime, size, h5lite.File): the dataset load_batch_device read last stays mapped
 
 

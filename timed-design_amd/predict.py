@@ -160,7 +160,18 @@ def _assemble_shard_files(files, gather, rank, world):
 def _row_groups(n_rows, batch_size, start_batch, frames_per_call):
     """[lo, hi) row ranges, each a whole number of reference batches (so resuming at ``start_batch`` lines up)"""
     per_call = max(1, int(frames_per_call) // max(1, batch_size)) * batch_size
-    return [(lo, min(lo + per_call, n_rows)) for lo in range(start_batch * batch_size, n_rows, per_call)]
+    first = start_batch * batch_size
+    groups, lo = [], first
+    # a run of several large calls starts with a quarter- and a half-size one: the GPU gets its first frames after a quarter of
+    # a group's load time instead of a whole one (the first load and the last forward pass are the two stages nothing overlaps)
+    ramp = [per_call // 4, per_call // 2] if per_call >= 1024 and n_rows - first > per_call else []
+    for size in ramp:
+        size = size // batch_size * batch_size
+        if size >= batch_size and lo + size < n_rows:
+            groups.append((lo, lo + size))
+            lo += size
+    groups += [(a, min(a + per_call, n_rows)) for a in range(lo, n_rows, per_call)]
+    return groups
 
 
 def _run_groups(models, dataset_path, flat_dataset_map, groups, consume, gpu_decode=False):
