@@ -340,6 +340,10 @@ def main():
             base = None if args.no_cpu_baseline else (lambda c, w, t: cpu_baseline(c, w, t, budget_s=8.0, min_s=5.0))
             line["other_configs"] = [bench_legs.topology_rate(t, device, d_frames.ptr, min(n, args.other_frames), args.chunk,
                                                               traffic=pmc.get(t), cpu_baseline=base) for t in others]
+            # the opt-in 7-point Cook-Toom scheme (TH_WINOGRAD=2: F(5,3) in-plane, ~4x the rounding error of the default plan — never
+            # the headline): same frames, its rate and its logits against the default plan's
+            line["other_configs"] += [bench_legs.topology_rate(t, device, d_frames.ptr, min(n, args.other_frames), args.chunk, winograd=2)
+                                      for t in (args.topology, "timed_rotamer") if t in ("timed", "timed_rotamer")]
             line["extras_wall_s"] = time.perf_counter() - t_legs
         # the full record (per-kernel tables of every topology, all e2e/sampler legs) goes to a side file and stderr;
         # stdout gets ONE compact line (tools/bench_line.py, < 4 KB) — the driver only reads the tail of stdout

@@ -126,14 +126,15 @@ int launch_conv_mfma(hipStream_t s, int64_t n, const ConvMfmaPlan& p, TView in, 
 
 // ---- Cook-Toom / Winograd convolution for 3x3x3 'same' layers on 5^3 volumes (conv_wino.hip) ----
 struct ConvWinoPlan {
+    int P = 9;                                   // evaluation points per in-plane axis: 9 = F(3,3)+F(2,3) (default), 7 = F(5,3)
     int Cin = 0, Cout = 0, Coutp = 0, ncb = 0;   // Coutp: Cout rounded up to the 128-column GEMM block
     size_t wpk_floats = 0;                       // transformed weights in fragment-stream order
     int64_t v_fpf = 0, m_fpf = 0;                // scratch floats per frame: transformed input V, GEMM output M
-    double gemm_flops = 0;                       // the algorithm's multiply-adds x 2 per frame: 81 positions x 13 z-tap pairs x Cin x Cout
+    double gemm_flops = 0;                       // the algorithm's multiply-adds x 2 per frame: P^2 positions x 13 z-tap pairs x Cin x Cout
     double exec_flops = 0;                       // MFMA FLOPs issued per frame (Cout padded to the column block)
     std::string label;
 };
-bool conv_wino_plan(const TView& in, const TView& out_conv, const ConvGeom& g, int Cin, int Cout, ConvWinoPlan* plan);
+bool conv_wino_plan(const TView& in, const TView& out_conv, const ConvGeom& g, int Cin, int Cout, int scheme, ConvWinoPlan* plan);
 void conv_wino_pack_weights(const ConvWinoPlan& p, const float* w_keras, float* dst);
 // V, M: scratch for ceil(n / 64) * 64 frames (v_fpf / m_fpf floats each).  Three launches = three plan steps.
 int launch_wino_in(hipStream_t s, int64_t n, const ConvWinoPlan& p, TView in, float* V, PreOp pre);

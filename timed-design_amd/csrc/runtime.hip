@@ -192,7 +192,9 @@ struct th_model {
     std::vector<Buffer> bufs;
     std::vector<Step> steps;
     int wino_v_buf = -1, wino_m_buf = -1;   // scratch arenas of the Winograd layers (shared: the layers run one after the other)
-    int winograd = 1;                       // eligible 3x3x3 'same' layers on 5^3 volumes run on conv_wino.hip (TH_WINOGRAD=0: direct kernels)
+    int winograd = 1;                       // eligible 3x3x3 'same' layers on 5^3 volumes run on conv_wino.hip: 1 = F(3,3)+F(2,3) in-plane
+                                            // (default, as accurate as the direct form), 2 = F(5,3) (1.65x fewer products, ~4x the rounding
+                                            // error; opt-in), 0 = direct kernels (TH_WINOGRAD)
     int input_node = -1, output_node = -1, logits_node = -1;
     int in_dims[4] = {0, 0, 0, 0};
     int n_classes = 0;
@@ -608,7 +610,7 @@ int plan(th_model* m) {
                     ConvWinoPlan wp;
                     TView wiv; wiv.D = sn.D; wiv.H = sn.H; wiv.W = sn.W; wiv.C = sn.C;
                     TView wov; wov.D = n.D; wov.H = n.H; wov.W = n.W; wov.C = n.C;
-                    if (M->winograd && use_mfma && fuse && f.pool < 0 && !split_softmax && conv_wino_plan(wiv, wov, g, Cin, Cout, &wp)) {
+                    if (M->winograd && use_mfma && fuse && f.pool < 0 && !split_softmax && conv_wino_plan(wiv, wov, g, Cin, Cout, M->winograd == 2 ? 7 : 9, &wp)) {
                         std::vector<float> packed(wp.wpk_floats);
                         conv_wino_pack_weights(wp, hw, packed.data());
                         float* dw;
@@ -629,7 +631,7 @@ int plan(th_model* m) {
                         auto Mp = [=]() { const Buffer& b = M->bufs[M->wino_m_buf]; return b.dev + M->lane_off * b.floats_per_frame; };
                         Step a;
                         a.out_node = st.out_node;
-                        a.label = n.name + ": wino_in (25 voxels -> 81 points per plane) [k_wino_in]";
+                        a.label = n.name + ": wino_in (25 voxels -> " + std::to_string(wp.P * wp.P) + " points per plane) [k_wino_in]";
                         a.bytes = 4.0 * ((double)sn.D * sn.H * sn.W * Cin + (double)vf);
                         a.run = [=](hipStream_t s, int64_t cnt) { return launch_wino_in(s, cnt, wp, M->view(src), Vp(), pre); };
                         add_step(a);
@@ -642,7 +644,7 @@ int plan(th_model* m) {
                         add_step(st);
                         Step o;
                         o.out_node = st.out_node;
-                        o.label = n.name + ": wino_out (81 points -> 25 voxels per plane, bias + epilogue) [k_wino_out]";
+                        o.label = n.name + ": wino_out (" + std::to_string(wp.P * wp.P) + " points -> 25 voxels per plane, bias + epilogue) [k_wino_out]";
                         o.bytes = 4.0 * ((double)mf / wp.Coutp * Cout + (act_bytes / 4.0 - (double)sn.D * sn.H * sn.W * Cin));
                         o.run = [=](hipStream_t s, int64_t cnt) { return launch_wino_out(s, cnt, wp, Mp(), M->view(dst), dbias, po); };
                         add_step(o);
@@ -1000,7 +1002,7 @@ int load_common(th_model* m) {
     HIP_TRY(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
     if (const char* e = getenv("TH_LANES")) m->lanes = atoi(e) == 2 ? 2 : 1;
-    if (const char* e = getenv("TH_WINOGRAD")) m->winograd = atoi(e) != 0;
+    if (const char* e = getenv("TH_WINOGRAD")) m->winograd = std::max(0, std::min(2, atoi(e)));
     if (const char* e = getenv("TH_LANE_LAG")) m->lane_lag = std::max(0, atoi(e));
     for (int r = 0; r < th_model::kRing; ++r) {
         HIP_TRY(hipEventCreateWithFlags(&m->ev_h2d[r], hipEventDisableTiming));

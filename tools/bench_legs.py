@@ -288,6 +288,21 @@ def sampler_config5(device=0, n_res=300, n_samples=1000, temps=(0.1, 0.5, 1.0), 
             "cpu_numpy_ms": t_cpu * 1e3, "cpu_numpy_sequences_per_s": n_samples / t_cpu,
             "cpu_numpy_with_metrics_ms": t_cpu_m * 1e3, "indices_bit_exact_vs_oracle": bool(exact)}
         assert exact, f"sampler indices differ from the oracle at T={t}"
+    # where an API call's time goes (T = 0.5): the reference's contract fixes two host-side costs — the uniforms come from NumPy's
+    # global legacy generator (np.random.rand: MT19937 on one core) and the result is a Python list of (str, float, ...) tuples;
+    # what is left is the GPU part (upload of rows + uniforms, temper / draw / metrics kernels, download of letters + metrics)
+    q = su.apply_temp_to_probs(p, 0.5)
+    r = np.random.rand(draws)
+    let = "".join(letters)
+    t_rand = _best(lambda: np.random.rand(draws), 5)
+    t_gpu = _best(lambda: (sm.load(q), sm.draw([0, n_res], n_samples, uniforms=r, letters=let, want_idx=False, want_metrics=True)), 10)
+    d = sm.draw([0, n_res], n_samples, uniforms=r, letters=let, want_idx=False, want_metrics=True)
+
+    def tuples():
+        seqs = [row.tobytes().decode("ascii") for row in d["letters"].reshape(n_samples, n_res)]
+        return [(s_, float(m[0]), float(m[1]), float(m[2]), float(m[3])) for s_, m in zip(seqs, d["metrics"])]
+    t_py = _best(tuples, 5)
+    out["api_breakdown_ms"] = {"numpy_legacy_rand": t_rand * 1e3, "gpu_load_draw_metrics_copies": t_gpu * 1e3, "python_result_tuples": t_py * 1e3}
     sm.close()
     out["cpu_cores"] = 1
     from timed_hip import _lib
@@ -385,14 +400,24 @@ def step_roofline(step, frames, traffic_bytes=None, chunk=None):
 
 
 # ---- other BASELINE topologies ---------------------------------------------------------------------------------------
-def topology_rate(name, device, d_frames_ptr, n, chunk, steps=2, traffic=None, cpu_baseline=None):
+def topology_rate(name, device, d_frames_ptr, n, chunk, steps=2, traffic=None, cpu_baseline=None, winograd=None):
     """device-resident frames/s of another BASELINE topology on the same frames (config 3: densecpd, config 4's model:
     timed_rotamer) with its own roofline records: the whole model against the fp32-MFMA peak, the dominant kernel
     (largest share of device time) and every kernel's bound / fraction / measured HBM traffic; all n output rows are
     checked.  ``traffic``: this topology's record from pmc_traffic_inrun; ``cpu_baseline``: callable(cfg, weights, name)."""
     from timed_hip import _lib, engine, synth
     cfg, weights = synth.TOPOLOGIES[name]()
-    model = engine.HipFrameModel.from_keras(cfg, weights, device=device, name=name)
+    keep = os.environ.get("TH_WINOGRAD")
+    if winograd is not None:                 # the library reads TH_WINOGRAD when a model is loaded
+        os.environ["TH_WINOGRAD"] = str(winograd)
+    try:
+        model = engine.HipFrameModel.from_keras(cfg, weights, device=device, name=name)
+    finally:
+        if winograd is not None:
+            if keep is None:
+                os.environ.pop("TH_WINOGRAD", None)
+            else:
+                os.environ["TH_WINOGRAD"] = keep
     model.set_chunk(chunk)
     d_probs = engine.DeviceBuffer(n * model.n_classes * 4, device)
     lib = _lib.load()
@@ -433,6 +458,20 @@ def topology_rate(name, device, d_frames_ptr, n, chunk, steps=2, traffic=None, c
                             GBps_algo=(s["bytes"] * n / (s["ms"] * 1e-3) / 1e9) if s["ms"] else 0.0) for s in table]}
     for k in res["kernels"]:
         k.pop("kernel", None)
+    if winograd is not None:
+        # parity note of a non-default plan: its logits on the first frames against the DEFAULT plan's on the same frames
+        res["topology"] = f"{name} (TH_WINOGRAD={winograd})"
+        k = min(n, 512)
+        ref = engine.HipFrameModel.from_keras(cfg, weights, device=device, name=name)
+        d_a, d_b = engine.DeviceBuffer(k * model.n_classes * 4, device), engine.DeviceBuffer(k * model.n_classes * 4, device)
+        try:
+            model.predict_device(d_frames_ptr, k, d_a.ptr, logits=True)
+            ref.predict_device(d_frames_ptr, k, d_b.ptr, logits=True)
+            a, b = d_a.download((k, model.n_classes), np.float32), d_b.download((k, model.n_classes), np.float32)
+            res["max_abs_dlogit_vs_default_plan"] = float(np.abs(a - b).max())
+            res["argmax_equal_to_default_plan"] = bool(np.array_equal(a.argmax(1), b.argmax(1)))
+        finally:
+            ref.close(); d_a.free(); d_b.free()
     model.close()
     d_probs.free()
     if cpu_baseline is not None:

@@ -61,6 +61,8 @@ def _other(o: dict) -> dict:
         out["traffic_over_algorithmic"] = _r(mr["traffic"] / mr["algorithmic_bytes"], 3)
     if o.get("cpu_baseline"):
         out["cpu_frames_per_s"] = _r(o["cpu_baseline"].get("value"))
+    if o.get("max_abs_dlogit_vs_default_plan") is not None:
+        out["max_dlogit_vs_default"] = _r(o["max_abs_dlogit_vs_default_plan"], 3)
     return out
 
 
@@ -76,6 +78,8 @@ def _sampler(s: dict) -> dict:
         out[f"T{t}"] = {"api_ms": _r(v.get("api_ms")), "kernel_ms": _r(v.get("kernel_ms")),
                         "seq_per_s": _r(v.get("api_sequences_per_s")), "cpu_numpy_ms": _r(v.get("cpu_numpy_ms")),
                         "bit_exact": v.get("indices_bit_exact_vs_oracle")}
+    if s.get("api_breakdown_ms"):
+        out["api_breakdown_ms"] = {k: _r(v, 3) for k, v in s["api_breakdown_ms"].items()}
     return out
 
 

@@ -139,22 +139,25 @@ def winograd_inplane_conv3d_same(x, kernel, bias, segments, dtype=np.float32):
     return y.astype(dtype)
 
 
-def emit_header(path, n=5, segments=(3, 2)):
-    """csrc/wino_tables.h: the per-axis composite matrices of the [3, 2] cut of a 5-wide 'same' axis, for the HIP kernels and the
-    host-side weight transform"""
-    BTc, Gc, ATc = composite(n, list(segments))
-    P = BTc.shape[0]
+def emit_header(path, n=5):
+    """csrc/wino_tables.h: the per-axis composite matrices of a 5-wide 'same' axis for the HIP kernels and the host-side weight
+    transform — scheme 9 = F(3, 3) + F(2, 3) (9 points, the default: as accurate as the direct form) and scheme 7 = F(5, 3)
+    (7 points, the minimum: 1.65x fewer products and bytes, ~4x the rounding error; opt-in)"""
     def arr(name, M, typ):
         rows = ",\n    ".join("{" + ", ".join(repr(float(v)) if typ == "double" else (f"{v:.10g}f" if v != int(v) else f"{int(v)}.f") for v in r) + "}" for r in M)
         dev = "__device__ " if typ == "float" else ""      # the float tables are read by the kernels (folded after unrolling)
         return f"static {dev}constexpr {typ} {name}[{M.shape[0]}][{M.shape[1]}] = {{\n    {rows}}};\n"
     txt = ("// GENERATED by tools/microbench/winograd_numerics.py --emit-header — do not edit.\n"
-           f"// Cook-Toom minimal filtering F(m, 3) for a 'same' 3-tap axis of {n} outputs cut into segments {list(segments)}:\n"
-           f"// {P} products per axis instead of {3 * n}.  y = AT [(G g) * (BT d)], d = the axis WITHOUT its zero halo (the two halo\n"
-           "// columns of BT multiply zeros and are dropped).  BT is integer (exact products); the fractions live in G, applied to the\n"
-           "// weights once on the host in double precision.\n#pragma once\n"
-           f"#define WINO_N {n}\n#define WINO_P {P}\n")
-    txt += arr("kWinoBT", BTc[:, 1:n + 1], "float") + arr("kWinoAT", ATc, "float") + arr("kWinoG", Gc, "double")
+           f"// Cook-Toom minimal filtering F(m, 3) for a 'same' 3-tap axis of {n} outputs: y = AT [(G g) * (BT d)], d = the axis WITHOUT\n"
+           "// its zero halo (the two halo columns of BT multiply zeros and are dropped).  BT is integer (exact products); the fractions\n"
+           "// live in G, applied to the weights once on the host in double precision.\n"
+           "//   scheme 9: segments [3, 2] = F(3, 3) + F(2, 3), 9 products per axis instead of 15\n"
+           "//   scheme 7: segments [5]    = F(5, 3), 7 products per axis (points 0, 1, -1, 1/2, -1/2, 2, inf)\n#pragma once\n"
+           f"#define WINO_N {n}\n")
+    for segments in ([3, 2], [5]):
+        BTc, Gc, ATc = composite(n, list(segments))
+        P = BTc.shape[0]
+        txt += arr(f"kWinoBT{P}", BTc[:, 1:n + 1], "float") + arr(f"kWinoAT{P}", ATc, "float") + arr(f"kWinoG{P}", Gc, "double")
     open(path, "w").write(txt)
     print("wrote", path)
 

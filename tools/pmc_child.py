@@ -32,10 +32,13 @@ def main():
         _lib.check(lib.th_dev_synth_frames(0, C.c_void_p(d_frames.ptr), chunk, D, Cc, 200, 1234))
         model.predict_device(d_frames.ptr, chunk, d_probs.ptr)
         _lib.check(lib.th_dev_sync(0))
-        _lib.check(lib.th_dev_synth_frames(0, C.c_void_p(d_frames.ptr), chunk, D, Cc, 200, 1234))    # the marker launch
-        model.predict_device(d_frames.ptr, chunk, d_probs.ptr)
-        _lib.check(lib.th_dev_sync(0))
+        for _ in range(int(os.environ.get("PMC_CHILD_REPS", "1"))):      # (tools/roofline_table.py averages several passes)
+            _lib.check(lib.th_dev_synth_frames(0, C.c_void_p(d_frames.ptr), chunk, D, Cc, 200, 1234))    # the marker launch
+            model.predict_device(d_frames.ptr, chunk, d_probs.ptr)
+            _lib.check(lib.th_dev_sync(0))
         out[name] = [s["label"] for s in model.steps()]
+        if os.environ.get("PMC_CHILD_COSTS"):
+            out[name + "/costs"] = [[s["flops"], s["exec_flops"], s["bytes"]] for s in model.steps()]
         model.close()
         d_frames.free()
         d_probs.free()
