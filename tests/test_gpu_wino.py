@@ -147,3 +147,30 @@ def test_single_layer_seven_point_scheme(gpu, monkeypatch, cin, cout, n):
     np.testing.assert_allclose(got, want, atol=1e-4 * max(1.0, float(np.abs(want).max())), rtol=0)
     assert float(np.sqrt(np.mean((got - want) ** 2))) < 1.5e-5
     model.close()
+
+
+def test_winograd_layers_on_concat_arenas(gpu):
+    """a Winograd layer that WRITES into a channel slice of a zero-copy concat arena (voxel stride 96, first channel 32), one
+    that READS the whole arena (Cin = 96) and one that reads only the slice its sibling wrote: strided views on both sides of
+    the transform kernels, against the float64 oracle"""
+    b = synth.KerasGraphBuilder((5, 5, 5, 32), seed=11)
+    x = b.input_name
+    a = b.batchnorm(b.elu(b.conv3d(x, 64, 3, padding="same")))
+    c = b.concat([x, a])
+    y1 = b.batchnorm(b.elu(b.conv3d(c, 64, 3, padding="same")))
+    y2 = b.relu(b.conv3d(a, 96, 3, padding="same"))
+    z = b.concat([y1, y2])
+    out = b.softmax(b.gap(b.conv3d(z, 20, 1, padding="same")))
+    cfg, w = b.finish(out)
+    rng = np.random.default_rng(4)
+    frames = (rng.standard_normal((9, 5, 5, 5, 32)) * (rng.random((9, 5, 5, 5, 32)) < 0.4)).astype(np.float32)
+    model = engine.HipFrameModel.from_keras(cfg, w, device=gpu)
+    assert sum("k_wino_gemm" in s["label"] for s in model.steps()) == 3, [s["label"] for s in model.steps()]
+    probs = model.predict(frames)
+    ref = cnn_oracle.forward(cfg, w, frames, np.float64, return_all=True)
+    np.testing.assert_allclose(probs, ref[list(ref)[-1]], atol=TIGHT, rtol=0)
+    for name in (y1, y2):
+        want = ref[name]
+        got = model.fetch(name, 9, want.shape[1:])
+        np.testing.assert_allclose(got, want, atol=LAYER * max(1.0, float(np.abs(want).max())), rtol=0, err_msg=name)
+    model.close()
