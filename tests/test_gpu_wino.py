@@ -174,3 +174,32 @@ def test_winograd_layers_on_concat_arenas(gpu):
         got = model.fetch(name, 9, want.shape[1:])
         np.testing.assert_allclose(got, want, atol=LAYER * max(1.0, float(np.abs(want).max())), rtol=0, err_msg=name)
     model.close()
+
+
+def test_transform_launches_in_pieces(gpu):
+    """the transform kernels address with 32-bit offsets; a launch beyond that is issued in pieces (TH_WINO_PIECE forces 50-frame
+    pieces here — the library reads it once per process, hence the child): same bits as the one-piece run"""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from timed_hip import engine\nimport test_gpu_wino as T\n"
+        "cfg, w, layer = T._one_layer(64, 128, seed=5)\n"
+        "rng = np.random.default_rng(0)\n"
+        "x = rng.standard_normal((130, 5, 5, 5, 64)).astype(np.float32)\n"
+        "m = engine.HipFrameModel.from_keras(cfg, w)\n"
+        "np.save(sys.argv[1], m.predict(x, logits=True))\n"
+    ) % (os.path.dirname(os.path.abspath(engine.__file__)) + "/..", os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for piece in ("", "50"):
+        out = f"/tmp/wino_piece_{piece or 'one'}_{os.getpid()}.npy"
+        env = dict(os.environ)
+        env.pop("TH_WINO_PIECE", None)
+        if piece:
+            env["TH_WINO_PIECE"] = piece
+        subprocess.run([sys.executable, "-c", code, out], check=True, env=env)
+        outs.append(np.load(out))
+        os.remove(out)
+    assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1])
