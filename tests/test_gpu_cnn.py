@@ -183,3 +183,23 @@ def test_full_size_properties(gpu):
     perm = np.random.default_rng(0).permutation(96)
     assert np.array_equal(fast.predict(frames[perm]), a[perm])
     assert np.array_equal(fast.predict(frames), a)
+
+
+@pytest.mark.parametrize("name", ["timed20", "timed338"])
+def test_fused_gap_softmax_tail_is_bit_identical(gpu, cnn_golden, monkeypatch, name):
+    """TIMED's tail GlobalAveragePooling3D -> Softmax runs as ONE launch (k_gap_softmax: one wavefront per frame, 20 or 338
+    channels over the lanes): probabilities AND logits equal the k_global_pool + k_softmax path bit for bit (same summation
+    and reduction order), for one frame and for a ragged count"""
+    z, meta = cnn_golden
+    cfg, weights, frames = _build(meta, name)
+    frames = np.concatenate([frames, frames[:3][::-1]])               # 11 frames: not a multiple of the 4 frames per workgroup
+    fused = engine.HipFrameModel.from_keras(cfg, weights, device=gpu)
+    assert any("k_gap_softmax" in s["label"] for s in fused.steps())
+    assert not any(s["label"].endswith(": softmax") for s in fused.steps())
+    monkeypatch.setenv("TH_NO_TAIL_FUSE", "1")
+    plain = engine.HipFrameModel.from_keras(cfg, weights, device=gpu)
+    assert not any("k_gap_softmax" in s["label"] for s in plain.steps())
+    for n in (1, len(frames)):
+        assert np.array_equal(fused.predict(frames[:n]), plain.predict(frames[:n]))
+        assert np.array_equal(fused.predict(frames[:n], logits=True), plain.predict(frames[:n], logits=True))
+    fused.close(); plain.close()

@@ -86,6 +86,8 @@ int launch_global_pool(hipStream_t s, int64_t n, TView in, TView out, int is_max
 // dense on a contiguous [n, F] input (in.C = F, V = 1); weights [F, out]
 int launch_dense(hipStream_t s, int64_t n, TView in, TView out, const float* w, const float* bias, PostOps post);
 int launch_softmax(hipStream_t s, int64_t n, TView in, TView out);
+// GlobalAveragePooling3D -> Softmax in one launch (<= 512 channels): writes the pooled logits and the probabilities
+int launch_gap_softmax(hipStream_t s, int64_t n, TView in, TView logits, TView probs);
 int launch_copy(hipStream_t s, int64_t n, TView in, TView out);
 int launch_add(hipStream_t s, int64_t n, TView a, TView b, TView out);
 int launch_synth_frames(hipStream_t s, float* d, int64_t n, int side, int channels, int atoms, uint64_t seed);

@@ -207,6 +207,44 @@ __global__ void k_softmax(int64_t rows, TView in, TView out) {
     }
 }
 
+// ---- GlobalAveragePooling3D -> Softmax tail in ONE launch: one wavefront per frame -------------------------------------------
+// (TIMED's head: reference README.md:252-258 "GlobalAveragePooling3D instead of Dense; softmax".)  Lane l owns channels l, l + 64, ...:
+// it walks its channels' voxels in k_global_pool's order and the row maximum / sum of exponentials are reduced with the same
+// lane-partial + xor-shuffle scheme as k_softmax, so logits AND probabilities are bit-identical to the two-kernel path; the logits
+// are written too (TH_PREDICT_LOGITS reads them).
+__global__ void __launch_bounds__(256) k_gap_softmax(int64_t n, TView in, TView logits, TView probs) {
+    const int lane = threadIdx.x & 63;
+    const int C = in.C, V = in.D * in.H * in.W;
+    const int64_t f = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (f >= n) return;
+    float x[8];
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = lane + 64 * k;
+        x[k] = -INFINITY;
+        if (c < C) {
+            const float* p = in.p + f * in.fs + in.coff + c;
+            float s = 0.f;
+            for (int v = 0; v < V; ++v) s += p[(int64_t)v * in.cs];
+            x[k] = s / (float)V;
+            logits.p[f * logits.fs + logits.coff + c] = x[k];
+            m = fmaxf(m, x[k]);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (lane + 64 * k < C) s += expf(x[k] - m);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = lane + 64 * k;
+        if (c < C) probs.p[f * probs.fs + probs.coff + c] = expf(x[k] - m) / s;
+    }
+}
+
 // ---- synthetic frames generated on the device (bench: keeps 22 GB of input off PCIe) ----------
 __device__ inline uint32_t mix32(uint64_t x) {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
@@ -288,6 +326,12 @@ int launch_dense(hipStream_t s, int64_t n, TView in, TView out, const float* w, 
 }
 int launch_softmax(hipStream_t s, int64_t n, TView in, TView out) {
     hipLaunchKernelGGL(k_softmax, dim3(grid_for(n * in.V(), kThreads / 64)), dim3(kThreads), 0, s, n * in.V(), in, out);
+    LAUNCH_CHECK();
+    return TH_OK;
+}
+int launch_gap_softmax(hipStream_t s, int64_t n, TView in, TView logits, TView probs) {
+    if (n <= 0) return TH_OK;
+    hipLaunchKernelGGL(k_gap_softmax, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, n, in, logits, probs);
     LAUNCH_CHECK();
     return TH_OK;
 }

@@ -558,6 +558,7 @@ int plan(th_model* m) {
     auto V = [&](int node) { return m->view(node); };  // NOTE: device pointers are bound at run time
     auto add_step = [&](Step s) { m->steps.push_back(std::move(s)); };
     th_model* M = m;
+    int fused_tail = -1;     // the final Softmax node when it was folded into the GlobalAveragePooling3D step
     for (int i = 0; i < nn; ++i) {
         Node& n = N[i];
         const bool emits = fus.count(i) || n.absorbed_by < 0;
@@ -760,6 +761,7 @@ int plan(th_model* m) {
             case OP_BN:
             case OP_ACT: {
                 const int src = n.in[0];
+                if (i == fused_tail) continue;                 // computed by the k_gap_softmax step of its input
                 if (n.op == OP_ACT && n.ip[0] == ACT_SOFTMAX) {
                     st.label = n.name + ": softmax";
                     st.is_final_softmax = i == M->output_node;
@@ -797,6 +799,19 @@ int plan(th_model* m) {
             case OP_GMP: {
                 const int src = n.in[0];
                 const int is_max = n.op == OP_GMP;
+                // TIMED's tail GlobalAveragePooling3D -> Softmax (the model output): one launch, one wavefront per frame
+                if (!is_max && fuse && n.consumers.size() == 1 && n.C <= 512 && !getenv("TH_NO_TAIL_FUSE")) {
+                    const int sm = n.consumers[0];
+                    if (N[sm].op == OP_ACT && N[sm].ip[0] == ACT_SOFTMAX && sm == M->output_node && N[sm].absorbed_by < 0 &&
+                        N[sm].materialised && n.materialised) {
+                        st.label = n.name + ": global_avg_pool + softmax [k_gap_softmax]";
+                        st.bytes = 4.0 * ((double)N[src].D * N[src].H * N[src].W * N[src].C + 2.0 * n.C);
+                        st.run = [=](hipStream_t s, int64_t cnt) { return launch_gap_softmax(s, cnt, M->view(src), M->view(i), M->view(sm)); };
+                        M->logits_node = i;
+                        fused_tail = sm;
+                        break;
+                    }
+                }
                 st.label = n.name + (is_max ? ": global_max_pool" : ": global_avg_pool");
                 st.bytes = 4.0 * N[src].D * N[src].H * N[src].W * N[src].C;
                 st.run = [=](hipStream_t s, int64_t cnt) { return launch_global_pool(s, cnt, M->view(src), M->view(i), is_max); };
