@@ -28,6 +28,9 @@ m.profile(1)
 for _ in range(3):
     m.predict_device(d_in.ptr, n, d_out.ptr)
 for s in m.steps():
+    if s["launches"] and not s["flops"] and s["bytes"] and ("wino" in s["label"]):
+        ms = s["ms"] / 3
+        print(json.dumps(dict(label=s["label"], ms_per_4096=ms * 4096 / n, GBps=s["bytes"] * n / (ms * 1e-3) / 1e9, frac_of_8TBps=s["bytes"] * n / (ms * 1e-3) / 8e12)))
     if s["launches"] and s["flops"]:
         ms = s["ms"] / 3
         print(json.dumps(dict(label=s["label"], ms_per_4096=ms * 4096 / n, tflops_algo=s["flops"] * n / (ms * 1e-3) / 1e12,
