@@ -2,7 +2,7 @@
 switches it off) against the
 float64 oracle and the torch-fp64 fixtures, through the C ABI.  Same bounds as the direct kernels (tests/test_gpu_cnn.py): the
 transforms are integer / power-of-two matrices and the products run on the fp32 matrix pipe, so the error is accumulation-order
-noise (tools/microbench/winograd_numerics.py: 6.8e-7 on the logits of TIMED-synth against 7.7e-7 for the direct form)."""
+noise (tests/winograd_numerics.py: 6.8e-7 on the logits of TIMED-synth against 7.7e-7 for the direct form)."""
 import numpy as np
 import pytest
 
@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 TIGHT = 5e-6
 # single layers on DENSE standard-normal inputs (sums of up to 27 x 256 products of magnitude ~1: values around 50 before the
 # BatchNorm): the direct kernel's own worst element is 1.0e-5 x max|y| there (a serial fp32 chain over K = 6912), the Winograd
-# path's 3.3e-5 x (rms 1.6e-6 against 5.9e-7; tools/microbench/wino_layer_error.py) — both accumulation noise at that scale
+# path's 3.3e-5 x (rms 1.6e-6 against 5.9e-7; tests/wino_layer_error.py) — both accumulation noise at that scale
 LAYER = 1e-5
 
 
@@ -112,7 +112,7 @@ FAST = 2e-5          # F(5, 3): asserted bound of the opt-in 7-point scheme (nor
 @pytest.mark.parametrize("name", ["timed20", "timed338"])
 def test_timed_fixtures_with_the_seven_point_scheme(gpu, cnn_golden, monkeypatch, name):
     """TH_WINOGRAD=2: F(5, 3) in both in-plane axes (49 positions per plane instead of 81).  Its transforms carry entries up
-    to 16, so the rounding error is ~4x that of the default scheme (tools/microbench/winograd_numerics.py: 2.4e-6 on the
+    to 16, so the rounding error is ~4x that of the default scheme (tests/winograd_numerics.py: 2.4e-6 on the
     logits of TIMED-synth against 6.8e-7): asserted at 2e-5 — five times inside the north-star bound — with equal argmax;
     never the default and never the headline number."""
     monkeypatch.setenv("TH_WINOGRAD", "2")

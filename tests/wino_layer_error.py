@@ -1,5 +1,8 @@
+"""Single-layer error of the direct and the Cook-Toom kernels against the float64 oracle on dense standard-normal inputs (GPU box;
+test infrastructure: uses the CPU oracle).  python tests/wino_layer_error.py"""
 import os, sys, numpy as np
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/timed-design_amd"); sys.path.insert(0, "/root/repo/tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "timed-design_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import cnn_oracle
 from timed_hip import engine
 import test_gpu_wino as T
