@@ -100,9 +100,10 @@ def test_winograd_is_not_taken_where_it_does_not_apply(gpu, monkeypatch):
     cfg, w = synth.timed_synth(20)
     model = engine.HipFrameModel.from_keras(cfg, w, device=gpu)
     labels = [s["label"] for s in model.steps()]
-    conv = [l for l in labels if l.startswith("conv3d") and "wino_in" not in l and "wino_out" not in l]
+    conv = [l for l in labels if l.startswith("conv3d") and not any(k in l for k in ("wino_in", "wino_out", "wino_mid"))]
     assert [("k_wino_gemm" in l) for l in conv] == [False, False, True, True, True, False]
-    assert sum("k_wino_in" in l for l in labels) == 3 and sum("k_wino_out" in l for l in labels) == 3
+    # conv3d_2 -> conv3d_3 -> conv3d_4 are consecutive Winograd layers: one input transform, two fused mid transforms, one output
+    assert [sum(k in l for l in labels) for k in ("k_wino_in", "k_wino_mid", "k_wino_out")] == [1, 2, 1]
     model.close()
 
 
@@ -203,3 +204,23 @@ def test_transform_launches_in_pieces(gpu):
         outs.append(np.load(out))
         os.remove(out)
     assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("name", ["timed20", "timed338"])
+def test_fused_mid_transform_is_bit_identical(gpu, cnn_golden, monkeypatch, name):
+    """k_wino_mid (output transform of one Winograd layer + input transform of the next, the tensor between them never written) against
+    the separate k_wino_out / k_wino_in launches (TH_WINO_NOMID=1): same arithmetic in the same order, so the same bits"""
+    z, meta = cnn_golden
+    m = next(x for x in meta if x["name"] == name)
+    cfg, weights = getattr(synth, m["builder"])(**m["kwargs"])
+    frames = synth.synthetic_frames(m["n"], **m["frame_kwargs"])
+    fused = engine.HipFrameModel.from_keras(cfg, weights, device=gpu)
+    assert sum("k_wino_mid" in s["label"] for s in fused.steps()) >= 2
+    with pytest.raises(_lib.TimedHipError, match="fused away"):
+        fused.predict(frames[:1]); fused.fetch("batch_normalization_2", 1, (5, 5, 5, 128))
+    monkeypatch.setenv("TH_WINO_NOMID", "1")
+    plain = engine.HipFrameModel.from_keras(cfg, weights, device=gpu)
+    assert not any("k_wino_mid" in s["label"] for s in plain.steps())
+    assert np.array_equal(fused.predict(frames, logits=True), plain.predict(frames, logits=True))
+    assert np.array_equal(fused.predict(frames), plain.predict(frames))
+    fused.close(); plain.close()

@@ -142,6 +142,8 @@ void conv_wino_pack_weights(const ConvWinoPlan& p, const float* w_keras, float* 
 int launch_wino_in(hipStream_t s, int64_t n, const ConvWinoPlan& p, TView in, float* V, PreOp pre);
 int launch_wino_gemm(hipStream_t s, int64_t n, const ConvWinoPlan& p, const float* V, float* M, const float* wpk);
 int launch_wino_out(hipStream_t s, int64_t n, const ConvWinoPlan& p, const float* M, TView out, const float* bias, PostOps post);
+// launch_wino_out of layer p + launch_wino_in of the NEXT Winograd layer in one pass (the tensor between them is not written)
+int launch_wino_mid(hipStream_t s, int64_t n, const ConvWinoPlan& p, const float* M, float* V_next, const float* bias, PostOps post);
 
 // ---- first-layer convolution (conv_first.hip): Cin <= 8, Cout <= 32, 3x3x3, reads the caller's frames ----
 std::string conv_first_label(const ConvMfmaPlan& p, int Cin, const PostOps& post);

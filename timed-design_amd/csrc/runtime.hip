@@ -23,6 +23,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <set>
 
 // ---- errors ---------------------------------------------------------------------------------
 static thread_local char g_err[1024] = "";
@@ -559,6 +560,7 @@ int plan(th_model* m) {
     auto add_step = [&](Step s) { m->steps.push_back(std::move(s)); };
     th_model* M = m;
     int fused_tail = -1;     // the final Softmax node when it was folded into the GlobalAveragePooling3D step
+    std::set<int> wino_in_done;   // Winograd convolutions whose input transform was fused into the previous layer's output transform
     for (int i = 0; i < nn; ++i) {
         Node& n = N[i];
         const bool emits = fus.count(i) || n.absorbed_by < 0;
@@ -630,12 +632,14 @@ int plan(th_model* m) {
                         const int64_t vf = wp.v_fpf, mf = wp.m_fpf;
                         auto Vp = [=]() { const Buffer& b = M->bufs[M->wino_v_buf]; return b.dev + M->lane_off * b.floats_per_frame; };
                         auto Mp = [=]() { const Buffer& b = M->bufs[M->wino_m_buf]; return b.dev + M->lane_off * b.floats_per_frame; };
-                        Step a;
-                        a.out_node = st.out_node;
-                        a.label = n.name + ": wino_in (25 voxels -> " + std::to_string(wp.P * wp.P) + " points per plane) [k_wino_in]";
-                        a.bytes = 4.0 * ((double)sn.D * sn.H * sn.W * Cin + (double)vf);
-                        a.run = [=](hipStream_t s, int64_t cnt) { return launch_wino_in(s, cnt, wp, M->view(src), Vp(), pre); };
-                        add_step(a);
+                        if (!wino_in_done.count(i)) {
+                            Step a;
+                            a.out_node = st.out_node;
+                            a.label = n.name + ": wino_in (25 voxels -> " + std::to_string(wp.P * wp.P) + " points per plane) [k_wino_in]";
+                            a.bytes = 4.0 * ((double)sn.D * sn.H * sn.W * Cin + (double)vf);
+                            a.run = [=](hipStream_t s, int64_t cnt) { return launch_wino_in(s, cnt, wp, M->view(src), Vp(), pre); };
+                            add_step(a);
+                        }
                         st.flops = wp.gemm_flops;
                         st.direct_flops = direct;
                         st.exec_flops = wp.exec_flops;
@@ -643,6 +647,34 @@ int plan(th_model* m) {
                         st.label = n.name + ": " + wp.label + " [k_wino_gemm]";
                         st.run = [=](hipStream_t s, int64_t cnt) { return launch_wino_gemm(s, cnt, wp, Vp(), Mp(), dw); };
                         add_step(st);
+                        // two Winograd layers in a row and nobody else reads the tensor between them: this layer's output transform
+                        // feeds the next layer's V directly (k_wino_mid) and the 5^3 activation is never written
+                        int next = -1;
+                        ConvWinoPlan np;
+                        if (!(getenv("TH_WINO_NOMID") && atoi(getenv("TH_WINO_NOMID"))) && dst != M->output_node && N[dst].consumers.size() == 1) {
+                            const int c2 = N[dst].consumers[0];
+                            const Node& nx = N[c2];
+                            if (nx.op == OP_CONV3D && fus.count(c2) && fus[c2].src == dst && fus[c2].pre.empty() && fus[c2].pool < 0 &&
+                                nx.ip[13] != ACT_SOFTMAX) {
+                                const ConvGeom g2 = geom_of(nx, N[dst]);
+                                TView i2; i2.D = N[dst].D; i2.H = N[dst].H; i2.W = N[dst].W; i2.C = N[dst].C;
+                                TView o2; o2.D = nx.D; o2.H = nx.H; o2.W = nx.W; o2.C = nx.C;
+                                if (conv_wino_plan(i2, o2, g2, N[dst].C, nx.C, wp.P, &np) && np.Cin == Cout) next = c2;
+                            }
+                        }
+                        if (next >= 0) {
+                            M->bufs[M->wino_v_buf].floats_per_frame = std::max(M->bufs[M->wino_v_buf].floats_per_frame, np.v_fpf);
+                            Step o;
+                            o.out_node = st.out_node;
+                            o.label = n.name + ": wino_mid (" + std::to_string(wp.P * wp.P) + " points -> bias + epilogue -> " + std::to_string(wp.P * wp.P) +
+                                      " points of " + N[next].name + ") [k_wino_mid]";
+                            o.bytes = 4.0 * ((double)mf / wp.Coutp * Cout + (double)np.v_fpf);
+                            o.run = [=](hipStream_t s, int64_t cnt) { return launch_wino_mid(s, cnt, wp, Mp(), Vp(), dbias, po); };
+                            add_step(o);
+                            wino_in_done.insert(next);
+                            N[dst].materialised = false;        // th_model_fetch refuses it ("fused away")
+                            continue;
+                        }
                         Step o;
                         o.out_node = st.out_node;
                         o.label = n.name + ": wino_out (" + std::to_string(wp.P * wp.P) + " points -> 25 voxels per plane, bias + epilogue) [k_wino_out]";
