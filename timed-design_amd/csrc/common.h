@@ -145,6 +145,22 @@ int launch_wino_out(hipStream_t s, int64_t n, const ConvWinoPlan& p, const float
 // launch_wino_out of layer p + launch_wino_in of the NEXT Winograd layer in one pass (the tensor between them is not written)
 int launch_wino_mid(hipStream_t s, int64_t n, const ConvWinoPlan& p, const float* M, float* V_next, const float* bias, PostOps post);
 
+// ---- fused Winograd convolution, everything of the transform domain in LDS (conv_wfused.hip): 3x3x3 'same' on 10^3 volumes ----
+struct ConvWfPlan {
+    int geo = -1;                    // index into the instantiated volume geometries
+    int pool = 0;                    // 0 none, 1 max 2x2x2, 2 avg 2x2x2
+    int Cin = 0, Cout = 0, ncb = 0, nchunks = 0;   // ncb: blocks of 16 output channels, nchunks: 4-channel input chunks
+    size_t wpk_floats = 0, lds_bytes = 0;
+    double own_flops = 0;            // the algorithm's multiply-adds x 2 per frame (16 positions x 3 z taps per 2 x 2 tile)
+    double exec_flops = 0;           // MFMA FLOPs issued per frame
+    std::string label;
+};
+bool conv_wf_plan(const TView& in, const TView& out_conv, const ConvGeom& g, int Cin, int Cout, int pool, ConvWfPlan* plan);
+bool conv_wf_view_ok(const TView& in);      // 16-byte aligned channel slices
+void conv_wf_pack_weights(const ConvWfPlan& p, const float* w_keras, float* dst);
+int launch_conv_wf(hipStream_t s, int64_t n, const ConvWfPlan& p, TView in, TView out, const float* wpk, const float* bias, PreOp pre,
+                   PostOps post);
+
 // ---- first-layer convolution (conv_first.hip): Cin <= 8, Cout <= 32, 3x3x3, reads the caller's frames ----
 std::string conv_first_label(const ConvMfmaPlan& p, int Cin, const PostOps& post);
 bool conv_first_plan(int Din, int Hin, int Win, int Cin, const TView& out_conv, const ConvGeom& g, int Cout, int pool,

@@ -193,6 +193,7 @@ struct th_model {
     std::vector<Buffer> bufs;
     std::vector<Step> steps;
     int wino_v_buf = -1, wino_m_buf = -1;   // scratch arenas of the Winograd layers (shared: the layers run one after the other)
+    int wfused = 1;                         // eligible 3x3x3 'same' layers on 10^3 volumes run on conv_wfused.hip (TH_WFUSED=0: direct kernels)
     int winograd = 1;                       // eligible 3x3x3 'same' layers on 5^3 volumes run on conv_wino.hip: 1 = F(3,3)+F(2,3) in-plane
                                             // (default, as accurate as the direct form), 2 = F(5,3) (1.65x fewer products, ~4x the rounding
                                             // error; opt-in), 0 = direct kernels (TH_WINOGRAD)
@@ -682,6 +683,23 @@ int plan(th_model* m) {
                         o.run = [=](hipStream_t s, int64_t cnt) { return launch_wino_out(s, cnt, wp, Mp(), M->view(dst), dbias, po); };
                         add_step(o);
                         continue;
+                    }
+                    ConvWfPlan fp;
+                    TView fiv = wiv; fiv.cs = sn.cs; fiv.coff = sn.coff;
+                    if (M->wfused && use_mfma && fuse && !split_softmax && conv_wf_view_ok(fiv) &&
+                        conv_wf_plan(wiv, wov, g, Cin, Cout, f.pool >= 0 ? (N[f.pool].op == OP_MAXPOOL ? 1 : 2) : 0, &fp)) {
+                        // F(2,3)^2 in-plane with the whole transform domain in LDS: one step, one kernel
+                        std::vector<float> packed(fp.wpk_floats);
+                        conv_wf_pack_weights(fp, hw, packed.data());
+                        float* dw;
+                        if ((rc = upload(M, packed.data(), packed.size(), &dw))) return rc;
+                        st.direct_flops = st.flops;
+                        st.flops = fp.own_flops;
+                        st.exec_flops = fp.exec_flops;
+                        st.label = n.name + ": " + fp.label;
+                        st.run = [=](hipStream_t s, int64_t cnt) {
+                            return launch_conv_wf(s, cnt, fp, M->view(src), M->view(dst), dw, dbias, pre, po);
+                        };
                     } else if (mplans.count(i) && mplans[i].cfg == 100) {
                         const ConvMfmaPlan mp = mplans[i];
                         std::vector<float> packed(mp.wpk_floats);
@@ -1050,6 +1068,7 @@ int load_common(th_model* m) {
     HIP_TRY(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
     if (const char* e = getenv("TH_LANES")) m->lanes = atoi(e) == 2 ? 2 : 1;
     if (const char* e = getenv("TH_WINOGRAD")) m->winograd = std::max(0, std::min(2, atoi(e)));
+    if (const char* e = getenv("TH_WFUSED")) m->wfused = atoi(e) != 0;
     if (const char* e = getenv("TH_LANE_LAG")) m->lane_lag = std::max(0, atoi(e));
     for (int r = 0; r < th_model::kRing; ++r) {
         HIP_TRY(hipEventCreateWithFlags(&m->ev_h2d[r], hipEventDisableTiming));
