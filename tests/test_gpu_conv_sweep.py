@@ -237,8 +237,10 @@ def test_compile_time_geometry_kernels_with_preactivation(gpu, monkeypatch, side
     """The instantiations with the staged row geometry fixed at compile time (tap offsets as ds_read immediates; chunks
     after the first re-stage real voxels only): BN -> ReLU in front of the convolution, several Cin chunks, ragged last
     workgroup; the plan label must name the specialised kernel.  (TH_WINOGRAD=0: these are the DIRECT kernels — the wide
-    5^3 layers go to conv_wino.hip by default, tests/test_gpu_wino.py.)"""
+    5^3 layers go to conv_wino.hip by default, tests/test_gpu_wino.py; TH_WFUSED=0: the 10^3 layers go to conv_wfused.hip by
+    default, tests/test_gpu_conv_wfused.py.)"""
     monkeypatch.setenv("TH_WINOGRAD", "0")
+    monkeypatch.setenv("TH_WFUSED", "0")
     def build(b, x):
         x = b.conv3d(x, cmid, 1, padding="same")
         y = b.relu(b.batchnorm(x))

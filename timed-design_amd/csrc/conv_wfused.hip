@@ -31,6 +31,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -59,12 +60,14 @@ __device__ __forceinline__ void wf_bt(float d0, float d1, float d2, float d3, fl
 
 // POOL: 0 none, 1 max 2x2x2, 2 average 2x2x2.  PRE: prologue on the staged input — 0 none, 1 BN-affine -> ReLU (DenseNet-style
 // pre-activation layers), 2 generic (optional affine, any activation: op decoded per stage)
-template <int D, int H, int W, int POOL, int PRE>
+// DBG: timing knock-outs (TH_WF_DBG, results are WRONG): 1 no transform, 2 no slice loads / R writes, 4 no weight traffic, 8 no barriers;
+// 6 (= bit 32, results right): no MFMA / other interleave request inside the slots; 14 (slot 14 of the table = bit 16, results right): the two wave groups of a SIMD pair on different slot schedules (spills: the branches cost more than the overlap gives)
+template <int D, int H, int W, int POOL, int PRE, int DBG = 0>
 __global__ void __launch_bounds__(512, 1) k_conv_wf(const ConvWfArgs a) {
     constexpr int TY = H / 2, TX = W / 2, NT = TY * TX, NR = D * NT, NZ = NR;
     // R: rows of W + 1 floats — column x = -1 of a row is column x = W of the row before it (both are padding), and planes of
     // H + 1 rows — row y = -1 of a plane is row y = H of the plane before it: (D (H + 1) + 1) rows, one more float, one dump float
-    constexpr int RX = W + 1, RYS = H + 1, RVOX = (D * RYS + 1) * RX + 1, RPL = RVOX + 1, NV = D * H * W;
+    constexpr int RX = W + 1, RXH = W / 2 + 1, RYS = H + 1, RVOX = (D * RYS + 1) * RX + 1, RPL = RVOX + 1, NV = D * H * W;
     constexpr int kVB = 16 * 256;                      // float4 per V buffer
     static_assert(H % 2 == 0 && W % 2 == 0, "in-plane tiles are 2 x 2");
     static_assert(NR <= 250, "256 rows per workgroup: the zero record and the dump records live above the real ones");
@@ -111,7 +114,10 @@ __global__ void __launch_bounds__(512, 1) k_conv_wf(const ConvWfArgs a) {
         const int vv = ok ? v : 0;
         const int z = vv / (H * W), y = (vv / W) % H, x = vv % W;
         goff[j] = vv * a.in_cs;
-        rdst[j] = ok ? (z * RYS + y + 1) * RX + x + 1 : RVOX;
+        // inside a row the even columns xx = x + 1 = 0, 2, .. come first, then the odd ones: the tiles of a row read columns
+        // 2 tx + j, i.e. for a fixed j consecutive lanes read consecutive floats (a plain row would put them on even banks only)
+        const int xx = x + 1;
+        rdst[j] = ok ? (z * RYS + y + 1) * RX + ((xx & 1) ? RXH + (xx >> 1) : (xx >> 1)) : RVOX;
     }
     // transform side: record tid & 255, channels 2 (tid >> 8) and 2 (tid >> 8) + 1
     const int trec = tid & 255, th = tid >> 8;
@@ -120,7 +126,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_wf(const ConvWfArgs a) {
         const bool ok = trec < NR;
         const int rr = ok ? trec : 0;
         const int z = rr / NT, tile = rr % NT, ty = tile / TX, tx = tile % TX;
-        rsrc = 2 * th * RPL + (z * RYS + 2 * ty) * RX + 2 * tx;
+        rsrc = 2 * th * RPL + (z * RYS + 2 * ty) * RX + tx;
         wdst = th * 8 * 256 + (ok ? trec : 255);
     }
     // A side: rows 32 wave + 16 rt + i16 (POOL: rows are ordered (z pair, tile, z low) so that a lane's registers r = 0,1 and
@@ -156,13 +162,17 @@ __global__ void __launch_bounds__(512, 1) k_conv_wf(const ConvWfArgs a) {
     };
     int kL = 0, cL = 0, cR = 0;
     float4 pre[2];
-    auto issue_loads = [&]() {
-        const float* p = slice_ptr(kL, cL);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) pre[j] = *reinterpret_cast<const float4*>(p + goff[j]);
+    const float* pslice = slice_ptr(0, 0);              // the slice whose loads are issued next
+    auto advance_slice = [&]() {
         if (++cL == a.nchunks) { cL = 0; ++kL; }
+        pslice = slice_ptr(kL, cL);
     };
-    // PRE == 1: scale / shift of the 4 channels write_R handles next, requested a stage ahead like everything else
+    auto issue_loads = [&]() {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) pre[j] = *reinterpret_cast<const float4*>(pslice + goff[j]);
+        advance_slice();
+    };
+    // PRE == 1: scale / shift of the 4 channels the prologue handles next, requested a stage ahead like everything else
     float4 psc = make_float4(1.f, 1.f, 1.f, 1.f), psh = make_float4(0.f, 0.f, 0.f, 0.f);
     auto load_pre = [&]() {
         if (PRE == 1) {
@@ -170,45 +180,65 @@ __global__ void __launch_bounds__(512, 1) k_conv_wf(const ConvWfArgs a) {
             psh = *reinterpret_cast<const float4*>(a.pre.shift + 4 * cR);
         }
     };
-    auto write_R = [&]() {
-        float x[8] = {pre[0].x, pre[0].y, pre[0].z, pre[0].w, pre[1].x, pre[1].y, pre[1].z, pre[1].w};
+    // BN -> activation prologue on voxel j's four channels (x[4 j .. 4 j + 3]) of chunk cR
+    auto prologue4 = [&](float (&x)[8], int j) {
         if (PRE == 1) {
-            const float4 sc = psc, sh = psh;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                x[4 * j + 0] = fmaxf(fmaf(x[4 * j + 0], sc.x, sh.x), 0.f);
-                x[4 * j + 1] = fmaxf(fmaf(x[4 * j + 1], sc.y, sh.y), 0.f);
-                x[4 * j + 2] = fmaxf(fmaf(x[4 * j + 2], sc.z, sh.z), 0.f);
-                x[4 * j + 3] = fmaxf(fmaf(x[4 * j + 3], sc.w, sh.w), 0.f);
-            }
+            x[4 * j + 0] = fmaxf(fmaf(x[4 * j + 0], psc.x, psh.x), 0.f);
+            x[4 * j + 1] = fmaxf(fmaf(x[4 * j + 1], psc.y, psh.y), 0.f);
+            x[4 * j + 2] = fmaxf(fmaf(x[4 * j + 2], psc.z, psh.z), 0.f);
+            x[4 * j + 3] = fmaxf(fmaf(x[4 * j + 3], psc.w, psh.w), 0.f);
         } else if (PRE == 2) {
+            float y[4] = {x[4 * j], x[4 * j + 1], x[4 * j + 2], x[4 * j + 3]};
             if (a.pre.scale) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) x[k] = fmaf(x[k], a.pre.scale[4 * cR + (k & 3)], a.pre.shift[4 * cR + (k & 3)]);
+                for (int k = 0; k < 4; ++k) y[k] = fmaf(y[k], a.pre.scale[4 * cR + k], a.pre.shift[4 * cR + k]);
             }
-            th_act_vec<8>(x, a.pre.act, a.pre.alpha);
+            th_act_vec<4>(y, a.pre.act, a.pre.alpha);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[4 * j + k] = y[k];
         }
+    };
+    auto store_R = [&](const float (&x)[8], int j) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) R1[k * RPL + rdst[j]] = x[4 * j + k];
+        for (int k = 0; k < 4; ++k) R1[k * RPL + rdst[j]] = x[4 * j + k];
+    };
+    auto next_pre = [&]() {
         if (++cR == a.nchunks) cR = 0;
         load_pre();
     };
-    // V = BT d BT^T of this thread's patch, channel 2 th + k, into Vn: 16 ds_read_b32, 32 adds, 4 ds_write_b128
-    auto transform_ch = [&](float4* Vn, int k) {
-        float t[4][4];                                   // [a][x]
+    auto write_R = [&]() {
+        float x[8] = {pre[0].x, pre[0].y, pre[0].z, pre[0].w, pre[1].x, pre[1].y, pre[1].z, pre[1].w};
+        prologue4(x, 0);
+        prologue4(x, 1);
+        store_R(x, 0);
+        store_R(x, 1);
+        next_pre();
+    };
+    // V = BT d BT^T of this thread's patch, channel 2 th + k, into Vn: 16 ds_read_b32, 32 adds, 4 ds_write_b128 — in three
+    // pieces so that the stage loop can spread them over its slots
+    auto read_patch = [&](float (&d)[16], int k) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float* r = R1 + k * RPL + rsrc + j;
-            wf_bt(r[0], r[RX], r[2 * RX], r[3 * RX], t[0][j], t[1][j], t[2][j], t[3][j]);
-        }
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int aa = 0; aa < 4; ++aa) {
+            for (int j = 0; j < 4; ++j) d[4 * i + j] = R1[k * RPL + rsrc + i * RX + (j >> 1) + (j & 1) * RXH];
+    };
+    auto cols = [&](const float (&d)[16], float (&t)[4][4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wf_bt(d[j], d[4 + j], d[8 + j], d[12 + j], t[0][j], t[1][j], t[2][j], t[3][j]);
+    };
+    auto rows = [&](const float (&t)[4][4], float4* Vn, int k, int a0, int a1) {
+#pragma unroll
+        for (int aa = a0; aa < a1; ++aa) {
             float4 v;
             wf_bt(t[aa][0], t[aa][1], t[aa][2], t[aa][3], v.x, v.y, v.z, v.w);
             Vn[wdst + (k * 4 + aa) * 256] = v;
         }
+    };
+    auto transform_ch = [&](float4* Vn, int k) {
+        float d[16], t[4][4];
+        read_patch(d, k);
+        cols(d, t);
+        rows(t, Vn, k, 0, 4);
     };
     // B fragments: the 768 float4 of a stage ([a][dz][lane]) live in LDS, read by every wave.  They arrive in two halves
     // (a-steps 0,1 / 2,3) through one register each of threads 0..383: loaded from L2 a stage ahead — BEFORE the slice loads of
@@ -237,44 +267,109 @@ __global__ void __launch_bounds__(512, 1) k_conv_wf(const ConvWfArgs a) {
         B4[bdst] = wq[w0];
         bn1 = wq[w0 + 384];
     }
+    unsigned wnext = a.nchunks > 1 ? wbase(0, 1) : wbase(1, 0);     // the weights of the stage after the current one
 
     int ku = 0, c = 0;                                  // current stage's unit ordinal and chunk
     for (int s = 0; s < S; ++s) {
-        __syncthreads();                                // (A) V[s & 1] complete; nobody reads V[(s + 1) & 1] or R any more
+        if (!(DBG & 8)) __syncthreads();                // (A) V[s & 1] complete; nobody reads V[(s + 1) & 1] or R any more
         const float4* const Vc = V4 + (s & 1) * kVB;
         float4* const Vn = V4 + ((s + 1) & 1) * kVB;
-        B4[tid < 384 ? 384 + tid : 768] = bn1;          // a-steps 2,3 of this stage
-        write_R();                                      // slice of stage s + 1 (garbage past the end: never used)
-        {
-            const int cn = c + 1 == a.nchunks ? 0 : c + 1, kn = c + 1 == a.nchunks ? ku + 1 : ku;
-            const unsigned wnext = wbase(kn, cn);
+        // The stage as 12 MFMA steps n = 3 g + dz (8 MFMAs each: positions (g, 0..3) of both row tiles for z tap dz) with
+        // everything else placed in the slots between them; the operands of step n + 1 are requested before the MFMAs of
+        // step n.  The slots are pinned (sched_barrier): all eight waves leave a barrier together, so whatever a wave does
+        // between two MFMAs nobody else on its SIMD covers.
+        float4 ob[3], oa0[3], oa1[3];
+#define WF_FETCH_A(n) { oa0[(n) % 3] = Vc[abase[0][(n) % 3] + ((n) / 3) * 256]; oa1[(n) % 3] = Vc[abase[1][(n) % 3] + ((n) / 3) * 256]; }
+#define WF_FETCH_B(n) { ob[(n) % 3] = B4[(n) * 64 + lane]; }
+#define WF_MMA4(rt, A, n)                                                                                                                \
+        acc[rt][4 * ((n) / 3) + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A.x, ob[(n) % 3].x, acc[rt][4 * ((n) / 3) + 0], 0, 0, 0);     \
+        acc[rt][4 * ((n) / 3) + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(A.y, ob[(n) % 3].y, acc[rt][4 * ((n) / 3) + 1], 0, 0, 0);     \
+        acc[rt][4 * ((n) / 3) + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(A.z, ob[(n) % 3].z, acc[rt][4 * ((n) / 3) + 2], 0, 0, 0);     \
+        acc[rt][4 * ((n) / 3) + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(A.w, ob[(n) % 3].w, acc[rt][4 * ((n) / 3) + 3], 0, 0, 0);
+#define WF_MMA(n) { WF_MMA4(0, oa0[(n) % 3], n) WF_MMA4(1, oa1[(n) % 3], n) }
+// end of a slot: inside it the scheduler is asked for "one MFMA, then up to 5 other instructions (VALU | SALU | VMEM | DS)", eight
+// times — a wave's own VALU / LDS work issues in the shadow of its own MFMAs instead of after them (all waves leave a barrier
+// together: what one wave does after its MFMAs, the other wave of the SIMD does at the same time, and the matrix pipe idles)
+#define WF_PIPE1 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x096, 5, 0);
+#define WF_SLOT { if (!(DBG & 32)) { WF_PIPE1 WF_PIPE1 WF_PIPE1 WF_PIPE1 WF_PIPE1 WF_PIPE1 WF_PIPE1 WF_PIPE1 } __builtin_amdgcn_sched_barrier(0); }
+        if (!(DBG & 4)) B4[tid < 384 ? 384 + tid : 768] = bn1;          // a-steps 2,3 of this stage
+        float x[8] = {pre[0].x, pre[0].y, pre[0].z, pre[0].w, pre[1].x, pre[1].y, pre[1].z, pre[1].w};   // slice of stage s + 1
+        if (!(DBG & 4)) {
             bn0 = wq[wnext];                            // stage s + 1
             bn1 = wq[wnext + 384];
         }
-        issue_loads();                                  // stage s + 2
-        // 4 MFMAs: positions (g, 0..3) of row tile rt, z tap dz
-#define WF_GROUP(g, dz, rt)                                                                                                  \
-        {                                                                                                                    \
-            const float4 av = Vc[abase[rt][dz] + (g) * 256];                                                                 \
-            acc[rt][4 * (g) + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b4.x, acc[rt][4 * (g) + 0], 0, 0, 0);           \
-            acc[rt][4 * (g) + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b4.y, acc[rt][4 * (g) + 1], 0, 0, 0);           \
-            acc[rt][4 * (g) + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b4.z, acc[rt][4 * (g) + 2], 0, 0, 0);           \
-            acc[rt][4 * (g) + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b4.w, acc[rt][4 * (g) + 3], 0, 0, 0);           \
+        if (!(DBG & 2)) {                               // slice of stage s + 2
+#pragma unroll
+            for (int j = 0; j < 2; ++j) pre[j] = *reinterpret_cast<const float4*>(pslice + goff[j]);
         }
-#define WF_STEP_DZ(g, dz) { const float4 b4 = B4[((g) * 3 + (dz)) * 64 + lane]; WF_GROUP(g, dz, 0) WF_GROUP(g, dz, 1) }
-        WF_STEP_DZ(0, 0) WF_STEP_DZ(0, 1) WF_STEP_DZ(0, 2)
-        WF_STEP_DZ(1, 0) WF_STEP_DZ(1, 1) WF_STEP_DZ(1, 2)
-        __syncthreads();                                // (B) R complete; nobody reads the first half of B any more
-        B4[bdst] = bn0;                                 // a-steps 0,1 of stage s + 1
-        // the transform of slice s + 1 (two channels per thread) between the MFMA groups of a-steps 2 and 3
-        WF_STEP_DZ(2, 0)
-        transform_ch(Vn, 0);
-        WF_STEP_DZ(2, 1) WF_STEP_DZ(2, 2)
-        WF_STEP_DZ(3, 0)
-        transform_ch(Vn, 1);
-        WF_STEP_DZ(3, 1) WF_STEP_DZ(3, 2)
-#undef WF_STEP_DZ
-#undef WF_GROUP
+        // Waves 0..3 and 4..7 share the SIMDs pairwise (a workgroup's waves go to SIMDs cyclically): the two groups do their
+        // non-MFMA work in DIFFERENT slots, so that one wave of a SIMD keeps the matrix pipe busy while the other stages.
+        auto half1 = [&](auto late_t) __attribute__((always_inline)) {
+            constexpr int L = decltype(late_t)::value ? 3 : 0;      // first slot of the prologue work
+            WF_FETCH_A(0) WF_FETCH_B(0) WF_FETCH_A(1) WF_FETCH_B(1)
+            WF_SLOT
+#define WF_P1(k)                                                                           \
+            if (!(DBG & 2)) {                                                              \
+                if ((k) == L) prologue4(x, 0);                                             \
+                if ((k) == L + 1) { prologue4(x, 1); store_R(x, 0); }                      \
+                if ((k) == L + 2) { store_R(x, 1); next_pre(); }                           \
+            }
+            WF_FETCH_A(2) WF_FETCH_B(2) WF_MMA(0) WF_P1(0)
+            WF_SLOT
+            WF_FETCH_A(3) WF_FETCH_B(3) WF_MMA(1) WF_P1(1)
+            WF_SLOT
+            WF_FETCH_A(4) WF_FETCH_B(4) WF_MMA(2) WF_P1(2)
+            {   // where the next stage's weights and the slice after next live (scalar arithmetic only)
+                const int cn = c + 1 == a.nchunks ? 0 : c + 1, kn = c + 1 == a.nchunks ? ku + 1 : ku;
+                const int cn2 = cn + 1 == a.nchunks ? 0 : cn + 1, kn2 = cn + 1 == a.nchunks ? kn + 1 : kn;
+                wnext = wbase(kn2, cn2);
+                advance_slice();
+            }
+            WF_SLOT
+            WF_FETCH_A(5) WF_FETCH_B(5) WF_MMA(3) WF_P1(3)
+            WF_SLOT
+            WF_FETCH_A(6) WF_MMA(4) WF_P1(4)
+            WF_SLOT
+            WF_FETCH_A(7) WF_MMA(5) WF_P1(5)
+            WF_SLOT
+#undef WF_P1
+        };
+        // the transform of slice s + 1 (two channels per thread) in six pieces
+        auto half2 = [&](auto late_t) __attribute__((always_inline)) {
+            constexpr int L = decltype(late_t)::value ? 2 : 0;      // first slot of the transform
+            float d[16], t[4][4];
+#define WF_P2(k)                                                                           \
+            if (!(DBG & 1)) {                                                              \
+                if ((k) == L) read_patch(d, 0);                                            \
+                if ((k) == L + 1) { cols(d, t); read_patch(d, 1); rows(t, Vn, 0, 0, 3); }  \
+                if ((k) == L + 2) { rows(t, Vn, 0, 3, 4); cols(d, t); rows(t, Vn, 1, 0, 2); } \
+                if ((k) == L + 3) { rows(t, Vn, 1, 2, 4); }                                \
+            }
+            WF_FETCH_B(6) WF_FETCH_B(7) WF_P2(0)
+            WF_SLOT
+            WF_FETCH_A(8) WF_FETCH_B(8) WF_MMA(6) WF_P2(1)
+            WF_SLOT
+            WF_FETCH_A(9) WF_FETCH_B(9) WF_MMA(7) WF_P2(2)
+            WF_SLOT
+            WF_FETCH_A(10) WF_FETCH_B(10) WF_MMA(8) WF_P2(3)
+            WF_SLOT
+            WF_FETCH_A(11) WF_FETCH_B(11) WF_MMA(9) WF_P2(4)
+            WF_SLOT
+            WF_MMA(10) WF_P2(5)
+            WF_SLOT
+            WF_MMA(11)
+#undef WF_P2
+        };
+        if (!(DBG & 16) || wave < 4) half1(std::false_type{}); else half1(std::true_type{});
+        if (!(DBG & 8)) __syncthreads();                // (B) R complete; nobody reads the first half of B any more
+        if (!(DBG & 4)) B4[bdst] = bn0;                 // a-steps 0,1 of stage s + 1
+        if (!(DBG & 16) || wave < 4) half2(std::false_type{}); else half2(std::true_type{});
+#undef WF_FETCH_A
+#undef WF_FETCH_B
+#undef WF_MMA4
+#undef WF_MMA
+#undef WF_SLOT
+#undef WF_PIPE1
 
         if (c + 1 == a.nchunks) {
             // ---- unit done: inverse transform, bias, epilogue chain, (pool,) store; C layout col = i16, row = 4 q + r ----
@@ -353,6 +448,9 @@ struct WfGeo { int D, H, W; WfKernel k[3][3]; };     // [pool][pre]
                                     {k_conv_wf<D, H, W, 2, 0>, k_conv_wf<D, H, W, 2, 1>, k_conv_wf<D, H, W, 2, 2>}}}
 const WfGeo kWfGeo[] = {WF_INST(10, 10, 10)};
 #undef WF_INST
+const WfKernel kWfDbg[16] = {nullptr, k_conv_wf<10, 10, 10, 0, 0, 1>, k_conv_wf<10, 10, 10, 0, 0, 2>, k_conv_wf<10, 10, 10, 0, 0, 3>,
+                             k_conv_wf<10, 10, 10, 0, 0, 4>, nullptr, k_conv_wf<10, 10, 10, 0, 0, 32>, k_conv_wf<10, 10, 10, 0, 0, 7>,
+                             k_conv_wf<10, 10, 10, 0, 0, 8>, nullptr, nullptr, nullptr, nullptr, nullptr, k_conv_wf<10, 10, 10, 0, 0, 16>, k_conv_wf<10, 10, 10, 0, 0, 15>};
 
 }  // namespace
 
@@ -440,6 +538,10 @@ int launch_conv_wf(hipStream_t s, int64_t n, const ConvWfPlan& p, TView in, TVie
     const bool relu_affine = pre.scale && pre.act == ACT_RELU && p.Cin % 4 == 0 && ((uintptr_t)pre.scale % 16) == 0 && ((uintptr_t)pre.shift % 16) == 0;
     const int pre_kind = (!pre.scale && pre.act == ACT_LINEAR) ? 0 : relu_affine ? 1 : 2;
     WfKernel k = kWfGeo[p.geo].k[p.pool][pre_kind];
+    {   // timing experiments only (tools/bench_layer.py): knock-out instantiations of the plain 10^3 kernel
+        static const int dbg = getenv("TH_WF_DBG") ? atoi(getenv("TH_WF_DBG")) : 0;
+        if (dbg > 0 && dbg < 16 && kWfDbg[dbg] && p.geo == 0 && p.pool == 0 && pre_kind == 0) k = kWfDbg[dbg];
+    }
     HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWfLdsLimit));
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(512), p.lds_bytes, s, a);
     hipError_t e = hipGetLastError();
