@@ -160,3 +160,37 @@ def test_wfused_input_slice_of_an_arena_and_switch(gpu, monkeypatch):
     ref, rl = _run(cfg, weights, frames)
     assert not any("k_conv_wf" in l for l in rl), rl
     assert float(np.abs(got - ref).max()) <= 4e-5 * max(1.0, float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("first", [False, True])
+def test_wfused_chunk_blocked_input_is_bit_identical_to_channels_last(gpu, monkeypatch, first):
+    """A tensor written by one pointwise (or first-layer) step and read only by a conv_wfused step is stored chunk-blocked
+    ([C/4][voxel][4], TView::blk): the producer's stores and the consumer's slice loads change, no arithmetic does — the
+    outputs equal the channels-last plan's (TH_WF_NOBLK=1) bit for bit, ragged chunks included."""
+    if first:
+        shape, cin = (21, 21, 21), 6
+
+        def build(b, x):                                             # TIMED's first two blocks
+            x = b.maxpool(b.batchnorm(b.elu(b.conv3d(x, 32, 3, padding="same"))), 2)
+            return b.maxpool(b.batchnorm(b.elu(b.conv3d(x, 48, 3, padding="same"))), 2)
+    else:
+        shape, cin = SHAPE, 24
+
+        def build(b, x):                                             # DenseCPD bottleneck -> growth convolution
+            y = b.conv3d(b.relu(b.batchnorm(x)), 64, 1, padding="same", use_bias=False)
+            return b.conv3d(b.relu(b.batchnorm(y)), 16, 3, padding="same", use_bias=False)
+
+    b = synth.KerasGraphBuilder((*shape, cin), seed=77, bias_std=0.3)
+    cfg, weights = b.finish(b.flatten(build(b, b.input_name)))
+    rng = np.random.default_rng(5)
+    frames = (rng.standard_normal((11, *shape, cin)) * (rng.random((11, *shape, cin)) < 0.5)).astype(np.float32)
+    want = cnn_oracle.forward(cfg, weights, frames[:3], np.float32)
+    got, labels = _run(cfg, weights, frames)
+    assert sum("output chunk-blocked" in l for l in labels) == 1 and sum("input chunk-blocked" in l for l in labels) == 1, labels
+    assert float(np.abs(got[:3] - want).max()) <= 2e-5 * max(1.0, float(np.abs(want).max()))
+    got3, _ = _run(cfg, weights, frames, chunk=3)
+    assert np.array_equal(got, got3)
+    monkeypatch.setenv("TH_WF_NOBLK", "1")
+    ref, rl = _run(cfg, weights, frames)
+    assert not any("chunk-blocked" in l for l in rl), rl
+    assert np.array_equal(got, ref)

@@ -45,6 +45,11 @@ struct TView {
     int cs = 0;      // floats between consecutive voxels (>= C)
     int coff = 0;    // first channel of this view inside the buffer
     int64_t fs = 0;  // floats between consecutive frames
+    // blk = 4: chunk-blocked storage [C / 4][voxel][4] instead of channels-last — element (f, v, c) at
+    // p[f*fs + (c >> 2) * V() * 4 + v * 4 + (c & 3)] (cs = C, coff = 0).  The planner hands it only to a tensor whose single
+    // producer (conv_pointwise.hip, conv_first.hip) and single consumer (conv_wfused.hip, which reads 4-channel slices of whole
+    // frames: contiguous 16 KB instead of 16 bytes out of every voxel's row) both implement it; every other kernel sees 0.
+    int blk = 0;
     int V() const { return D * H * W; }
 };
 

@@ -40,6 +40,7 @@ struct ConvFirstArgs {
     const float* bias;
     PostOps post;
     float* out; int64_t out_fs; int out_cs, out_coff, Ho, Wo;
+    int out_blk_stride;   // > 0: chunk-blocked output (TView::blk): out_cs is 4 and channel co lives (co >> 2) * out_blk_stride + (co & 3) floats in
     int64_t nframes;
 };
 
@@ -173,6 +174,7 @@ __global__ void __launch_bounds__(WAVES * 64, 3) k_conv_first(const ConvFirstArg
     const int rounds = (a.n_mtiles + WAVES - 1) / WAVES;
     float* outb = a.out + f * a.out_fs + a.out_coff;
     const int co = j;
+    const int cofs = a.out_blk_stride ? (co >> 2) * a.out_blk_stride + (co & 3) : co;
     const bool cok = co < a.Cout;
     const int cc = cok ? co : 0;
     const float bv = a.bias ? a.bias[cc] : 0.f;
@@ -237,8 +239,8 @@ __global__ void __launch_bounds__(WAVES * 64, 3) k_conv_first(const ConvFirstArg
             float y0 = (h ? m4[2] : m4[0]) + bv, y1 = (h ? m4[3] : m4[1]) + bv;
             th_post2(y0, y1, cc, a.post);
             const int o0 = cok ? rowout[mt * 4 + 2 * h] : -1, o1 = cok ? rowout[mt * 4 + 2 * h + 1] : -1;
-            if (o0 >= 0) outb[o0 + co] = y0;
-            if (o1 >= 0) outb[o1 + co] = y1;
+            if (o0 >= 0) outb[o0 + cofs] = y0;
+            if (o1 >= 0) outb[o1 + cofs] = y1;
             continue;
         }
         th_post16(x, cc, a.post);
@@ -246,7 +248,7 @@ __global__ void __launch_bounds__(WAVES * 64, 3) k_conv_first(const ConvFirstArg
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int oo = cok ? rowout[mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h] : -1;
-                if (oo >= 0) outb[oo + co] = x[i];
+                if (oo >= 0) outb[oo + cofs] = x[i];
             }
         } else {
 #pragma unroll
@@ -257,7 +259,7 @@ __global__ void __launch_bounds__(WAVES * 64, 3) k_conv_first(const ConvFirstArg
                 const float o2 = __shfl_xor(m, 32);
                 m = (POOL == 1) ? fmaxf(m, o2) : (m + o2) * 0.125f;
                 const int oo = cok ? rowout[mt * 4 + q] : -1;
-                if (oo >= 0 && (q >> 1) == h) outb[oo + co] = m;
+                if (oo >= 0 && (q >> 1) == h) outb[oo + cofs] = m;
             }
         }
     }
@@ -382,6 +384,11 @@ int launch_conv_first(hipStream_t s, int64_t n, const ConvMfmaPlan& p, const voi
     a.rows = p.rows_pf; a.n_mtiles = p.rows_pf / 32; a.tab_off = (int)p.tab_off;
     a.wpk = wpk; a.Cout = Cout; a.bias = bias; a.post = post;
     a.out = out.p; a.out_fs = out.fs; a.out_cs = out.cs; a.out_coff = out.coff; a.Ho = out.H; a.Wo = out.W;
+    if (out.blk) {
+        if (out.blk != 4 || out.coff || out.cs != Cout || Cout % 4) TH_FAIL(TH_EINVAL, "conv_first: bad chunk-blocked output view");
+        a.out_cs = 4;
+        a.out_blk_stride = out.D * out.H * out.W * 4;
+    }
     a.nframes = n;
     a.vec8 = (dtype == TH_F32 && Cin == 6 && ((uintptr_t)frames % 8) == 0) ? 1 : 0;
     const int64_t grid = n * p.nzb;

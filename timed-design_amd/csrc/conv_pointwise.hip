@@ -39,6 +39,7 @@ struct ConvPwArgs {
     PreOp pre;
     PostOps post;
     float* out; int64_t out_fs; int out_cs, out_coff, out_dense;
+    int out_blk;        // POOL == 0 only: chunk-blocked output (TView::blk) — (f, v, co) at f*out_fs + (co >> 2)*V*4 + v*4 + (co & 3)
     unsigned nrows;     // GEMM rows: frames*V, or frames*Vo*8 when pooled
     unsigned ntiles;
     unsigned in_bytes, out_bytes;   // k_conv_pw2: byte spans of the activation views (buffer descriptors, < 4 GiB)
@@ -86,6 +87,11 @@ __device__ __forceinline__ void pw_epilogue(const ConvPwArgs& a, unsigned tile, 
                 const unsigned row = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (cok && row < a.nrows) {
                     int64_t off;
+                    if (a.out_blk) {
+                        const unsigned f = row / (unsigned)a.V;
+                        a.out[(int64_t)f * a.out_fs + (int64_t)(co >> 2) * a.V * 4 + (int64_t)(row - f * a.V) * 4 + (co & 3)] = x[r];
+                        continue;
+                    }
                     if (a.out_dense) off = (int64_t)row * a.out_cs;
                     else { const unsigned f = row / (unsigned)a.V; off = (int64_t)f * a.out_fs + (int64_t)(row - f * a.V) * a.out_cs; }
                     a.out[off + a.out_coff + co] = x[r];
@@ -325,7 +331,22 @@ __global__ void __launch_bounds__(256, (NT == 4 || KMAX == 16) ? 2 : 3) k_conv_p
 #pragma unroll
             for (int r = 0; r < 16; ++r) x[r] = acc[nt][r] + bv;
             if (npost) th_post16(x, cc, a.post);    // (its BatchNorm constants are loaded in the loop: layers with an epilogue chain pay the drain)
-            if (POOL == 0 && a.out_dense && tile * 32 + 32 <= a.nrows) {
+            if (POOL == 0 && a.out_blk) {
+                // chunk-blocked output: the lane's 16 rows are tile*32 + 4h + {0..3, 8..11, 16..19, 24..27}; a tile crosses at
+                // most one frame boundary (V >= 32), so ONE division per (tile, n-tile) and a compare per row
+                const unsigned row0 = tile * 32 + 4 * h;
+                const unsigned f0 = row0 / (unsigned)a.V, v0 = row0 - f0 * (unsigned)a.V;
+                const unsigned cbase = (unsigned)(co >> 2) * (unsigned)a.V * 4u + (unsigned)(co & 3);
+                const unsigned fwrap = (unsigned)a.out_fs - (unsigned)a.V * 4u;      // floats from (f, V) to (f + 1, 0) of the same chunk
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned dr = (unsigned)((r & 3) + 8 * (r >> 2));
+                    const unsigned v = v0 + dr;
+                    const unsigned e = f0 * (unsigned)a.out_fs + v * 4u + (v >= (unsigned)a.V ? fwrap : 0u) + cbase;
+                    const unsigned off = (cok && row0 + dr < a.nrows && !(a.dbg & 2)) ? e * 4u : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x[r]), rout, off, 0, 0);
+                }
+            } else if (POOL == 0 && a.out_dense && tile * 32 + 32 <= a.nrows) {
                 // whole tile in range, rows at a constant byte stride: ONE vector offset per (tile, n-tile) and the row
                 // displacement as the instruction's scalar offset — no per-store address arithmetic (it was ~8 VALU
                 // instructions x 32 stores per tile, a third of this kernel's VALU issue)
@@ -481,6 +502,8 @@ int launch_conv_pw(hipStream_t s, int64_t n, const ConvMfmaPlan& p, TView in, TV
     a.Vo = out.D * out.H * out.W; a.Ho = out.H; a.Wo = out.W;
     a.wpk = wpk; a.Cout = Cout; a.bias = bias; a.pre = pre; a.post = post;
     a.out = out.p; a.out_fs = out.fs; a.out_cs = out.cs; a.out_coff = out.coff;
+    a.out_blk = out.blk;
+    if (out.blk && (p.pool || out.blk != 4 || out.coff || out.cs != Cout || Cout % 4)) TH_FAIL(TH_EINVAL, "conv_pw: bad chunk-blocked output view");
     const int64_t out_v = p.pool ? a.Vo : a.V;
     a.out_dense = (out.fs == out_v * out.cs) ? 1 : 0;
     const int64_t nrows = p.pool ? n * a.Vo * 8 : n * a.V;

@@ -7,7 +7,7 @@
 // the halves of G are folded into the weights on the host in double precision).  Unlike conv_wino.hip (5^3 volumes, wide
 // layers, V and M through HBM) NOTHING of the transform domain leaves the CU here:
 //
-//   R  [4 channels][z][y+1][x+1]                      the raw 4-channel slice of the frame (BN -> act prologue applied), zero halo
+//   R  [2 channel pairs][z][y+1][x+1] x float2        the raw 4-channel slice of the frame (BN -> act prologue applied), zero halo
 //   B  [a 4][dz 3][lane 64] x float4(b)               the stage's transformed weights, shared by the 8 waves
 //   V  [ci 4][a 4][rec = z * NT + tile] x float4(b)   V = BT d BT^T of every 4 x 4 patch, double-buffered (2 x 64 KB)
 //   M  accumulators: 16 positions x 2 row tiles of 16 (z, tile) rows x 16 output channels per wave (128 AGPRs)
@@ -42,6 +42,7 @@ constexpr size_t kWfLdsLimit = 160 * 1024;
 
 struct ConvWfArgs {
     const float* in; int64_t in_fs; int in_cs, in_coff;
+    int in_blk;                       // chunk-blocked input (TView::blk): the slice of chunk c is the contiguous run [c][voxel][4]
     int Cin, nchunks;
     const float* wpk;                 // [cb][chunk][a][dz][lane = 16 (ci & 3) + (co & 15)][b]
     int Cout, ncb;
@@ -61,7 +62,7 @@ __device__ __forceinline__ void wf_bt(float d0, float d1, float d2, float d3, fl
 // POOL: 0 none, 1 max 2x2x2, 2 average 2x2x2.  PRE: prologue on the staged input — 0 none, 1 BN-affine -> ReLU (DenseNet-style
 // pre-activation layers), 2 generic (optional affine, any activation: op decoded per stage)
 // DBG: timing knock-outs (TH_WF_DBG, results are WRONG): 1 no transform, 2 no slice loads / R writes, 4 no weight traffic, 8 no barriers;
-// 6 (= bit 32, results right): no MFMA / other interleave request inside the slots; 14 (slot 14 of the table = bit 16, results right): the two wave groups of a SIMD pair on different slot schedules (spills: the branches cost more than the overlap gives)
+// 64 no V writes, 128 R reads replaced by loop invariants (the compiler then hoists the whole transform), 256 every slice from frame 0; 32 (results right): no MFMA / other interleave request inside the slots; 16 (results right): the two wave groups of a SIMD pair on different slot schedules (spills: the branches cost more than the overlap gives)
 template <int D, int H, int W, int POOL, int PRE, int DBG = 0>
 __global__ void __launch_bounds__(512, 1) k_conv_wf(const ConvWfArgs a) {
     constexpr int TY = H / 2, TX = W / 2, NT = TY * TX, NR = D * NT, NZ = NR;
@@ -76,7 +77,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_wf(const ConvWfArgs a) {
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     float4* const V4 = smem;                                            // [2][16 planes][256 records]
     float4* const B4 = smem + 2 * kVB;                                  // [a 4][dz 3][lane 64] + 1 dump: this stage's weight fragments
-    float* const R1 = reinterpret_cast<float*>(smem + 2 * kVB + 769);   // [4 channels][RVOX + 1 (dump)]
+    float2* const R2 = reinterpret_cast<float2*>(smem + 2 * kVB + 769); // [2 channel pairs][RVOX + 1 (dump)]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -113,7 +114,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_wf(const ConvWfArgs a) {
         const bool ok = v < NV;
         const int vv = ok ? v : 0;
         const int z = vv / (H * W), y = (vv / W) % H, x = vv % W;
-        goff[j] = vv * a.in_cs;
+        goff[j] = vv * (a.in_blk ? 4 : a.in_cs);
         // inside a row the even columns xx = x + 1 = 0, 2, .. come first, then the odd ones: the tiles of a row read columns
         // 2 tx + j, i.e. for a fixed j consecutive lanes read consecutive floats (a plain row would put them on even banks only)
         const int xx = x + 1;
@@ -126,7 +127,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_wf(const ConvWfArgs a) {
         const bool ok = trec < NR;
         const int rr = ok ? trec : 0;
         const int z = rr / NT, tile = rr % NT, ty = tile / TX, tx = tile % TX;
-        rsrc = 2 * th * RPL + (z * RYS + 2 * ty) * RX + tx;
+        rsrc = th * RPL + (z * RYS + 2 * ty) * RX + tx;
         wdst = th * 8 * 256 + (ok ? trec : 255);
     }
     // A side: rows 32 wave + 16 rt + i16 (POOL: rows are ordered (z pair, tile, z low) so that a lane's registers r = 0,1 and
@@ -158,7 +159,8 @@ __global__ void __launch_bounds__(512, 1) k_conv_wf(const ConvWfArgs a) {
     auto slice_ptr = [&](int kunit, int chunk) -> const float* {
         int64_t f; int cb; bool ok;
         unit_of(kunit < my_units ? kunit : my_units - 1, f, cb, ok);
-        return in0 + f * a.in_fs + 4 * chunk;
+        if (DBG & 256) f = 0;                           // (timing: every workgroup reads frame 0 — the slices come from L2)
+        return in0 + f * a.in_fs + (a.in_blk ? NV * 4 : 4) * chunk;
     };
     int kL = 0, cL = 0, cR = 0;
     float4 pre[2];
@@ -200,7 +202,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_wf(const ConvWfArgs a) {
     };
     auto store_R = [&](const float (&x)[8], int j) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) R1[k * RPL + rdst[j]] = x[4 * j + k];
+        for (int k = 0; k < 2; ++k) R2[k * RPL + rdst[j]] = make_float2(x[4 * j + 2 * k], x[4 * j + 2 * k + 1]);
     };
     auto next_pre = [&]() {
         if (++cR == a.nchunks) cR = 0;
@@ -214,31 +216,38 @@ __global__ void __launch_bounds__(512, 1) k_conv_wf(const ConvWfArgs a) {
         store_R(x, 1);
         next_pre();
     };
-    // V = BT d BT^T of this thread's patch, channel 2 th + k, into Vn: 16 ds_read_b32, 32 adds, 4 ds_write_b128 — in three
-    // pieces so that the stage loop can spread them over its slots
-    auto read_patch = [&](float (&d)[16], int k) {
+    // V = BT d BT^T of this thread's patch for its two channels (2 th, 2 th + 1: the float2 halves) into Vn: 16 ds_read_b64,
+    // 32 packed adds, 8 ds_write_b128 — column by column, so that the stage loop can spread the pieces over its slots
+    auto read_col = [&](float2 (&d)[4], int j) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) d[4 * i + j] = R1[k * RPL + rsrc + i * RX + (j >> 1) + (j & 1) * RXH];
+            d[i] = (DBG & 128) ? make_float2(__builtin_bit_cast(float, rsrc + 4 * i + j), 1.f) : R2[rsrc + i * RX + (j >> 1) + (j & 1) * RXH];
     };
-    auto cols = [&](const float (&d)[16], float (&t)[4][4]) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) wf_bt(d[j], d[4 + j], d[8 + j], d[12 + j], t[0][j], t[1][j], t[2][j], t[3][j]);
+    auto col = [&](const float2 (&d)[4], float2 (&t)[4][4], int j) {
+        t[0][j] = make_float2(d[0].x - d[2].x, d[0].y - d[2].y);
+        t[1][j] = make_float2(d[1].x + d[2].x, d[1].y + d[2].y);
+        t[2][j] = make_float2(d[2].x - d[1].x, d[2].y - d[1].y);
+        t[3][j] = make_float2(d[1].x - d[3].x, d[1].y - d[3].y);
     };
-    auto rows = [&](const float (&t)[4][4], float4* Vn, int k, int a0, int a1) {
+    auto rows = [&](const float2 (&t)[4][4], float4* Vn, int a0, int a1) {
 #pragma unroll
         for (int aa = a0; aa < a1; ++aa) {
-            float4 v;
-            wf_bt(t[aa][0], t[aa][1], t[aa][2], t[aa][3], v.x, v.y, v.z, v.w);
-            Vn[wdst + (k * 4 + aa) * 256] = v;
+            float4 v0, v1;
+            wf_bt(t[aa][0].x, t[aa][1].x, t[aa][2].x, t[aa][3].x, v0.x, v0.y, v0.z, v0.w);
+            wf_bt(t[aa][0].y, t[aa][1].y, t[aa][2].y, t[aa][3].y, v1.x, v1.y, v1.z, v1.w);
+            if (DBG & 64) {
+                if (v0.x + v0.y + v0.z + v0.w + v1.x + v1.y + v1.z + v1.w == 1.2345e-30f) Vn[wdst + aa * 256] = v0;
+            } else {
+                Vn[wdst + aa * 256] = v0;
+                Vn[wdst + (4 + aa) * 256] = v1;
+            }
         }
     };
-    auto transform_ch = [&](float4* Vn, int k) {
-        float d[16], t[4][4];
-        read_patch(d, k);
-        cols(d, t);
-        rows(t, Vn, k, 0, 4);
+    auto transform_all = [&](float4* Vn) {
+        float2 d[4], t[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { read_col(d, j); col(d, t, j); }
+        rows(t, Vn, 0, 4);
     };
     // B fragments: the 768 float4 of a stage ([a][dz][lane]) live in LDS, read by every wave.  They arrive in two halves
     // (a-steps 0,1 / 2,3) through one register each of threads 0..383: loaded from L2 a stage ahead — BEFORE the slice loads of
@@ -260,8 +269,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_wf(const ConvWfArgs a) {
     write_R();
     issue_loads();
     __syncthreads();
-    transform_ch(V4, 0);
-    transform_ch(V4, 1);
+    transform_all(V4);
     {
         const unsigned w0 = wbase(0, 0);
         B4[bdst] = wq[w0];
@@ -278,15 +286,15 @@ __global__ void __launch_bounds__(512, 1) k_conv_wf(const ConvWfArgs a) {
         // everything else placed in the slots between them; the operands of step n + 1 are requested before the MFMAs of
         // step n.  The slots are pinned (sched_barrier): all eight waves leave a barrier together, so whatever a wave does
         // between two MFMAs nobody else on its SIMD covers.
-        float4 ob[3], oa0[3], oa1[3];
-#define WF_FETCH_A(n) { oa0[(n) % 3] = Vc[abase[0][(n) % 3] + ((n) / 3) * 256]; oa1[(n) % 3] = Vc[abase[1][(n) % 3] + ((n) / 3) * 256]; }
-#define WF_FETCH_B(n) { ob[(n) % 3] = B4[(n) * 64 + lane]; }
+        float4 ob[2], oa0[2], oa1[2];
+#define WF_FETCH_A(n) { oa0[(n) & 1] = Vc[abase[0][(n) % 3] + ((n) / 3) * 256]; oa1[(n) & 1] = Vc[abase[1][(n) % 3] + ((n) / 3) * 256]; }
+#define WF_FETCH_B(n) { ob[(n) & 1] = B4[(n) * 64 + lane]; }
 #define WF_MMA4(rt, A, n)                                                                                                                \
-        acc[rt][4 * ((n) / 3) + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A.x, ob[(n) % 3].x, acc[rt][4 * ((n) / 3) + 0], 0, 0, 0);     \
-        acc[rt][4 * ((n) / 3) + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(A.y, ob[(n) % 3].y, acc[rt][4 * ((n) / 3) + 1], 0, 0, 0);     \
-        acc[rt][4 * ((n) / 3) + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(A.z, ob[(n) % 3].z, acc[rt][4 * ((n) / 3) + 2], 0, 0, 0);     \
-        acc[rt][4 * ((n) / 3) + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(A.w, ob[(n) % 3].w, acc[rt][4 * ((n) / 3) + 3], 0, 0, 0);
-#define WF_MMA(n) { WF_MMA4(0, oa0[(n) % 3], n) WF_MMA4(1, oa1[(n) % 3], n) }
+        acc[rt][4 * ((n) / 3) + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A.x, ob[(n) & 1].x, acc[rt][4 * ((n) / 3) + 0], 0, 0, 0);     \
+        acc[rt][4 * ((n) / 3) + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(A.y, ob[(n) & 1].y, acc[rt][4 * ((n) / 3) + 1], 0, 0, 0);     \
+        acc[rt][4 * ((n) / 3) + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(A.z, ob[(n) & 1].z, acc[rt][4 * ((n) / 3) + 2], 0, 0, 0);     \
+        acc[rt][4 * ((n) / 3) + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(A.w, ob[(n) & 1].w, acc[rt][4 * ((n) / 3) + 3], 0, 0, 0);
+#define WF_MMA(n) { WF_MMA4(0, oa0[(n) & 1], n) WF_MMA4(1, oa1[(n) & 1], n) }
 // end of a slot: inside it the scheduler is asked for "one MFMA, then up to 5 other instructions (VALU | SALU | VMEM | DS)", eight
 // times — a wave's own VALU / LDS work issues in the shadow of its own MFMAs instead of after them (all waves leave a barrier
 // together: what one wave does after its MFMAs, the other wave of the SIMD does at the same time, and the matrix pipe idles)
@@ -306,7 +314,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_wf(const ConvWfArgs a) {
         // non-MFMA work in DIFFERENT slots, so that one wave of a SIMD keeps the matrix pipe busy while the other stages.
         auto half1 = [&](auto late_t) __attribute__((always_inline)) {
             constexpr int L = decltype(late_t)::value ? 3 : 0;      // first slot of the prologue work
-            WF_FETCH_A(0) WF_FETCH_B(0) WF_FETCH_A(1) WF_FETCH_B(1)
+            WF_FETCH_A(0) WF_FETCH_B(0)
             WF_SLOT
 #define WF_P1(k)                                                                           \
             if (!(DBG & 2)) {                                                              \
@@ -314,11 +322,11 @@ __global__ void __launch_bounds__(512, 1) k_conv_wf(const ConvWfArgs a) {
                 if ((k) == L + 1) { prologue4(x, 1); store_R(x, 0); }                      \
                 if ((k) == L + 2) { store_R(x, 1); next_pre(); }                           \
             }
-            WF_FETCH_A(2) WF_FETCH_B(2) WF_MMA(0) WF_P1(0)
+            WF_FETCH_A(1) WF_FETCH_B(1) WF_MMA(0) WF_P1(0)
             WF_SLOT
-            WF_FETCH_A(3) WF_FETCH_B(3) WF_MMA(1) WF_P1(1)
+            WF_FETCH_A(2) WF_FETCH_B(2) WF_MMA(1) WF_P1(1)
             WF_SLOT
-            WF_FETCH_A(4) WF_FETCH_B(4) WF_MMA(2) WF_P1(2)
+            WF_FETCH_A(3) WF_FETCH_B(3) WF_MMA(2) WF_P1(2)
             {   // where the next stage's weights and the slice after next live (scalar arithmetic only)
                 const int cn = c + 1 == a.nchunks ? 0 : c + 1, kn = c + 1 == a.nchunks ? ku + 1 : ku;
                 const int cn2 = cn + 1 == a.nchunks ? 0 : cn + 1, kn2 = cn + 1 == a.nchunks ? kn + 1 : kn;
@@ -326,36 +334,38 @@ __global__ void __launch_bounds__(512, 1) k_conv_wf(const ConvWfArgs a) {
                 advance_slice();
             }
             WF_SLOT
-            WF_FETCH_A(5) WF_FETCH_B(5) WF_MMA(3) WF_P1(3)
+            WF_FETCH_A(4) WF_FETCH_B(4) WF_MMA(3) WF_P1(3)
             WF_SLOT
-            WF_FETCH_A(6) WF_MMA(4) WF_P1(4)
+            WF_FETCH_A(5) WF_FETCH_B(5) WF_MMA(4) WF_P1(4)
             WF_SLOT
-            WF_FETCH_A(7) WF_MMA(5) WF_P1(5)
+            WF_FETCH_A(6) WF_MMA(5) WF_P1(5)
             WF_SLOT
 #undef WF_P1
         };
         // the transform of slice s + 1 (two channels per thread) in six pieces
         auto half2 = [&](auto late_t) __attribute__((always_inline)) {
-            constexpr int L = decltype(late_t)::value ? 2 : 0;      // first slot of the transform
-            float d[16], t[4][4];
+            constexpr int L = 0;                                    // first slot of the transform
+            float2 d[4], t[4][4];
 #define WF_P2(k)                                                                           \
             if (!(DBG & 1)) {                                                              \
-                if ((k) == L) read_patch(d, 0);                                            \
-                if ((k) == L + 1) { cols(d, t); read_patch(d, 1); rows(t, Vn, 0, 0, 3); }  \
-                if ((k) == L + 2) { rows(t, Vn, 0, 3, 4); cols(d, t); rows(t, Vn, 1, 0, 2); } \
-                if ((k) == L + 3) { rows(t, Vn, 1, 2, 4); }                                \
+                if ((k) == L) read_col(d, 0);                                              \
+                if ((k) == L + 1) { col(d, t, 0); read_col(d, 1); }                        \
+                if ((k) == L + 2) { col(d, t, 1); read_col(d, 2); }                        \
+                if ((k) == L + 3) { col(d, t, 2); read_col(d, 3); }                        \
+                if ((k) == L + 4) { col(d, t, 3); rows(t, Vn, 0, 2); }                     \
+                if ((k) == L + 5) { rows(t, Vn, 2, 4); }                                   \
             }
-            WF_FETCH_B(6) WF_FETCH_B(7) WF_P2(0)
+            WF_FETCH_B(6) WF_P2(0)
             WF_SLOT
-            WF_FETCH_A(8) WF_FETCH_B(8) WF_MMA(6) WF_P2(1)
+            WF_FETCH_A(7) WF_FETCH_B(7) WF_MMA(6) WF_P2(1)
             WF_SLOT
-            WF_FETCH_A(9) WF_FETCH_B(9) WF_MMA(7) WF_P2(2)
+            WF_FETCH_A(8) WF_FETCH_B(8) WF_MMA(7) WF_P2(2)
             WF_SLOT
-            WF_FETCH_A(10) WF_FETCH_B(10) WF_MMA(8) WF_P2(3)
+            WF_FETCH_A(9) WF_FETCH_B(9) WF_MMA(8) WF_P2(3)
             WF_SLOT
-            WF_FETCH_A(11) WF_FETCH_B(11) WF_MMA(9) WF_P2(4)
+            WF_FETCH_A(10) WF_FETCH_B(10) WF_MMA(9) WF_P2(4)
             WF_SLOT
-            WF_MMA(10) WF_P2(5)
+            WF_FETCH_A(11) WF_FETCH_B(11) WF_MMA(10) WF_P2(5)
             WF_SLOT
             WF_MMA(11)
 #undef WF_P2
@@ -448,9 +458,10 @@ struct WfGeo { int D, H, W; WfKernel k[3][3]; };     // [pool][pre]
                                     {k_conv_wf<D, H, W, 2, 0>, k_conv_wf<D, H, W, 2, 1>, k_conv_wf<D, H, W, 2, 2>}}}
 const WfGeo kWfGeo[] = {WF_INST(10, 10, 10)};
 #undef WF_INST
-const WfKernel kWfDbg[16] = {nullptr, k_conv_wf<10, 10, 10, 0, 0, 1>, k_conv_wf<10, 10, 10, 0, 0, 2>, k_conv_wf<10, 10, 10, 0, 0, 3>,
-                             k_conv_wf<10, 10, 10, 0, 0, 4>, nullptr, k_conv_wf<10, 10, 10, 0, 0, 32>, k_conv_wf<10, 10, 10, 0, 0, 7>,
-                             k_conv_wf<10, 10, 10, 0, 0, 8>, nullptr, nullptr, nullptr, nullptr, nullptr, k_conv_wf<10, 10, 10, 0, 0, 16>, k_conv_wf<10, 10, 10, 0, 0, 15>};
+struct WfDbg { int code; WfKernel k; };
+#define WF_DBG(c) {c, k_conv_wf<10, 10, 10, 0, 0, c>}
+const WfDbg kWfDbg[] = {WF_DBG(1), WF_DBG(2), WF_DBG(3), WF_DBG(4), WF_DBG(7), WF_DBG(8), WF_DBG(15), WF_DBG(32), WF_DBG(64), WF_DBG(256)};
+#undef WF_DBG
 
 }  // namespace
 
@@ -519,6 +530,8 @@ int launch_conv_wf(hipStream_t s, int64_t n, const ConvWfPlan& p, TView in, TVie
     ConvWfArgs a;
     std::memset(&a, 0, sizeof a);
     a.in = in.p; a.in_fs = in.fs; a.in_cs = in.cs; a.in_coff = in.coff;
+    a.in_blk = in.blk;
+    if (in.blk && (in.blk != 4 || in.coff || in.cs != p.Cin)) TH_FAIL(TH_EINVAL, "conv_wf: bad chunk-blocked input view");
     a.Cin = p.Cin; a.nchunks = p.nchunks; a.wpk = wpk; a.Cout = p.Cout; a.ncb = p.ncb; a.bias = bias; a.pre = pre; a.post = post;
     a.out = out.p; a.out_fs = out.fs; a.out_cs = out.cs; a.out_coff = out.coff; a.nframes = n;
     const int64_t nslots = (n + 7) / 8 * 8 * p.ncb;
@@ -540,7 +553,8 @@ int launch_conv_wf(hipStream_t s, int64_t n, const ConvWfPlan& p, TView in, TVie
     WfKernel k = kWfGeo[p.geo].k[p.pool][pre_kind];
     {   // timing experiments only (tools/bench_layer.py): knock-out instantiations of the plain 10^3 kernel
         static const int dbg = getenv("TH_WF_DBG") ? atoi(getenv("TH_WF_DBG")) : 0;
-        if (dbg > 0 && dbg < 16 && kWfDbg[dbg] && p.geo == 0 && p.pool == 0 && pre_kind == 0) k = kWfDbg[dbg];
+        if (dbg > 0 && p.geo == 0 && p.pool == 0 && pre_kind == 0)
+            for (const WfDbg& d : kWfDbg) if (d.code == dbg) k = d.k;
     }
     HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWfLdsLimit));
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(512), p.lds_bytes, s, a);

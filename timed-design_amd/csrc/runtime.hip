@@ -152,6 +152,7 @@ struct Node {
     // planning state
     int absorbed_by = -1;  // node index of the step that computes this node as part of its chain
     int buf = -1, cs = 0, coff = 0;  // storage of this node's output (if materialised)
+    int blk = 0;                     // 4: chunk-blocked storage (TView::blk)
     bool materialised = false;
 };
 
@@ -256,6 +257,7 @@ struct th_model {
         v.p = b.dev + lane_off * b.floats_per_frame;
         v.D = nd.D; v.H = nd.H; v.W = nd.W; v.C = nd.C;
         v.cs = nd.cs; v.coff = nd.coff; v.fs = b.floats_per_frame;
+        v.blk = nd.blk;
         return v;
     }
 };
@@ -562,6 +564,44 @@ int plan(th_model* m) {
     th_model* M = m;
     int fused_tail = -1;     // the final Softmax node when it was folded into the GlobalAveragePooling3D step
     std::set<int> wino_in_done;   // Winograd convolutions whose input transform was fused into the previous layer's output transform
+    // does convolution i run on conv_wfused.hip?  (asked twice: by the layout pre-pass below and when its step is emitted)
+    auto wf_plan_for = [&](int i, ConvWfPlan* fp) -> bool {
+        const Node& n = N[i];
+        if (n.op != OP_CONV3D || !fus.count(i) || !(M->wfused && use_mfma && fuse) || n.ip[13] == ACT_SOFTMAX) return false;
+        const ConvFusion& f = fus[i];
+        const Node& sn = N[f.src];
+        const ConvGeom g = geom_of(n, sn);
+        TView iv; iv.D = sn.D; iv.H = sn.H; iv.W = sn.W; iv.C = sn.C; iv.cs = sn.cs; iv.coff = sn.coff;
+        TView ov; ov.D = n.D; ov.H = n.H; ov.W = n.W; ov.C = n.C;
+        if (!conv_wf_view_ok(iv)) return false;
+        return conv_wf_plan(iv, ov, g, sn.C, n.C, f.pool >= 0 ? (N[f.pool].op == OP_MAXPOOL ? 1 : 2) : 0, fp);
+    };
+    // chunk-blocked storage (TView::blk) for a tensor that is written by ONE pointwise / first-layer step and read by ONE
+    // conv_wfused step and by nothing else: that kernel reads 4-channel slices of whole frames, which are 16 bytes out of
+    // every voxel's channel row in the channels-last form (measured: 3.8x the tensor's bytes fetched from HBM) and one
+    // contiguous 16 KB run in the blocked form
+    if (!(getenv("TH_WF_NOBLK") && atoi(getenv("TH_WF_NOBLK"))))
+        for (int i = 0; i < nn; ++i) {
+            ConvWfPlan fp;
+            if (!(fus.count(i) || N[i].absorbed_by < 0) || !wf_plan_for(i, &fp)) continue;
+            const ConvFusion& f = fus[i];
+            const int src = f.src;
+            Node& sn = N[src];
+            if (src == M->input_node || src == M->output_node || !sn.materialised || sn.buf < 0) continue;
+            if (sn.consumers.size() != 1 || sn.consumers[0] != (f.pre.empty() ? i : f.pre[0])) continue;
+            if (sn.cs != sn.C || sn.coff != 0 || sn.C % 4) continue;
+            int prod = -1, nprod = 0;
+            for (auto& kv : fus) if (kv.second.last == src) { prod = kv.first; ++nprod; }
+            if (nprod != 1 || N[prod].op != OP_CONV3D || !mplans.count(prod)) continue;
+            const ConvMfmaPlan& pp = mplans[prod];
+            ConvWfPlan dummy;
+            if (wf_plan_for(prod, &dummy)) continue;                    // (the producer itself runs on conv_wfused: channels-last stores only)
+            if (!((pp.cfg >= 300 && pp.pool == 0) || pp.cfg == 100)) continue;
+            bool shared = false;                                        // nobody else may alias the buffer (Flatten / Identity views)
+            for (int k = 0; k < nn; ++k) if (k != src && N[k].buf == sn.buf && N[k].materialised) shared = true;
+            if (shared) continue;
+            sn.blk = 4;
+        }
     for (int i = 0; i < nn; ++i) {
         Node& n = N[i];
         const bool emits = fus.count(i) || n.absorbed_by < 0;
@@ -685,9 +725,7 @@ int plan(th_model* m) {
                         continue;
                     }
                     ConvWfPlan fp;
-                    TView fiv = wiv; fiv.cs = sn.cs; fiv.coff = sn.coff;
-                    if (M->wfused && use_mfma && fuse && !split_softmax && conv_wf_view_ok(fiv) &&
-                        conv_wf_plan(wiv, wov, g, Cin, Cout, f.pool >= 0 ? (N[f.pool].op == OP_MAXPOOL ? 1 : 2) : 0, &fp)) {
+                    if (wf_plan_for(i, &fp)) {
                         // F(2,3)^2 in-plane with the whole transform domain in LDS: one step, one kernel
                         std::vector<float> packed(fp.wpk_floats);
                         conv_wf_pack_weights(fp, hw, packed.data());
@@ -696,7 +734,7 @@ int plan(th_model* m) {
                         st.direct_flops = st.flops;
                         st.flops = fp.own_flops;
                         st.exec_flops = fp.exec_flops;
-                        st.label = n.name + ": " + fp.label;
+                        st.label = n.name + ": " + fp.label + (sn.blk ? " (input chunk-blocked)" : "");
                         st.run = [=](hipStream_t s, int64_t cnt) {
                             return launch_conv_wf(s, cnt, fp, M->view(src), M->view(dst), dw, dbias, pre, po);
                         };
@@ -707,7 +745,7 @@ int plan(th_model* m) {
                         float* dw;
                         if ((rc = upload(M, packed.data(), packed.size(), &dw))) return rc;
                         st.exec_flops = mp.exec_flops;
-                        st.label = n.name + ": " + conv_first_label(mp, Cin, po);
+                        st.label = n.name + ": " + conv_first_label(mp, Cin, po) + (N[dst].blk ? " (output chunk-blocked)" : "");
                         const int iD = sn.D, iH = sn.H, iW = sn.W;
                         st.run = [=](hipStream_t s, int64_t cnt) {
                             return launch_conv_first(s, cnt, mp, M->cur_in, M->cur_dtype, iD, iH, iW, Cin, M->view(dst), g, Cout,
@@ -720,7 +758,7 @@ int plan(th_model* m) {
                         float* dw;
                         if ((rc = upload(M, packed.data(), packed.size(), &dw))) return rc;
                         st.exec_flops = mp.exec_flops;
-                        st.label = n.name + ": " + mp.label;
+                        st.label = n.name + ": " + mp.label + (N[dst].blk ? " (output chunk-blocked)" : "");
                         st.run = [=](hipStream_t s, int64_t cnt) {
                             return launch_conv_pw(s, cnt, mp, M->view(src), M->view(dst), Cin, Cout, dw, dbias, pre, po);
                         };
@@ -1368,7 +1406,7 @@ int th_model_fetch(th_model* m, const char* layer_name, int64_t n, float* out, i
     for (size_t i = 0; i < m->nodes.size(); ++i) {
         const Node& nd = m->nodes[i];
         if (nd.name != layer_name) continue;
-        if (!nd.materialised || nd.buf < 0) TH_FAIL(TH_EINVAL, "layer %s is fused away (load with TH_LOAD_KEEP_ALL)", layer_name);
+        if (!nd.materialised || nd.buf < 0 || nd.blk) TH_FAIL(TH_EINVAL, "layer %s is fused away (load with TH_LOAD_KEEP_ALL)", layer_name);
         if (n > m->last_n) TH_FAIL(TH_EINVAL, "only %lld frames in the last chunk", (long long)m->last_n);
         const int64_t per = (int64_t)nd.D * nd.H * nd.W * nd.C;
         if (out_floats < n * per) TH_FAIL(TH_EINVAL, "output buffer too small (%lld < %lld)", (long long)out_floats, (long long)(n * per));
