@@ -211,8 +211,10 @@ __global__ void __launch_bounds__(256, NT == 4 ? 2 : (KMAX == 16 && NT == 2 ? 3 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-template <int KMAX, int NT, int POOL>
-__global__ void __launch_bounds__(256, (NT == 4 || KMAX == 16) ? 2 : 3) k_conv_pw2(const ConvPwArgs a) {   // KMAX = 12: three per CU
+// BLK: the chunk-blocked output form (TView::blk, POOL == 0 only) as its own instantiation — compiled into the plain kernels it
+// cost them registers (k_conv_pw2<12,2,0> spilled, <4,2,0> lost a workgroup per CU: 0.29 -> 0.56 ms for DenseCPD's first bottleneck)
+template <int KMAX, int NT, int POOL, int BLK = 0>
+__global__ void __launch_bounds__(256, (NT == 4 || KMAX == 16 || (BLK && KMAX == 12 && NT == 2)) ? 2 : ((BLK && KMAX == 4 && NT <= 2) ? 4 : 3)) k_conv_pw2(const ConvPwArgs a) {   // KMAX = 12: three per CU
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -224,6 +226,8 @@ __global__ void __launch_bounds__(256, (NT == 4 || KMAX == 16) ? 2 : 3) k_conv_p
     float4* Bs = smem;
     float* psc = reinterpret_cast<float*>(smem + (size_t)K8 * NT * 64);
     float* psh = psc + K8 * 8;
+    // chunk-blocked output only: a [32 rows][36] transpose tile per wave behind the prologue constants (launch_conv_pw adds it)
+    float* const tsc = psh + K8 * 8 + wave * (32 * 36);
     {
         const float4* src = reinterpret_cast<const float4*>(a.wpk);
         for (int i = tid; i < K8 * NT * 64; i += 256) Bs[i] = src[i];
@@ -331,22 +335,24 @@ __global__ void __launch_bounds__(256, (NT == 4 || KMAX == 16) ? 2 : 3) k_conv_p
 #pragma unroll
             for (int r = 0; r < 16; ++r) x[r] = acc[nt][r] + bv;
             if (npost) th_post16(x, cc, a.post);    // (its BatchNorm constants are loaded in the loop: layers with an epilogue chain pay the drain)
-            if (POOL == 0 && a.out_blk) {
-                // chunk-blocked output: the lane's 16 rows are tile*32 + 4h + {0..3, 8..11, 16..19, 24..27}; a tile crosses at
-                // most one frame boundary (V >= 32), so ONE division per (tile, n-tile) and a compare per row
-                const unsigned row0 = tile * 32 + 4 * h;
-                const unsigned f0 = row0 / (unsigned)a.V, v0 = row0 - f0 * (unsigned)a.V;
-                const unsigned cbase = (unsigned)(co >> 2) * (unsigned)a.V * 4u + (unsigned)(co & 3);
-                const unsigned fwrap = (unsigned)a.out_fs - (unsigned)a.V * 4u;      // floats from (f, V) to (f + 1, 0) of the same chunk
+            if (POOL == 0 && BLK) {
+                // chunk-blocked output ([C/4][voxel][4]): the accumulator layout has a lane own ONE channel of 16 rows — stored
+                // as it is, every instruction would write 16 separate 16-byte pieces.  The 32 x 32 tile goes through a per-wave
+                // LDS tile instead (wave-synchronous: no barrier) and comes back with a lane owning one ROW and 16 channels:
+                // four 16-byte stores whose 32 lanes cover 32 consecutive voxels of a chunk, 512 contiguous bytes
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const unsigned dr = (unsigned)((r & 3) + 8 * (r >> 2));
-                    const unsigned v = v0 + dr;
-                    const unsigned e = f0 * (unsigned)a.out_fs + v * 4u + (v >= (unsigned)a.V ? fwrap : 0u) + cbase;
-                    const unsigned off = (cok && row0 + dr < a.nrows && !(a.dbg & 2)) ? e * 4u : OOB;
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x[r]), rout, off, 0, 0);
+                for (int r = 0; r < 16; ++r) tsc[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + j] = x[r];
+                const unsigned row = tile * 32 + (unsigned)j;
+                const unsigned f = row / (unsigned)a.V, v = row - f * (unsigned)a.V;
+                const unsigned ebase = f * (unsigned)a.out_fs + v * 4u;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const u32x4 y = *reinterpret_cast<const u32x4*>(tsc + j * 36 + 16 * h + 4 * k);
+                    const unsigned chunk = (unsigned)(nt * 8 + h * 4 + k);
+                    const unsigned off = (row < a.nrows && (int)(chunk * 4) < a.Cout && !(a.dbg & 2)) ? (ebase + chunk * (unsigned)a.V * 4u) * 4u : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(y, rout, off, 0, 0);
                 }
-            } else if (POOL == 0 && a.out_dense && tile * 32 + 32 <= a.nrows) {
+            } else if (POOL == 0 && !BLK && a.out_dense && tile * 32 + 32 <= a.nrows) {
                 // whole tile in range, rows at a constant byte stride: ONE vector offset per (tile, n-tile) and the row
                 // displacement as the instruction's scalar offset — no per-store address arithmetic (it was ~8 VALU
                 // instructions x 32 stores per tile, a third of this kernel's VALU issue)
@@ -425,6 +431,11 @@ const PwKernel kPw2[3][3][3] = {
 // 12 slots for 72..96 input channels (most of DenseCPD's bottleneck layers): two register sets of 12 float4 leave room for
 // three workgroups per CU where 16 slots allow two
 const PwKernel kPw2_12[2][3] = {PW2_ROW(12, 1), PW2_ROW(12, 2)};
+// chunk-blocked output (no pooling): [kmax index][nt index], and the 12-slot pair
+const PwKernel kPw2Blk[3][3] = {{k_conv_pw2<4, 1, 0, 1>, k_conv_pw2<4, 2, 0, 1>, k_conv_pw2<4, 4, 0, 1>},
+                                {k_conv_pw2<8, 1, 0, 1>, k_conv_pw2<8, 2, 0, 1>, k_conv_pw2<8, 4, 0, 1>},
+                                {k_conv_pw2<16, 1, 0, 1>, k_conv_pw2<16, 2, 0, 1>, nullptr}};
+const PwKernel kPw2Blk_12[2] = {k_conv_pw2<12, 1, 0, 1>, k_conv_pw2<12, 2, 0, 1>};
 const int kPwKmax[3] = {4, 8, 16};
 const int kPwNt[3] = {1, 2, 4};
 constexpr size_t kPwLdsLimit = 64 * 1024;
@@ -522,8 +533,9 @@ int launch_conv_pw(hipStream_t s, int64_t n, const ConvMfmaPlan& p, TView in, TV
         out_span < 0xfffffff0LL) {
         a.in_bytes = (unsigned)in_span; a.out_bytes = (unsigned)out_span;
         k = (a.K8 > 8 && a.K8 <= 12 && nti <= 1) ? kPw2_12[nti][p.pool] : kPw2[kmi][nti][p.pool];
+        if (out.blk) k = (a.K8 > 8 && a.K8 <= 12 && nti <= 1) ? kPw2Blk_12[nti] : kPw2Blk[kmi][nti];
     }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), p.lds_bytes, s, a);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), p.lds_bytes + (out.blk ? 4 * 32 * 36 * 4 + 16 : 0), s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) TH_FAIL(TH_EHIP, "conv_pw launch failed: %s (%s)", hipGetErrorString(e), p.label.c_str());
     return TH_OK;
