@@ -162,6 +162,8 @@ struct ConvWfPlan {
 };
 bool conv_wf_plan(const TView& in, const TView& out_conv, const ConvGeom& g, int Cin, int Cout, int pool, ConvWfPlan* plan);
 bool conv_wf_view_ok(const TView& in);      // 16-byte aligned channel slices
+int conv_wf_pre_kind(const PreOp& pre);
+std::string conv_wf_label(const ConvWfPlan& p, const PreOp& pre);    // the plan's label with the kernel's full template argument list
 void conv_wf_pack_weights(const ConvWfPlan& p, const float* w_keras, float* dst);
 int launch_conv_wf(hipStream_t s, int64_t n, const ConvWfPlan& p, TView in, TView out, const float* wpk, const float* bias, PreOp pre,
                    PostOps post);

@@ -471,9 +471,9 @@ bool conv_pw_plan(const TView& in, const TView& oc, const ConvGeom& g, int Cin, 
     // the pipelined kernel when the layer allows it (launch_conv_pw falls back to k_conv_pw for unaligned or > 4 GiB views)
     const bool pipe = !getenv("TH_PW_NOPIPE") && kPw2[kmi][nti][pool] && Cin % 8 == 0 && K8 <= kPwKmax[kmi];
     const int kmax = (pipe && K8 > 8 && K8 <= 12 && nti <= 1) ? 12 : kPwKmax[kmi];
-    snprintf(buf, sizeof buf, "conv_pw<k%d,nt%d,pool%d> K8=%d lds%zuK (streaming 1x1x1, weights in LDS%s) [k_conv_pw%s<%d,%d,%d>]",
+    snprintf(buf, sizeof buf, "conv_pw<k%d,nt%d,pool%d> K8=%d lds%zuK (streaming 1x1x1, weights in LDS%s) [k_conv_pw%s<%d,%d,%d%s>]",
              kmax, NT, pool, K8, lds / 1024, pipe ? ", next tile prefetched, buffer addressing" : "", pipe ? "2" : "",
-             kmax, NT, pool);
+             kmax, NT, pool, pipe ? ",0" : "");
     p->label = buf;
     (void)in;
     return true;

@@ -522,6 +522,16 @@ void conv_wf_pack_weights(const ConvWfPlan& p, const float* w, float* dst) {
 
 bool conv_wf_view_ok(const TView& in) { return in.cs % 4 == 0 && in.coff % 4 == 0; }
 
+// which prologue instantiation a layer runs on: 0 none, 1 BN-affine -> ReLU from 16-byte aligned vectors, 2 generic
+int conv_wf_pre_kind(const PreOp& pre) {
+    const bool relu_affine = pre.scale && pre.act == ACT_RELU && ((uintptr_t)pre.scale % 16) == 0 && ((uintptr_t)pre.shift % 16) == 0;
+    return (!pre.scale && pre.act == ACT_LINEAR) ? 0 : relu_affine ? 1 : 2;
+}
+std::string conv_wf_label(const ConvWfPlan& p, const PreOp& pre) {
+    const size_t k = p.label.rfind(">]");
+    return k == std::string::npos ? p.label : p.label.substr(0, k) + "," + std::to_string(conv_wf_pre_kind(pre)) + ",0>]";
+}
+
 int launch_conv_wf(hipStream_t s, int64_t n, const ConvWfPlan& p, TView in, TView out, const float* wpk, const float* bias, PreOp pre,
                    PostOps post) {
     if (n <= 0) return TH_OK;
@@ -548,8 +558,7 @@ int launch_conv_wf(hipStream_t s, int64_t n, const ConvWfPlan& p, TView in, TVie
     const int64_t trips = (nslots + resident - 1) / resident;
     int64_t grid = (nslots + trips - 1) / trips;
     grid = (grid + 7) / 8 * 8;
-    const bool relu_affine = pre.scale && pre.act == ACT_RELU && p.Cin % 4 == 0 && ((uintptr_t)pre.scale % 16) == 0 && ((uintptr_t)pre.shift % 16) == 0;
-    const int pre_kind = (!pre.scale && pre.act == ACT_LINEAR) ? 0 : relu_affine ? 1 : 2;
+    const int pre_kind = conv_wf_pre_kind(pre);
     WfKernel k = kWfGeo[p.geo].k[p.pool][pre_kind];
     {   // timing experiments only (tools/bench_layer.py): knock-out instantiations of the plain 10^3 kernel
         static const int dbg = getenv("TH_WF_DBG") ? atoi(getenv("TH_WF_DBG")) : 0;

@@ -172,6 +172,12 @@ struct Step {
     bool is_final_softmax = false;
 };
 
+// a remark in a step label, in front of the trailing " [kernel]" that tools/ parse
+inline std::string label_note(const std::string& label, const char* note) {
+    const size_t k = label.rfind(" [");
+    return k == std::string::npos ? label + note : label.substr(0, k) + note + label.substr(k);
+}
+
 inline void keras_same_pad(int n, int k, int s, int d, int* before) {
     const int ke = (k - 1) * d + 1;
     const int out = (n + s - 1) / s;
@@ -734,7 +740,7 @@ int plan(th_model* m) {
                         st.direct_flops = st.flops;
                         st.flops = fp.own_flops;
                         st.exec_flops = fp.exec_flops;
-                        st.label = n.name + ": " + fp.label + (sn.blk ? " (input chunk-blocked)" : "");
+                        st.label = n.name + ": " + (sn.blk ? label_note(conv_wf_label(fp, pre), " (input chunk-blocked)") : conv_wf_label(fp, pre));
                         st.run = [=](hipStream_t s, int64_t cnt) {
                             return launch_conv_wf(s, cnt, fp, M->view(src), M->view(dst), dw, dbias, pre, po);
                         };
@@ -745,7 +751,7 @@ int plan(th_model* m) {
                         float* dw;
                         if ((rc = upload(M, packed.data(), packed.size(), &dw))) return rc;
                         st.exec_flops = mp.exec_flops;
-                        st.label = n.name + ": " + conv_first_label(mp, Cin, po) + (N[dst].blk ? " (output chunk-blocked)" : "");
+                        st.label = n.name + ": " + (N[dst].blk ? label_note(conv_first_label(mp, Cin, po), " (output chunk-blocked)") : conv_first_label(mp, Cin, po));
                         const int iD = sn.D, iH = sn.H, iW = sn.W;
                         st.run = [=](hipStream_t s, int64_t cnt) {
                             return launch_conv_first(s, cnt, mp, M->cur_in, M->cur_dtype, iD, iH, iW, Cin, M->view(dst), g, Cout,
@@ -758,7 +764,12 @@ int plan(th_model* m) {
                         float* dw;
                         if ((rc = upload(M, packed.data(), packed.size(), &dw))) return rc;
                         st.exec_flops = mp.exec_flops;
-                        st.label = n.name + ": " + mp.label + (N[dst].blk ? " (output chunk-blocked)" : "");
+                        st.label = n.name + ": " + mp.label;
+                        if (N[dst].blk) {                                   // the chunk-blocked instantiation k_conv_pw2<K, N, 0, 1>
+                            const size_t k = st.label.rfind(",0>]");
+                            if (k != std::string::npos) st.label.replace(k, 4, ",1>]");
+                            st.label = label_note(st.label, " (output chunk-blocked)");
+                        }
                         st.run = [=](hipStream_t s, int64_t cnt) {
                             return launch_conv_pw(s, cnt, mp, M->view(src), M->view(dst), Cin, Cout, dw, dbias, pre, po);
                         };
