@@ -64,3 +64,10 @@ def test_short_kernel_names():
     lab = "conv3d_4: conv_mfma<w4,4x2,nt4,ci16,stream,pool0> FB2 ZB5/5 rows128 lds58K [k_conv_mfma<4,4,2,4,16,2,0,7>]"
     assert bench_line.short_kernel(lab) == "conv3d_4 k_conv_mfma<4,4,2,4,16,2,0,7>"
     assert bench_line.short_kernel("dense: k_dense") == "dense k_dense"
+
+
+def test_short_kernel_names_with_a_remark_in_front_of_the_bracket():
+    """runtime.hip puts remarks such as '(input chunk-blocked)' in FRONT of the trailing [kernel] tag that the tools parse."""
+    lab = ("conv3d_1: conv_wf<F(2,3)^2 in-plane fused in LDS, z direct; pool1> 16c x 4, K32, lds159K (16x16x4 MFMA) "
+           "(input chunk-blocked) [k_conv_wf<10,10,10,1,0,0>]")
+    assert bench_line.short_kernel(lab) == "conv3d_1 k_conv_wf<10,10,10,1,0,0>"
