@@ -114,6 +114,8 @@ struct ConvMfmaPlan {
     size_t tab_off = 0;           // byte offset of the row tables inside the LDS allocation
     size_t wpk_floats = 0;        // size of the prepacked weight image
     double exec_flops = 0;        // MFMA FLOPs actually issued per frame
+    int first_wino = 0;           // first-layer kernel only: F(2,3) along x (k_conv_first_w), rows are x pairs
+    double own_flops = 0;         // first_wino: the algorithm's own multiply-adds x 2 per frame (4 points per x pair and (dz, dy) tap)
     int geo = 0;                  // > 0: the kernel instantiation with Hp = Wp = geo at compile time (tap offsets as immediates)
     std::string label;
 };
@@ -173,6 +175,7 @@ std::string conv_first_label(const ConvMfmaPlan& p, int Cin, const PostOps& post
 bool conv_first_plan(int Din, int Hin, int Win, int Cin, const TView& out_conv, const ConvGeom& g, int Cout, int pool,
                      ConvMfmaPlan* plan);
 void conv_first_pack_weights(int Cin, int Cout, const float* w_keras, float* dst);
+void conv_first_w_pack_weights(int Cin, int Cout, const float* w_keras, float* dst);    // plans with first_wino set
 int launch_conv_first(hipStream_t s, int64_t n, const ConvMfmaPlan& p, const void* frames, int dtype, int Din, int Hin,
                       int Win, int Cin, TView out, ConvGeom g, int Cout, const float* wpk, const float* bias, PostOps post);
 

@@ -265,6 +265,230 @@ __global__ void __launch_bounds__(WAVES * 64, 3) k_conv_first(const ConvFirstArg
     }
 }
 
+
+// ---- F(2,3) along x ---------------------------------------------------------------------------------------------------------
+// The same brick, the same raw LDS image, the same register-resident weights — but a GEMM row is a PAIR of output voxels
+// (2 tx, 2 tx + 1) and each (dz, dy) tap contributes 4 products per channel instead of 6 (3 x taps x 2 outputs): four transform
+// points V0 = d0 - d2, V1 = d1 + d2, V2 = d2 - d1, V3 = d1 - d3 of the four input voxels d0..d3 = x 2 tx - 1 .. 2 tx + 2, formed
+// in registers right after the LDS reads (one VALU op per MFMA), multiplied with U_p = G W (the halves folded into the weights on
+// the host in double precision) into FOUR independent accumulators; out(2 tx) = M0 + M1 + M2, out(2 tx + 1) = M1 - M2 - M3.
+// 1.5x fewer MFMAs, exact data transform (0 / +-1).  With a pool the pair is the window's x extent and the rows are grouped four
+// (dz, dy) mates at a time, so the whole 2^3 window sits in one lane's registers (no cross-lane step at all).  The four
+// accumulators also end the single-accumulator chain that made k_conv_first need three waves per SIMD; this one runs two
+// workgroups per CU on 4-plane bricks (25 row tiles, 70 KB of image).
+template <int NST, int PMODE, int GEO = 0>
+__global__ void __launch_bounds__(256, 2) k_conv_first_w(const ConvFirstArgs a) {
+    constexpr int POOL = PMODE == 3 ? 1 : PMODE;
+    constexpr bool POOL_FIRST = PMODE == 3;
+    constexpr int NTHREADS = 256, WAVES = 4;
+    extern __shared__ __attribute__((aligned(16))) float4 smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+
+    const int zb = blockIdx.x % a.nzb;
+    const int64_t f = blockIdx.x / a.nzb;
+    const int z0 = zb * a.ZB;
+    const int gHp = GEO ? GEO : a.Hp, gWp = GEO ? GEO : a.Wp, gHc = GEO ? GEO - 2 : a.Hc, gWc = GEO ? GEO - 2 : a.Wc;
+    const int TX = gWc >> 1;
+    const int nvox = a.Zp * gHp * gWp;
+    constexpr int REC = 2 * NST;
+    float* A = reinterpret_cast<float*>(smem);
+    int* rowvox = (int*)(reinterpret_cast<char*>(smem) + a.tab_off);
+    int* rowout = rowvox + a.rows;
+
+
+    // ---- row tables: rowvox = staged voxel of d0 at tap (0, 0); rowout = the pair's first output voxel / the pooled voxel
+    {
+        const int ZBv = min(a.ZB, a.Dc - z0);
+        for (int r = tid; r < a.rows; r += NTHREADS) {
+            int vox = 0, oo = -1;
+            if (POOL == 0) {
+                const int hw = gHc * TX;
+                if (r < ZBv * hw) {
+                    const int zl = r / hw, rem = r - zl * hw, y = rem / TX, tx = rem - y * TX;
+                    vox = (zl * gHp + y) * gWp + 2 * tx;
+                    oo = (((z0 + zl) * a.Ho + y) * a.Wo + 2 * tx) * a.out_cs;
+                }
+                rowout[r] = oo;
+            } else {
+                const int pq = r >> 2, mate = r & 3;
+                const int PH = gHc >> 1;
+                if (pq < (ZBv >> 1) * PH * TX) {
+                    const int pzz = pq / (PH * TX), rem = pq - pzz * (PH * TX), pyy = rem / TX, pxx = rem - pyy * TX;
+                    const int zl = 2 * pzz + (mate >> 1), y = 2 * pyy + (mate & 1);
+                    vox = (zl * gHp + y) * gWp + 2 * pxx;
+                    oo = ((((z0 >> 1) + pzz) * a.Ho + pyy) * a.Wo + pxx) * a.out_cs;
+                }
+                if (mate == 0) rowout[r >> 2] = oo;
+            }
+            rowvox[r] = vox;
+        }
+    }
+
+    // ---- stage the haloed input brick straight from the caller's frames (as k_conv_first) ----------------------------
+    {
+        const int64_t fbase = f * (int64_t)a.Din * a.Hin * a.Win * a.Cin;
+        const bool fast6 = (a.vec8 && NST == 3);
+        constexpr int U = 12;  // voxels in flight per thread: a 6-plane brick of 22 x 22 voxels is 11.3 per thread — one batch of loads
+        for (int vb = tid; vb < nvox; vb += NTHREADS * U) {
+            float e[U][8];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) e[u][c] = 0.f;
+                const int v = vb + u * NTHREADS;
+                const int xl = v % gWp; int t = v / gWp;
+                const int yl = t % gHp; const int zl = t / gHp;
+                const int zi = z0 + zl - a.pz, yi = yl - a.py, xi = xl - a.px;
+                if (v < nvox && zi >= 0 && zi < a.Din && yi >= 0 && yi < a.Hin && xi >= 0 && xi < a.Win) {
+                    const int64_t base = fbase + ((int64_t)(zi * a.Hin + yi) * a.Win + xi) * a.Cin;
+                    if (fast6) {
+                        const float2* p2 = reinterpret_cast<const float2*>((const float*)a.in + base);
+                        const float2 u0 = p2[0], u1 = p2[1], u2 = p2[2];
+                        e[u][0] = u0.x; e[u][1] = u0.y; e[u][2] = u1.x; e[u][3] = u1.y; e[u][4] = u2.x; e[u][5] = u2.y;
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 2 * NST; ++c)
+                            if (c < a.Cin) e[u][c] = load_elem(a.in, a.dtype, base + c);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int v = vb + u * NTHREADS;
+                if (v >= nvox) continue;
+                float* rec = A + (size_t)v * REC;
+                if (NST == 4) {
+                    *reinterpret_cast<float4*>(rec) = make_float4(e[u][0], e[u][2], e[u][4], e[u][6]);
+                    *reinterpret_cast<float4*>(rec + 4) = make_float4(e[u][1], e[u][3], e[u][5], e[u][7]);
+                } else if (NST == 3) {
+                    *reinterpret_cast<float2*>(rec) = make_float2(e[u][0], e[u][2]);
+                    *reinterpret_cast<float2*>(rec + 2) = make_float2(e[u][1], e[u][3]);
+                    *reinterpret_cast<float2*>(rec + 4) = make_float2(e[u][4], e[u][5]);
+                } else if (NST == 2) {
+                    *reinterpret_cast<float4*>(rec) = make_float4(e[u][0], e[u][2], e[u][1], e[u][3]);
+                } else {
+                    *reinterpret_cast<float2*>(rec) = make_float2(e[u][0], e[u][1]);
+                }
+            }
+        }
+    }
+    // ---- weights -> registers: U_p of tap (dz, dy), the k-steps in x / y / z / w (after the staging loop: its 12 voxels in
+    // flight per thread need the registers, and the weights come from L2)
+    float4 breg[36];
+    {
+        const float4* w4 = reinterpret_cast<const float4*>(a.wpk);
+#pragma unroll
+        for (int t = 0; t < 36; ++t) breg[t] = w4[(t * 2 + h) * 32 + j];
+    }
+    __syncthreads();
+
+    const int rounds = (a.n_mtiles + WAVES - 1) / WAVES;
+    float* outb = a.out + f * a.out_fs + a.out_coff;
+    const int co = j;
+    const int cofs = a.out_blk_stride ? (co >> 2) * a.out_blk_stride + (co & 3) : co;
+    const bool cok = co < a.Cout;
+    const int cc = cok ? co : 0;
+    const float bv = a.bias ? a.bias[cc] : 0.f;
+
+    for (int rd = 0; rd < rounds; ++rd) {
+        const int mt = rd * WAVES + wave;
+        if (mt >= a.n_mtiles) break;  // wave-uniform; no barriers below
+        f32x16 acc[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[p][i] = 0.f;
+        const float* arow = A + (size_t)rowvox[mt * 32 + j] * REC;
+        // the four input voxels of tap t9 = 3 dz + dy, this lane's k-slot of every step
+        auto fetch = [&](int t9, float (&d)[4][4]) {
+            const float* rec0 = arow + (((t9 / 3) * gHp + (t9 % 3)) * gWp) * REC;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float* rec = rec0 + i * REC;
+                if (NST == 4) {
+                    const float4 q = *reinterpret_cast<const float4*>(rec + 4 * h);
+                    d[i][0] = q.x; d[i][1] = q.y; d[i][2] = q.z; d[i][3] = q.w;
+                } else if (NST == 3) {
+                    const float2 q = *reinterpret_cast<const float2*>(rec + 2 * h);
+                    d[i][0] = q.x; d[i][1] = q.y; d[i][2] = rec[4 + h];
+                } else if (NST == 2) {
+                    const float2 q = *reinterpret_cast<const float2*>(rec + 2 * h);
+                    d[i][0] = q.x; d[i][1] = q.y;
+                } else {
+                    d[i][0] = rec[h];
+                }
+            }
+        };
+        float d[2][4][4];
+        fetch(0, d[0]);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            if (t + 1 < 9) fetch(t + 1, d[(t + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < NST; ++s) {
+                const float d0 = d[t & 1][0][s], d1 = d[t & 1][1][s], d2 = d[t & 1][2][s], d3 = d[t & 1][3][s];
+                const float w0 = s == 0 ? breg[t].x : s == 1 ? breg[t].y : s == 2 ? breg[t].z : breg[t].w;
+                const float w1 = s == 0 ? breg[9 + t].x : s == 1 ? breg[9 + t].y : s == 2 ? breg[9 + t].z : breg[9 + t].w;
+                const float w2 = s == 0 ? breg[18 + t].x : s == 1 ? breg[18 + t].y : s == 2 ? breg[18 + t].z : breg[18 + t].w;
+                const float w3 = s == 0 ? breg[27 + t].x : s == 1 ? breg[27 + t].y : s == 2 ? breg[27 + t].z : breg[27 + t].w;
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(d0 - d2, w0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(d1 + d2, w1, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(d2 - d1, w2, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(d1 - d3, w3, acc[3], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- epilogue in registers: the pair's two outputs, then as k_conv_first --------------------------------------
+        float x0[16], x1[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            x0[i] = (acc[0][i] + acc[1][i]) + acc[2][i];
+            x1[i] = (acc[1][i] - acc[2][i]) - acc[3][i];
+        }
+        if (POOL_FIRST) {
+            // rows 4 q .. 4 q + 3 of this lane are the (dz, dy) mates of pooled voxel 2 q + h of the tile; the pair is its x extent
+            float m4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                m4[q] = fmaxf(fmaxf(fmaxf(x0[4 * q], x0[4 * q + 1]), fmaxf(x0[4 * q + 2], x0[4 * q + 3])),
+                              fmaxf(fmaxf(x1[4 * q], x1[4 * q + 1]), fmaxf(x1[4 * q + 2], x1[4 * q + 3]))) + bv;
+            th_post2(m4[0], m4[1], cc, a.post);
+            th_post2(m4[2], m4[3], cc, a.post);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int oo = cok ? rowout[mt * 8 + 2 * q + h] : -1;
+                if (oo >= 0) outb[oo + cofs] = m4[q];
+            }
+            continue;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { x0[i] += bv; x1[i] += bv; }
+        th_post16(x0, cc, a.post);
+        th_post16(x1, cc, a.post);
+        if (POOL == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int oo = cok ? rowout[mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h] : -1;
+                if (oo >= 0) { outb[oo + cofs] = x0[i]; outb[oo + a.out_cs + cofs] = x1[i]; }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float m;
+                if (POOL == 1) m = fmaxf(fmaxf(fmaxf(x0[4 * q], x0[4 * q + 1]), fmaxf(x0[4 * q + 2], x0[4 * q + 3])),
+                                         fmaxf(fmaxf(x1[4 * q], x1[4 * q + 1]), fmaxf(x1[4 * q + 2], x1[4 * q + 3])));
+                else m = (((x0[4 * q] + x0[4 * q + 1]) + (x0[4 * q + 2] + x0[4 * q + 3])) + ((x1[4 * q] + x1[4 * q + 1]) + (x1[4 * q + 2] + x1[4 * q + 3]))) * 0.125f;
+                const int oo = cok ? rowout[mt * 8 + 2 * q + h] : -1;
+                if (oo >= 0) outb[oo + cofs] = m;
+            }
+        }
+    }
+}
+
 typedef void (*FirstKernel)(const ConvFirstArgs);
 constexpr int kWaves = 4;
 #define ROW(NST) { k_conv_first<kWaves, NST, 0>, k_conv_first<kWaves, NST, 1>, k_conv_first<kWaves, NST, 2>, k_conv_first<kWaves, NST, 3> }
@@ -275,6 +499,13 @@ const FirstGeo kFirstGeo[] = {
     {3, 3, 22, k_conv_first<kWaves, 3, 3, 22>},
     {3, 1, 22, k_conv_first<kWaves, 3, 1, 22>},
     {3, 0, 23, k_conv_first<kWaves, 3, 0, 23>},
+};
+
+#define ROWW(NST) { k_conv_first_w<NST, 0>, k_conv_first_w<NST, 1>, k_conv_first_w<NST, 2>, k_conv_first_w<NST, 3> }
+const FirstKernel kFirstWKernels[4][4] = {ROWW(1), ROWW(2), ROWW(3), ROWW(4)};
+const FirstGeo kFirstWGeo[] = {
+    {3, 3, 22, k_conv_first_w<3, 3, 22>},
+    {3, 1, 22, k_conv_first_w<3, 1, 22>},
 };
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -294,7 +525,12 @@ bool conv_first_plan(int Din, int Hin, int Win, int Cin, const TView& oc, const 
     p->Wc = pool ? (oc.W / 2) * 2 : oc.W;
     p->Hp = p->Hc + 2;
     p->Wp = p->Wc + 2;
+    // F(2,3) along x (k_conv_first_w): 'same' padding, an even number of computed columns; rows are x pairs
+    static const bool no_wino = getenv("TH_FIRST_WINO") && atoi(getenv("TH_FIRST_WINO")) == 0;   // read once: A/B runs set it per process
+    const bool wino = !no_wino && g.pz == 1 && g.py == 1 && g.px == 1 && p->Wc % 2 == 0 && p->Wc >= 2;
+    p->first_wino = wino ? 1 : 0;
     auto rows_for = [&](int zb) {
+        if (wino) return round_up(pool ? 4 * ((zb / 2) * (p->Hc / 2) * (p->Wc / 2)) : zb * p->Hc * (p->Wc / 2), 32);
         return round_up(pool ? 8 * ((zb / 2) * (p->Hc / 2) * (p->Wc / 2)) : zb * p->Hc * p->Wc, 32);
     };
     const int nst = (Cin + 1) / 2;
@@ -302,12 +538,12 @@ bool conv_first_plan(int Din, int Hin, int Win, int Cin, const TView& oc, const 
     auto img_for = [&](int zb) { return ((size_t)(zb + 2) * p->Hp * p->Wp * rec_bytes + 15) / 16 * 16; };
     auto lds_for = [&](int zb) {
         const int rows = rows_for(zb);
-        return img_for(zb) + (size_t)rows * 4 + (size_t)(pool ? rows / 8 : rows) * 4;
+        return img_for(zb) + (size_t)rows * 4 + (size_t)(pool ? rows / (wino ? 4 : 8) : rows) * 4;
     };
     const int step = pool ? 2 : 1;
     // prefer bricks that leave room for two workgroups per CU (<= 80 KiB); fall back to one per CU
     int ZB = 0;
-    for (size_t limit : {(size_t)160 * 1024 / 3, (size_t)80 * 1024, (size_t)160 * 1024}) {
+    for (size_t limit : {wino ? (size_t)80 * 1024 : (size_t)160 * 1024 / 3, (size_t)80 * 1024, (size_t)160 * 1024}) {
         for (int zb = p->Dc; zb >= step; zb -= step)
             if (lds_for(zb) <= limit) { ZB = zb; break; }
         if (ZB) break;
@@ -325,10 +561,15 @@ bool conv_first_plan(int Din, int Hin, int Win, int Cin, const TView& oc, const 
     p->rows_pf = rows_for(ZB);
     p->lds_bytes = lds_for(ZB);
     p->tab_off = img_for(ZB);
-    p->wpk_floats = (size_t)kTaps * 2 * 32 * 4;
-    p->exec_flops = 2.0 * (double)p->nzb * p->rows_pf * 32.0 * (2.0 * nst) * kTaps;
+    p->wpk_floats = (size_t)(wino ? 36 : kTaps) * 2 * 32 * 4;
+    p->exec_flops = 2.0 * (double)p->nzb * p->rows_pf * 32.0 * (2.0 * nst) * (wino ? 36 : kTaps);
+    p->own_flops = wino ? 2.0 * (double)p->Dc * p->Hc * (p->Wc / 2) * 36.0 * Cin * Cout : 0.0;
     if (oc.fs > 0x7fffffffLL) return false;
     char buf[224];
+    if (wino)
+        snprintf(buf, sizeof buf, "conv_first_w<F(2,3) along x; nst%d,pool%d> ZB%d/%d rows%d lds%zuK (weights in VGPRs, direct input) [k_conv_first_w<%d,%d>]",
+                 nst, pool, ZB, p->Dc, p->rows_pf, p->lds_bytes / 1024, nst, pool);
+    else
     snprintf(buf, sizeof buf, "conv_first<w%d,nst%d,pool%d> ZB%d/%d rows%d lds%zuK (weights in VGPRs, direct input) [k_conv_first<%d,%d,%d>]",
              kWaves, nst, pool, ZB, p->Dc, p->rows_pf, p->lds_bytes / 1024, kWaves, nst, pool);
     p->label = buf;
@@ -344,6 +585,20 @@ void conv_first_pack_weights(int Cin, int Cout, const float* w, float* dst) {
                 dst[(((size_t)tap * 2 + (c & 1)) * 32 + co) * 4 + (c >> 1)] = w[((size_t)tap * Cin + c) * Cout + co];
 }
 
+// Keras [3,3,3,Cin,Cout] -> U_p = sum_k G[p][k] W[dz][dy][k] (double), [p][3 dz + dy][h][co(32)][t(4)] with channel c = 2t + h
+void conv_first_w_pack_weights(int Cin, int Cout, const float* w, float* dst) {
+    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    std::memset(dst, 0, (size_t)36 * 2 * 32 * 4 * sizeof(float));
+    for (int t9 = 0; t9 < 9; ++t9)
+        for (int c = 0; c < Cin; ++c)
+            for (int co = 0; co < Cout; ++co)
+                for (int p = 0; p < 4; ++p) {
+                    double u = 0;
+                    for (int k = 0; k < 3; ++k) u += G[p][k] * (double)w[((size_t)(t9 * 3 + k) * Cin + c) * Cout + co];
+                    dst[((((size_t)p * 9 + t9) * 2 + (c & 1)) * 32 + co) * 4 + (c >> 1)] = (float)u;
+                }
+}
+
 namespace {
 // the instantiation a plan runs with a given epilogue chain: pool-first (PMODE 3) when the chain is monotone, the
 // compile-time geometry when there is one for this frame size
@@ -351,10 +606,16 @@ FirstKernel pick_first_kernel(const ConvMfmaPlan& p, int nst, const PostOps& pos
     const bool no_pool_first = getenv("TH_NO_POOL_FIRST") != nullptr;   // A/B comparisons and tests
     *pmode = (p.pool == 1 && post.monotone && !no_pool_first) ? 3 : p.pool;
     *geo = 0;
-    FirstKernel k = kFirstKernels[nst - 1][*pmode];
-    if (p.Hp == p.Wp && p.Hc == p.Hp - 2 && p.Wc == p.Wp - 2 && !getenv("TH_CONV_NOGEO"))
-        for (const FirstGeo& ge : kFirstGeo)
-            if (ge.nst == nst && ge.pmode == *pmode && ge.geo == p.Hp) { k = ge.k; *geo = ge.geo; }
+    FirstKernel k = p.first_wino ? kFirstWKernels[nst - 1][*pmode] : kFirstKernels[nst - 1][*pmode];
+    if (p.Hp == p.Wp && p.Hc == p.Hp - 2 && p.Wc == p.Wp - 2 && !getenv("TH_CONV_NOGEO")) {
+        if (p.first_wino) {
+            for (const FirstGeo& ge : kFirstWGeo)
+                if (ge.nst == nst && ge.pmode == *pmode && ge.geo == p.Hp) { k = ge.k; *geo = ge.geo; }
+        } else {
+            for (const FirstGeo& ge : kFirstGeo)
+                if (ge.nst == nst && ge.pmode == *pmode && ge.geo == p.Hp) { k = ge.k; *geo = ge.geo; }
+        }
+    }
     return k;
 }
 }  // namespace
@@ -367,7 +628,8 @@ std::string conv_first_label(const ConvMfmaPlan& p, int Cin, const PostOps& post
     const size_t b = l.rfind('[');
     if (b != std::string::npos) {
         char buf[64];
-        snprintf(buf, sizeof buf, "[k_conv_first<%d,%d,%d,%d>]", kWaves, (Cin + 1) / 2, pmode, geo);
+        if (p.first_wino) snprintf(buf, sizeof buf, "[k_conv_first_w<%d,%d,%d>]", (Cin + 1) / 2, pmode, geo);
+        else snprintf(buf, sizeof buf, "[k_conv_first<%d,%d,%d,%d>]", kWaves, (Cin + 1) / 2, pmode, geo);
         l = l.substr(0, b) + buf;
     }
     return l;

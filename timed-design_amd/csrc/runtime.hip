@@ -747,6 +747,11 @@ int plan(th_model* m) {
                     } else if (mplans.count(i) && mplans[i].cfg == 100) {
                         const ConvMfmaPlan mp = mplans[i];
                         std::vector<float> packed(mp.wpk_floats);
+                        if (mp.first_wino) {
+                            conv_first_w_pack_weights(Cin, Cout, hw, packed.data());
+                            st.direct_flops = st.flops;
+                            st.flops = mp.own_flops;
+                        } else
                         conv_first_pack_weights(Cin, Cout, hw, packed.data());
                         float* dw;
                         if ((rc = upload(M, packed.data(), packed.size(), &dw))) return rc;
