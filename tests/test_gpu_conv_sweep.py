@@ -293,3 +293,43 @@ def test_heterogeneous_cout_blocks(gpu, shape, cin, cout, pool, post, n, kernels
     assert not any(" + " in s["label"] for s in m.steps())
     assert np.array_equal(m.predict(frames), with_tail)
     m.close()
+
+
+@pytest.mark.parametrize("shape,cin,cout,pool,post,n", [
+    ((21, 21, 21), 6, 32, "max", "elu_bn", 3),       # TIMED block 1: pool-first epilogue, compile-time geometry
+    ((21, 21, 21), 6, 32, "max", "tanh", 2),         # non-monotone chain: the epilogue runs on all 2 x 16 values before the max
+    ((12, 10, 8), 5, 24, "avg", "relu", 5),          # run-time geometry, average pool, 5 channels
+    ((9, 8, 6), 8, 32, None, "leaky", 4),            # no pool: both outputs of a pair stored, 4 k-steps
+    ((7, 6, 10), 3, 9, "max", "none", 7),            # 2 k-steps, odd depth (last plane dropped by the pool), Cout < 32
+    ((6, 6, 4), 1, 16, None, "elu_bn", 3),           # one input channel
+])
+def test_first_layer_winograd_along_x(gpu, monkeypatch, shape, cin, cout, pool, post, n):
+    """k_conv_first_w (F(2,3) along x: rows are x pairs, four transform points per (dz, dy) tap formed in registers) against the
+    oracle and against the direct first-layer kernel (TH_FIRST_WINO=0), ragged chunks included."""
+    def build(b, x):
+        x = b.conv3d(x, cout, 3, padding="same")
+        if post == "elu_bn":
+            x = b.batchnorm(b.elu(x))
+        elif post == "relu":
+            x = b.relu(x)
+        elif post == "leaky":
+            x = b.leaky_relu(x, 0.2)
+        elif post == "tanh":
+            x = b.activation(x, "tanh")
+        if pool == "max":
+            x = b.maxpool(x, 2)
+        elif pool == "avg":
+            x = b.avgpool(x, 2)
+        return x
+
+    cfg, weights = _net(shape, cin, build, seed=cin * 7 + cout)
+    frames = _frames(n, shape, cin, seed=n + 3)
+    labels = _check(cfg, weights, frames)
+    assert any("k_conv_first_w" in l for l in labels), labels
+    _check(cfg, weights, frames, chunk=2)
+    got = engine.HipFrameModel.from_keras(cfg, weights).predict(frames)
+    monkeypatch.setenv("TH_FIRST_WINO", "0")
+    m = engine.HipFrameModel.from_keras(cfg, weights)
+    ref = m.predict(frames)
+    assert any("k_conv_first<" in s["label"] for s in m.steps()), [s["label"] for s in m.steps()]
+    np.testing.assert_allclose(got, ref, rtol=0, atol=4e-6 * max(1.0, float(np.abs(ref).max())))

@@ -403,22 +403,26 @@ __global__ void __launch_bounds__(256, 2) k_conv_first_w(const ConvFirstArgs a) 
             for (int i = 0; i < 16; ++i) acc[p][i] = 0.f;
         const float* arow = A + (size_t)rowvox[mt * 32 + j] * REC;
         // the four input voxels of tap t9 = 3 dz + dy, this lane's k-slot of every step
+        // (two per-lane bases — the lane half's slot of the wide read and of NST = 3's odd third — so that every tap / voxel
+        // displacement below is an immediate of the ds_read when the geometry is a template constant)
+        const float* arow_a = arow + (NST == 4 ? 4 * h : NST == 1 ? h : 2 * h);
+        const float* arow_b = arow + 4 + h;
         auto fetch = [&](int t9, float (&d)[4][4]) {
-            const float* rec0 = arow + (((t9 / 3) * gHp + (t9 % 3)) * gWp) * REC;
+            const int off0 = (((t9 / 3) * gHp + (t9 % 3)) * gWp) * REC;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float* rec = rec0 + i * REC;
+                const int off = off0 + i * REC;
                 if (NST == 4) {
-                    const float4 q = *reinterpret_cast<const float4*>(rec + 4 * h);
+                    const float4 q = *reinterpret_cast<const float4*>(arow_a + off);
                     d[i][0] = q.x; d[i][1] = q.y; d[i][2] = q.z; d[i][3] = q.w;
                 } else if (NST == 3) {
-                    const float2 q = *reinterpret_cast<const float2*>(rec + 2 * h);
-                    d[i][0] = q.x; d[i][1] = q.y; d[i][2] = rec[4 + h];
+                    const float2 q = *reinterpret_cast<const float2*>(arow_a + off);
+                    d[i][0] = q.x; d[i][1] = q.y; d[i][2] = arow_b[off];
                 } else if (NST == 2) {
-                    const float2 q = *reinterpret_cast<const float2*>(rec + 2 * h);
+                    const float2 q = *reinterpret_cast<const float2*>(arow_a + off);
                     d[i][0] = q.x; d[i][1] = q.y;
                 } else {
-                    d[i][0] = rec[h];
+                    d[i][0] = arow_a[off];
                 }
             }
         };
@@ -526,7 +530,7 @@ bool conv_first_plan(int Din, int Hin, int Win, int Cin, const TView& oc, const 
     p->Hp = p->Hc + 2;
     p->Wp = p->Wc + 2;
     // F(2,3) along x (k_conv_first_w): 'same' padding, an even number of computed columns; rows are x pairs
-    static const bool no_wino = getenv("TH_FIRST_WINO") && atoi(getenv("TH_FIRST_WINO")) == 0;   // read once: A/B runs set it per process
+    const bool no_wino = getenv("TH_FIRST_WINO") && atoi(getenv("TH_FIRST_WINO")) == 0;   // read at every model load (A/B runs, tests)
     const bool wino = !no_wino && g.pz == 1 && g.py == 1 && g.px == 1 && p->Wc % 2 == 0 && p->Wc >= 2;
     p->first_wino = wino ? 1 : 0;
     auto rows_for = [&](int zb) {

@@ -7,7 +7,7 @@
 // the halves of G are folded into the weights on the host in double precision).  Unlike conv_wino.hip (5^3 volumes, wide
 // layers, V and M through HBM) NOTHING of the transform domain leaves the CU here:
 //
-//   R  [2 channel pairs][z][y+1][x+1] x float2        the raw 4-channel slice of the frame (BN -> act prologue applied), zero halo
+//   R  [4 channels][z y rows + a zero row][x + 1]      the raw 4-channel slice of the frame (BN -> act prologue applied)
 //   B  [a 4][dz 3][lane 64] x float4(b)               the stage's transformed weights, shared by the 8 waves
 //   V  [ci 4][a 4][rec = z * NT + tile] x float4(b)   V = BT d BT^T of every 4 x 4 patch, double-buffered (2 x 64 KB)
 //   M  accumulators: 16 positions x 2 row tiles of 16 (z, tile) rows x 16 output channels per wave (128 AGPRs)
@@ -35,6 +35,7 @@
 #include <vector>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -59,6 +60,73 @@ __device__ __forceinline__ void wf_bt(float d0, float d1, float d2, float d3, fl
     o0 = d0 - d2; o1 = d1 + d2; o2 = d2 - d1; o3 = d1 - d3;
 }
 
+// unit done: inverse transform (AT M AT^T on a lane's 16 accumulators), bias, epilogue chain, (pool,) store, accumulators cleared.
+// C layout of v_mfma_f32_16x16x4_f32: col = i16, row = 4 q + r.
+template <int D, int H, int W, int POOL>
+__device__ __forceinline__ void wf_epilogue(const ConvWfArgs& a, f32x4 (&acc)[2][16], int64_t f, int cb, bool uok, int wave, int i16, int q) {
+    constexpr int TY = H / 2, TX = W / 2, NT = TY * TX, NR = D * NT;
+    (void)TY;
+    const int co = cb * 16 + i16;
+    const bool cok = uok && co < a.Cout;
+    const int cc = co < a.Cout ? co : 0;
+    const float bv = a.bias ? a.bias[cc] : 0.f;
+    float* const outb = a.out + f * a.out_fs + a.out_coff + cc;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        float y[16];                             // [r][o][p]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float sm[4][2];
+#pragma unroll
+            for (int aa = 0; aa < 4; ++aa) {
+                const float m0 = acc[rt][4 * aa][r], m1 = acc[rt][4 * aa + 1][r], m2 = acc[rt][4 * aa + 2][r], m3 = acc[rt][4 * aa + 3][r];
+                sm[aa][0] = (m0 + m1) + m2;
+                sm[aa][1] = (m1 - m2) - m3;
+            }
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                y[4 * r + p] = ((sm[0][p] + sm[1][p]) + sm[2][p]) + bv;
+                y[4 * r + 2 + p] = ((sm[1][p] - sm[2][p]) - sm[3][p]) + bv;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 16; ++p) acc[rt][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int row0 = 32 * wave + 16 * rt + 4 * q;
+        if (POOL == 0) {
+            th_post16(y, cc, a.post);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + r;
+                if (!cok || row >= NR) continue;
+                const int z = row / NT, tile = row % NT, ty = tile / TX, tx = tile % TX;
+                float* o = outb + (int64_t)((z * H + 2 * ty) * W + 2 * tx) * a.out_cs;
+                o[0] = y[4 * r];
+                o[a.out_cs] = y[4 * r + 1];
+                o[(int64_t)W * a.out_cs] = y[4 * r + 2];
+                o[(int64_t)(W + 1) * a.out_cs] = y[4 * r + 3];
+            }
+        } else {
+            // rows (r = 0, 1) and (2, 3) are the z mates of one pooled voxel; its 2 x 2 in-plane window is the tile
+            if (!(POOL == 1 && a.post.monotone)) th_post16(y, cc, a.post);
+            float pv[2];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const float* yy = y + 8 * h2;
+                if (POOL == 1) pv[h2] = fmaxf(fmaxf(fmaxf(yy[0], yy[1]), fmaxf(yy[2], yy[3])), fmaxf(fmaxf(yy[4], yy[5]), fmaxf(yy[6], yy[7])));
+                else pv[h2] = (((yy[0] + yy[1]) + (yy[2] + yy[3])) + ((yy[4] + yy[5]) + (yy[6] + yy[7]))) * 0.125f;
+            }
+            if (POOL == 1 && a.post.monotone) th_post2(pv[0], pv[1], cc, a.post);
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int row = row0 + 2 * h2;
+                if (!cok || row >= NR) continue;
+                const int pr = row >> 1, zp = pr / NT, tile = pr % NT;
+                outb[(int64_t)(zp * NT + tile) * a.out_cs] = pv[h2];
+            }
+        }
+    }
+}
+
 // POOL: 0 none, 1 max 2x2x2, 2 average 2x2x2.  PRE: prologue on the staged input — 0 none, 1 BN-affine -> ReLU (DenseNet-style
 // pre-activation layers), 2 generic (optional affine, any activation: op decoded per stage)
 // DBG: timing knock-outs (TH_WF_DBG, results are WRONG): 1 no transform, 2 no slice loads / R writes, 4 no weight traffic, 8 no barriers;
@@ -66,9 +134,9 @@ __device__ __forceinline__ void wf_bt(float d0, float d1, float d2, float d3, fl
 template <int D, int H, int W, int POOL, int PRE, int DBG = 0>
 __global__ void __launch_bounds__(512, 1) k_conv_wf(const ConvWfArgs a) {
     constexpr int TY = H / 2, TX = W / 2, NT = TY * TX, NR = D * NT, NZ = NR;
-    // R: rows of W + 1 floats — column x = -1 of a row is column x = W of the row before it (both are padding), and planes of
-    // H + 1 rows — row y = -1 of a plane is row y = H of the plane before it: (D (H + 1) + 1) rows, one more float, one dump float
-    constexpr int RX = W + 1, RXH = W / 2 + 1, RYS = H + 1, RVOX = (D * RYS + 1) * RX + 1, RPL = RVOX + 1, NV = D * H * W;
+    // R: one plane per channel of D H real rows + ONE zero row, each W + 2 floats (x = -1 .. W; the two halo columns are never
+    // written); patch rows above / below the frame's y range are pointed at the zero row.  4 dump floats behind every plane.
+    constexpr int RX = W + 2, RROWS = D * H + 1, RPL = RROWS * RX + 4, NV = D * H * W;
     constexpr int kVB = 16 * 256;                      // float4 per V buffer
     static_assert(H % 2 == 0 && W % 2 == 0, "in-plane tiles are 2 x 2");
     static_assert(NR <= 250, "256 rows per workgroup: the zero record and the dump records live above the real ones");
@@ -77,7 +145,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_wf(const ConvWfArgs a) {
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     float4* const V4 = smem;                                            // [2][16 planes][256 records]
     float4* const B4 = smem + 2 * kVB;                                  // [a 4][dz 3][lane 64] + 1 dump: this stage's weight fragments
-    float2* const R2 = reinterpret_cast<float2*>(smem + 2 * kVB + 769); // [2 channel pairs][RVOX + 1 (dump)]
+    float* const R1 = reinterpret_cast<float*>(smem + 2 * kVB + 769);   // [4 channels][RPL]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -115,19 +183,20 @@ __global__ void __launch_bounds__(512, 1) k_conv_wf(const ConvWfArgs a) {
         const int vv = ok ? v : 0;
         const int z = vv / (H * W), y = (vv / W) % H, x = vv % W;
         goff[j] = vv * (a.in_blk ? 4 : a.in_cs);
-        // inside a row the even columns xx = x + 1 = 0, 2, .. come first, then the odd ones: the tiles of a row read columns
-        // 2 tx + j, i.e. for a fixed j consecutive lanes read consecutive floats (a plain row would put them on even banks only)
-        const int xx = x + 1;
-        rdst[j] = ok ? (z * RYS + y + 1) * RX + ((xx & 1) ? RXH + (xx >> 1) : (xx >> 1)) : RVOX;
+        rdst[j] = ok ? (z * H + y) * RX + x + 1 : RROWS * RX;
     }
     // transform side: record tid & 255, channels 2 (tid >> 8) and 2 (tid >> 8) + 1
     const int trec = tid & 255, th = tid >> 8;
-    int rsrc, wdst;
+    int roff[4], wdst;                  // the four patch rows (floats from the channel plane's start), the V record
     {
         const bool ok = trec < NR;
         const int rr = ok ? trec : 0;
         const int z = rr / NT, tile = rr % NT, ty = tile / TX, tx = tile % TX;
-        rsrc = th * RPL + (z * RYS + 2 * ty) * RX + tx;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int y = 2 * ty - 1 + i;
+            roff[i] = 2 * th * RPL + ((y >= 0 && y < H) ? z * H + y : D * H) * RX + 2 * tx;
+        }
         wdst = th * 8 * 256 + (ok ? trec : 255);
     }
     // A side: rows 32 wave + 16 rt + i16 (POOL: rows are ordered (z pair, tile, z low) so that a lane's registers r = 0,1 and
@@ -202,7 +271,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_wf(const ConvWfArgs a) {
     };
     auto store_R = [&](const float (&x)[8], int j) {
 #pragma unroll
-        for (int k = 0; k < 2; ++k) R2[k * RPL + rdst[j]] = make_float2(x[4 * j + 2 * k], x[4 * j + 2 * k + 1]);
+        for (int k = 0; k < 4; ++k) R1[k * RPL + rdst[j]] = x[4 * j + k];
     };
     auto next_pre = [&]() {
         if (++cR == a.nchunks) cR = 0;
@@ -216,38 +285,45 @@ __global__ void __launch_bounds__(512, 1) k_conv_wf(const ConvWfArgs a) {
         store_R(x, 1);
         next_pre();
     };
-    // V = BT d BT^T of this thread's patch for its two channels (2 th, 2 th + 1: the float2 halves) into Vn: 16 ds_read_b64,
-    // 32 packed adds, 8 ds_write_b128 — column by column, so that the stage loop can spread the pieces over its slots
-    auto read_col = [&](float2 (&d)[4], int j) {
+    // V = BT d BT^T of this thread's patch, channel 2 th + k, into Vn.  The arithmetic runs on x PAIRS (the two floats of a
+    // ds_read_b64; v_pk_add_f32 with sign / half selects), so that the four b values of a row come out in consecutive registers —
+    // what ds_write_b128 wants: 8 ds_read_b64, ~16 packed adds, 4 ds_write_b128 per channel and nothing to shuffle.
+    auto read_patch = [&](v2f (&d)[4][2], int k) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            d[i] = (DBG & 128) ? make_float2(__builtin_bit_cast(float, rsrc + 4 * i + j), 1.f) : R2[rsrc + i * RX + (j >> 1) + (j & 1) * RXH];
+        for (int i = 0; i < 4; ++i) {
+            const float* r = R1 + k * RPL + roff[i];
+            if (DBG & 128) { d[i][0] = d[i][1] = (v2f){__builtin_bit_cast(float, roff[i] + k), 1.f}; continue; }
+            d[i][0] = *reinterpret_cast<const v2f*>(r);
+            d[i][1] = *reinterpret_cast<const v2f*>(r + 2);
+        }
     };
-    auto col = [&](const float2 (&d)[4], float2 (&t)[4][4], int j) {
-        t[0][j] = make_float2(d[0].x - d[2].x, d[0].y - d[2].y);
-        t[1][j] = make_float2(d[1].x + d[2].x, d[1].y + d[2].y);
-        t[2][j] = make_float2(d[2].x - d[1].x, d[2].y - d[1].y);
-        t[3][j] = make_float2(d[1].x - d[3].x, d[1].y - d[3].y);
+    auto cols = [&](const v2f (&d)[4][2], v2f (&t)[4][2]) {
+#pragma unroll
+        for (int hx = 0; hx < 2; ++hx) {
+            t[0][hx] = d[0][hx] - d[2][hx];
+            t[1][hx] = d[1][hx] + d[2][hx];
+            t[2][hx] = d[2][hx] - d[1][hx];
+            t[3][hx] = d[1][hx] - d[3][hx];
+        }
     };
-    auto rows = [&](const float2 (&t)[4][4], float4* Vn, int a0, int a1) {
+    auto rows = [&](const v2f (&t)[4][2], float4* Vn, int k, int a0, int a1) {
 #pragma unroll
         for (int aa = a0; aa < a1; ++aa) {
-            float4 v0, v1;
-            wf_bt(t[aa][0].x, t[aa][1].x, t[aa][2].x, t[aa][3].x, v0.x, v0.y, v0.z, v0.w);
-            wf_bt(t[aa][0].y, t[aa][1].y, t[aa][2].y, t[aa][3].y, v1.x, v1.y, v1.z, v1.w);
-            if (DBG & 64) {
-                if (v0.x + v0.y + v0.z + v0.w + v1.x + v1.y + v1.z + v1.w == 1.2345e-30f) Vn[wdst + aa * 256] = v0;
-            } else {
-                Vn[wdst + aa * 256] = v0;
-                Vn[wdst + (4 + aa) * 256] = v1;
-            }
+            const v2f t01 = t[aa][0], t23 = t[aa][1];
+            v2f v01, v23;
+            // (t0 - t2, t1 + t2) and (t2 - t1, t1 - t3) as ONE packed add each: half selects and sign bits are free operand
+            // modifiers (written out: hipcc builds these from scalar adds, sign flips and moves)
+            asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(v01) : "v"(t01), "v"(t23));
+            asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(v23) : "v"(t23), "v"(t01));
+            const float4 v = make_float4(v01.x, v01.y, v23.x, v23.y);
+            if (DBG & 64) { if (v.x + v.y + v.z + v.w == 1.2345e-30f) Vn[wdst + (k * 4 + aa) * 256] = v; }
+            else Vn[wdst + (k * 4 + aa) * 256] = v;
         }
     };
     auto transform_all = [&](float4* Vn) {
-        float2 d[4], t[4][4];
+        v2f d[4][2], t[4][2];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { read_col(d, j); col(d, t, j); }
-        rows(t, Vn, 0, 4);
+        for (int k = 0; k < 2; ++k) { read_patch(d, k); cols(d, t); rows(t, Vn, k, 0, 4); }
     };
     // B fragments: the 768 float4 of a stage ([a][dz][lane]) live in LDS, read by every wave.  They arrive in two halves
     // (a-steps 0,1 / 2,3) through one register each of threads 0..383: loaded from L2 a stage ahead — BEFORE the slice loads of
@@ -345,15 +421,14 @@ __global__ void __launch_bounds__(512, 1) k_conv_wf(const ConvWfArgs a) {
         // the transform of slice s + 1 (two channels per thread) in six pieces
         auto half2 = [&](auto late_t) __attribute__((always_inline)) {
             constexpr int L = 0;                                    // first slot of the transform
-            float2 d[4], t[4][4];
+            v2f d[4][2], t[4][2];
 #define WF_P2(k)                                                                           \
             if (!(DBG & 1)) {                                                              \
-                if ((k) == L) read_col(d, 0);                                              \
-                if ((k) == L + 1) { col(d, t, 0); read_col(d, 1); }                        \
-                if ((k) == L + 2) { col(d, t, 1); read_col(d, 2); }                        \
-                if ((k) == L + 3) { col(d, t, 2); read_col(d, 3); }                        \
-                if ((k) == L + 4) { col(d, t, 3); rows(t, Vn, 0, 2); }                     \
-                if ((k) == L + 5) { rows(t, Vn, 2, 4); }                                   \
+                if ((k) == L) read_patch(d, 0);                                            \
+                if ((k) == L + 1) { cols(d, t); read_patch(d, 1); }                        \
+                if ((k) == L + 2) { rows(t, Vn, 0, 0, 4); cols(d, t); }                    \
+                if ((k) == L + 3) { rows(t, Vn, 1, 0, 2); }                                \
+                if ((k) == L + 4) { rows(t, Vn, 1, 2, 4); }                                \
             }
             WF_FETCH_B(6) WF_P2(0)
             WF_SLOT
@@ -385,71 +460,14 @@ __global__ void __launch_bounds__(512, 1) k_conv_wf(const ConvWfArgs a) {
             // ---- unit done: inverse transform, bias, epilogue chain, (pool,) store; C layout col = i16, row = 4 q + r ----
             int64_t f; int cb; bool uok;
             unit_of(ku, f, cb, uok);
-            const int co = cb * 16 + i16;
-            const bool cok = uok && co < a.Cout;
-            const int cc = co < a.Cout ? co : 0;
-            const float bv = a.bias ? a.bias[cc] : 0.f;
-            float* const outb = a.out + f * a.out_fs + a.out_coff + cc;
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
-                float y[16];                             // [r][o][p]
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float sm[4][2];
-#pragma unroll
-                    for (int aa = 0; aa < 4; ++aa) {
-                        const float m0 = acc[rt][4 * aa][r], m1 = acc[rt][4 * aa + 1][r], m2 = acc[rt][4 * aa + 2][r], m3 = acc[rt][4 * aa + 3][r];
-                        sm[aa][0] = (m0 + m1) + m2;
-                        sm[aa][1] = (m1 - m2) - m3;
-                    }
-#pragma unroll
-                    for (int p = 0; p < 2; ++p) {
-                        y[4 * r + p] = ((sm[0][p] + sm[1][p]) + sm[2][p]) + bv;
-                        y[4 * r + 2 + p] = ((sm[1][p] - sm[2][p]) - sm[3][p]) + bv;
-                    }
-                }
-#pragma unroll
-                for (int p = 0; p < 16; ++p) acc[rt][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                const int row0 = 32 * wave + 16 * rt + 4 * q;
-                if (POOL == 0) {
-                    th_post16(y, cc, a.post);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = row0 + r;
-                        if (!cok || row >= NR) continue;
-                        const int z = row / NT, tile = row % NT, ty = tile / TX, tx = tile % TX;
-                        float* o = outb + (int64_t)((z * H + 2 * ty) * W + 2 * tx) * a.out_cs;
-                        o[0] = y[4 * r];
-                        o[a.out_cs] = y[4 * r + 1];
-                        o[(int64_t)W * a.out_cs] = y[4 * r + 2];
-                        o[(int64_t)(W + 1) * a.out_cs] = y[4 * r + 3];
-                    }
-                } else {
-                    // rows (r = 0, 1) and (2, 3) are the z mates of one pooled voxel; its 2 x 2 in-plane window is the tile
-                    if (!(POOL == 1 && a.post.monotone)) th_post16(y, cc, a.post);
-                    float pv[2];
-#pragma unroll
-                    for (int h2 = 0; h2 < 2; ++h2) {
-                        const float* yy = y + 8 * h2;
-                        if (POOL == 1) pv[h2] = fmaxf(fmaxf(fmaxf(yy[0], yy[1]), fmaxf(yy[2], yy[3])), fmaxf(fmaxf(yy[4], yy[5]), fmaxf(yy[6], yy[7])));
-                        else pv[h2] = (((yy[0] + yy[1]) + (yy[2] + yy[3])) + ((yy[4] + yy[5]) + (yy[6] + yy[7]))) * 0.125f;
-                    }
-                    if (POOL == 1 && a.post.monotone) th_post2(pv[0], pv[1], cc, a.post);
-#pragma unroll
-                    for (int h2 = 0; h2 < 2; ++h2) {
-                        const int row = row0 + 2 * h2;
-                        if (!cok || row >= NR) continue;
-                        const int pr = row >> 1, zp = pr / NT, tile = pr % NT;
-                        outb[(int64_t)(zp * NT + tile) * a.out_cs] = pv[h2];
-                    }
-                }
-            }
+            wf_epilogue<D, H, W, POOL>(a, acc, f, cb, uok, wave, i16, q);
             c = 0; ++ku;
         } else {
             ++c;
         }
     }
 }
+
 
 typedef void (*WfKernel)(const ConvWfArgs);
 struct WfGeo { int D, H, W; WfKernel k[3][3]; };     // [pool][pre]
@@ -486,7 +504,7 @@ bool conv_wf_plan(const TView& in, const TView& out, const ConvGeom& g, int Cin,
     // fall outside the volume are not counted; the kernel executes them on a zero record), and what the MFMAs issue
     p->own_flops = 2.0 * 16 * NT * (3.0 * in.D - 2) * Cin * (double)Cout;
     p->exec_flops = 2.0 * 16 * 256 * 3 * Cin * 16.0 * p->ncb;
-    p->lds_bytes = (size_t)2 * 65536 + 769 * 16 + (size_t)4 * ((in.D * (in.H + 1) + 1) * (in.W + 1) + 2) * 4 + 16;
+    p->lds_bytes = (size_t)2 * 65536 + 769 * 16 + (size_t)4 * ((in.D * in.H + 1) * (in.W + 2) + 4) * 4 + 16;
     if (p->lds_bytes > kWfLdsLimit) return false;
     char buf[200];
     snprintf(buf, sizeof buf, "conv_wf<F(2,3)^2 in-plane fused in LDS, z direct; pool%d> 16c x %d, K%d, lds%zuK (16x16x4 MFMA) [k_conv_wf<%d,%d,%d,%d>]",
@@ -560,13 +578,14 @@ int launch_conv_wf(hipStream_t s, int64_t n, const ConvWfPlan& p, TView in, TVie
     grid = (grid + 7) / 8 * 8;
     const int pre_kind = conv_wf_pre_kind(pre);
     WfKernel k = kWfGeo[p.geo].k[p.pool][pre_kind];
+    const size_t lds = p.lds_bytes;
     {   // timing experiments only (tools/bench_layer.py): knock-out instantiations of the plain 10^3 kernel
         static const int dbg = getenv("TH_WF_DBG") ? atoi(getenv("TH_WF_DBG")) : 0;
         if (dbg > 0 && p.geo == 0 && p.pool == 0 && pre_kind == 0)
             for (const WfDbg& d : kWfDbg) if (d.code == dbg) k = d.k;
     }
     HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWfLdsLimit));
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(512), p.lds_bytes, s, a);
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(512), lds, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) TH_FAIL(TH_EHIP, "conv_wf launch failed: %s (%s)", hipGetErrorString(e), p.label.c_str());
     return TH_OK;
