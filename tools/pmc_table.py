@@ -12,7 +12,7 @@ for db in sys.argv[1:]:
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for ev, name, st, en, wgs, lds in disp:
         if "conv" not in name and "wino" not in name: continue
-        key = (re.sub(r".*(k_(?:conv|wino)_[a-z0-9]+(?:<[^>]*>)?).*", r"\1", name), wgs, lds)
+        key = (re.sub(r".*(k_(?:conv|wino)_[a-z0-9_]+(?:<[^>]*>)?).*", r"\1", name), wgs, lds)
         for k, v in vals[ev].items(): agg[key][k].append(v)
         agg[key]["dur_us"].append((en - st) / 1e3)
     for key, d in sorted(agg.items(), key=lambda kv: -sum(kv[1]["dur_us"])):
