@@ -31,7 +31,6 @@
 #include <cstdlib>
 #include <cstring>
 #include <thread>
-#include <type_traits>
 #include <vector>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -130,7 +129,7 @@ __device__ __forceinline__ void wf_epilogue(const ConvWfArgs& a, f32x4 (&acc)[2]
 // POOL: 0 none, 1 max 2x2x2, 2 average 2x2x2.  PRE: prologue on the staged input — 0 none, 1 BN-affine -> ReLU (DenseNet-style
 // pre-activation layers), 2 generic (optional affine, any activation: op decoded per stage)
 // DBG: timing knock-outs (TH_WF_DBG, results are WRONG): 1 no transform, 2 no slice loads / R writes, 4 no weight traffic, 8 no barriers;
-// 64 no V writes, 128 R reads replaced by loop invariants (the compiler then hoists the whole transform), 256 every slice from frame 0; 32 (results right): no MFMA / other interleave request inside the slots; 16 (results right): the two wave groups of a SIMD pair on different slot schedules (spills: the branches cost more than the overlap gives)
+// 64 no V writes, 128 R reads replaced by loop invariants (the compiler then hoists the whole transform), 256 every slice from frame 0; 32 (results right): no MFMA / other interleave request inside the slots
 template <int D, int H, int W, int POOL, int PRE, int DBG = 0>
 __global__ void __launch_bounds__(512, 1) k_conv_wf(const ConvWfArgs a) {
     constexpr int TY = H / 2, TX = W / 2, NT = TY * TX, NR = D * NT, NZ = NR;
@@ -386,10 +385,10 @@ __global__ void __launch_bounds__(512, 1) k_conv_wf(const ConvWfArgs a) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) pre[j] = *reinterpret_cast<const float4*>(pslice + goff[j]);
         }
-        // Waves 0..3 and 4..7 share the SIMDs pairwise (a workgroup's waves go to SIMDs cyclically): the two groups do their
-        // non-MFMA work in DIFFERENT slots, so that one wave of a SIMD keeps the matrix pipe busy while the other stages.
-        auto half1 = [&](auto late_t) __attribute__((always_inline)) {
-            constexpr int L = decltype(late_t)::value ? 3 : 0;      // first slot of the prologue work
+        // (tried: waves 0..3 and 4..7 — they share the SIMDs pairwise — on DIFFERENT slot schedules behind a wave-uniform branch, so that
+        // one wave of a SIMD multiplies while the other stages: the branches cost 100+ spilled registers, 5.9 ms instead of 1.2)
+        auto half1 = [&]() __attribute__((always_inline)) {
+            constexpr int L = 0;                                    // first slot of the prologue work
             WF_FETCH_A(0) WF_FETCH_B(0)
             WF_SLOT
 #define WF_P1(k)                                                                           \
@@ -419,7 +418,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_wf(const ConvWfArgs a) {
 #undef WF_P1
         };
         // the transform of slice s + 1 (two channels per thread) in six pieces
-        auto half2 = [&](auto late_t) __attribute__((always_inline)) {
+        auto half2 = [&]() __attribute__((always_inline)) {
             constexpr int L = 0;                                    // first slot of the transform
             v2f d[4][2], t[4][2];
 #define WF_P2(k)                                                                           \
@@ -445,10 +444,10 @@ __global__ void __launch_bounds__(512, 1) k_conv_wf(const ConvWfArgs a) {
             WF_MMA(11)
 #undef WF_P2
         };
-        if (!(DBG & 16) || wave < 4) half1(std::false_type{}); else half1(std::true_type{});
+        half1();
         if (!(DBG & 8)) __syncthreads();                // (B) R complete; nobody reads the first half of B any more
         if (!(DBG & 4)) B4[bdst] = bn0;                 // a-steps 0,1 of stage s + 1
-        if (!(DBG & 16) || wave < 4) half2(std::false_type{}); else half2(std::true_type{});
+        half2();
 #undef WF_FETCH_A
 #undef WF_FETCH_B
 #undef WF_MMA4
