@@ -426,23 +426,38 @@ __global__ void __launch_bounds__(256, 2) k_conv_first_w(const ConvFirstArgs a) 
                 }
             }
         };
-        float d[2][4][4];
-        fetch(0, d[0]);
+        // The wave alternates between a burst of 4 NST MFMAs (tap t, its four points already in registers) and a short group
+        // of everything else (the points of tap t + 1 from the raw voxels read a tap ago, the reads of tap t + 2): whatever a
+        // wave issues BETWEEN two of its MFMAs delays the second one by about its own issue time, whether or not it depends on
+        // it (measured: a lone wave per SIMD ran this loop at 56 % of the pipe with one subtraction in front of every MFMA).
+        float d[4][4], v[2][4][4];
+        auto points = [&](float (&vv)[4][4]) {
+#pragma unroll
+            for (int s = 0; s < NST; ++s) {
+                vv[0][s] = d[0][s] - d[2][s];
+                vv[1][s] = d[1][s] + d[2][s];
+                vv[2][s] = d[2][s] - d[1][s];
+                vv[3][s] = d[1][s] - d[3][s];
+            }
+        };
+        fetch(0, d);
+        points(v[0]);
+        fetch(1, d);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            if (t + 1 < 9) fetch(t + 1, d[(t + 1) & 1]);
+            if (t + 1 < 9) points(v[(t + 1) & 1]);
+            if (t + 2 < 9) fetch(t + 2, d);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < NST; ++s) {
-                const float d0 = d[t & 1][0][s], d1 = d[t & 1][1][s], d2 = d[t & 1][2][s], d3 = d[t & 1][3][s];
                 const float w0 = s == 0 ? breg[t].x : s == 1 ? breg[t].y : s == 2 ? breg[t].z : breg[t].w;
                 const float w1 = s == 0 ? breg[9 + t].x : s == 1 ? breg[9 + t].y : s == 2 ? breg[9 + t].z : breg[9 + t].w;
                 const float w2 = s == 0 ? breg[18 + t].x : s == 1 ? breg[18 + t].y : s == 2 ? breg[18 + t].z : breg[18 + t].w;
                 const float w3 = s == 0 ? breg[27 + t].x : s == 1 ? breg[27 + t].y : s == 2 ? breg[27 + t].z : breg[27 + t].w;
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(d0 - d2, w0, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(d1 + d2, w1, acc[1], 0, 0, 0);
-                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(d2 - d1, w2, acc[2], 0, 0, 0);
-                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(d1 - d3, w3, acc[3], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[t & 1][0][s], w0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[t & 1][1][s], w1, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[t & 1][2][s], w2, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[t & 1][3][s], w3, acc[3], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -492,6 +507,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_first_w(const ConvFirstArgs a) 
         }
     }
 }
+
 
 typedef void (*FirstKernel)(const ConvFirstArgs);
 constexpr int kWaves = 4;
