@@ -276,7 +276,8 @@ __global__ void __launch_bounds__(WAVES * 64, 3) k_conv_first(const ConvFirstArg
 // (dz, dy) mates at a time, so the whole 2^3 window sits in one lane's registers (no cross-lane step at all).  The four
 // accumulators also end the single-accumulator chain that made k_conv_first need three waves per SIMD; this one runs two
 // workgroups per CU on 4-plane bricks (25 row tiles, 70 KB of image).
-template <int NST, int PMODE, int GEO = 0>
+// KN: timing knock-outs (TH_FIRST_DBG, results are WRONG): 1 one LDS fetch per tile, 2 no transform adds, 4 no epilogue chain / stores
+template <int NST, int PMODE, int GEO = 0, int KN = 0>
 __global__ void __launch_bounds__(256, 2) k_conv_first_w(const ConvFirstArgs a) {
     constexpr int POOL = PMODE == 3 ? 1 : PMODE;
     constexpr bool POOL_FIRST = PMODE == 3;
@@ -393,6 +394,47 @@ __global__ void __launch_bounds__(256, 2) k_conv_first_w(const ConvFirstArgs a) 
     const int cc = cok ? co : 0;
     const float bv = a.bias ? a.bias[cc] : 0.f;
 
+    // POOL_FIRST: a tile leaves 4 pooled sums per lane; their epilogue chain (exp / BatchNorm constants from memory), the output
+    // offsets (LDS) and the stores are DEFERRED into the next tile's tap loop (a slot between two MFMA bursts) instead of standing
+    // between the two tiles' MFMAs (knock-out: the chain + stores cost 12 % of the kernel there)
+    float mprev[4] = {0.f, 0.f, 0.f, 0.f};
+    int mtprev = -1;
+    // the two chains TIMED / DenseCPD blocks use get straight-line code with their constants in registers (the generic th_post2
+    // decodes the op list — kernel-argument loads, a switch per op — and fetches the BatchNorm constants for every tile: ~650
+    // cycles per tile and wave): 1 = ELU -> BN-affine, 2 = BN-affine -> ReLU, 0 = generic
+    int epi = 0;
+    float esc = 1.f, esh = 0.f, ealpha = 1.f;
+    if (POOL_FIRST && a.post.n == 2) {
+        if (a.post.type[0] == POP_ACT && a.post.act[0] == ACT_ELU && a.post.type[1] == POP_AFFINE) {
+            epi = 1; ealpha = a.post.alpha[0]; esc = a.post.scale[1][cc]; esh = a.post.shift[1][cc];
+        } else if (a.post.type[0] == POP_AFFINE && a.post.type[1] == POP_ACT && a.post.act[1] == ACT_RELU) {
+            epi = 2; esc = a.post.scale[0][cc]; esh = a.post.shift[0][cc];
+        }
+    }
+    epi = __builtin_amdgcn_readfirstlane(epi);
+    auto finish_prev = [&]() {
+        if (mtprev < 0) return;
+        if (KN & 4) { if (mprev[0] + mprev[1] + mprev[2] + mprev[3] == 1.2345e-30f) outb[0] = mprev[0]; mtprev = -1; return; }
+        if (epi == 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float x = mprev[q];
+                mprev[q] = fmaf(x > 0.f ? x : ealpha * (__expf(x) - 1.f), esc, esh);
+            }
+        } else if (epi == 2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) mprev[q] = fmaxf(fmaf(mprev[q], esc, esh), 0.f);
+        } else {
+            th_post2(mprev[0], mprev[1], cc, a.post);
+            th_post2(mprev[2], mprev[3], cc, a.post);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int oo = cok ? rowout[mtprev * 8 + 2 * q + h] : -1;
+            if (oo >= 0) outb[oo + cofs] = mprev[q];
+        }
+        mtprev = -1;
+    };
     for (int rd = 0; rd < rounds; ++rd) {
         const int mt = rd * WAVES + wave;
         if (mt >= a.n_mtiles) break;  // wave-uniform; no barriers below
@@ -434,6 +476,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_first_w(const ConvFirstArgs a) 
         auto points = [&](float (&vv)[4][4]) {
 #pragma unroll
             for (int s = 0; s < NST; ++s) {
+                if (KN & 2) { vv[0][s] = d[0][s]; vv[1][s] = d[1][s]; vv[2][s] = d[2][s]; vv[3][s] = d[3][s]; continue; }
                 vv[0][s] = d[0][s] - d[2][s];
                 vv[1][s] = d[1][s] + d[2][s];
                 vv[2][s] = d[2][s] - d[1][s];
@@ -446,7 +489,8 @@ __global__ void __launch_bounds__(256, 2) k_conv_first_w(const ConvFirstArgs a) 
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             if (t + 1 < 9) points(v[(t + 1) & 1]);
-            if (t + 2 < 9) fetch(t + 2, d);
+            if (t + 2 < 9 && !(KN & 1)) fetch(t + 2, d);
+            if (POOL_FIRST && t == 2) finish_prev();
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < NST; ++s) {
@@ -475,13 +519,9 @@ __global__ void __launch_bounds__(256, 2) k_conv_first_w(const ConvFirstArgs a) 
             for (int q = 0; q < 4; ++q)
                 m4[q] = fmaxf(fmaxf(fmaxf(x0[4 * q], x0[4 * q + 1]), fmaxf(x0[4 * q + 2], x0[4 * q + 3])),
                               fmaxf(fmaxf(x1[4 * q], x1[4 * q + 1]), fmaxf(x1[4 * q + 2], x1[4 * q + 3]))) + bv;
-            th_post2(m4[0], m4[1], cc, a.post);
-            th_post2(m4[2], m4[3], cc, a.post);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int oo = cok ? rowout[mt * 8 + 2 * q + h] : -1;
-                if (oo >= 0) outb[oo + cofs] = m4[q];
-            }
+            for (int q = 0; q < 4; ++q) mprev[q] = m4[q];
+            mtprev = mt;
             continue;
         }
 #pragma unroll
@@ -506,8 +546,8 @@ __global__ void __launch_bounds__(256, 2) k_conv_first_w(const ConvFirstArgs a) 
             }
         }
     }
+    if (POOL_FIRST) finish_prev();
 }
-
 
 typedef void (*FirstKernel)(const ConvFirstArgs);
 constexpr int kWaves = 4;
@@ -527,6 +567,8 @@ const FirstGeo kFirstWGeo[] = {
     {3, 3, 22, k_conv_first_w<3, 3, 22>},
     {3, 1, 22, k_conv_first_w<3, 1, 22>},
 };
+const FirstKernel kFirstWDbg[8] = {nullptr, k_conv_first_w<3, 3, 22, 1>, k_conv_first_w<3, 3, 22, 2>, k_conv_first_w<3, 3, 22, 3>,
+                                   k_conv_first_w<3, 3, 22, 4>, nullptr, nullptr, k_conv_first_w<3, 3, 22, 7>};
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
@@ -678,6 +720,10 @@ int launch_conv_first(hipStream_t s, int64_t n, const ConvMfmaPlan& p, const voi
     const int nst = (Cin + 1) / 2;
     int pmode, geo;
     FirstKernel k = pick_first_kernel(p, nst, post, &pmode, &geo);
+    {   // timing experiments only (tools/bench_layer.py): knock-out instantiations of k_conv_first_w<3,3,22>
+        static const int dbg = getenv("TH_FIRST_DBG") ? atoi(getenv("TH_FIRST_DBG")) : 0;
+        if (dbg > 0 && dbg < 8 && kFirstWDbg[dbg] && p.first_wino && nst == 3 && pmode == 3 && geo == 22) k = kFirstWDbg[dbg];
+    }
     HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kWaves * 64), p.lds_bytes, s, a);
     hipError_t e = hipGetLastError();
