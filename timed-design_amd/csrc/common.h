@@ -182,6 +182,7 @@ int launch_conv_first(hipStream_t s, int64_t n, const ConvMfmaPlan& p, const voi
 // ---- pointwise (1x1x1) streaming convolution (conv_pointwise.hip); plan.cfg in [300, 309) ----
 bool conv_pw_plan(const TView& in, const TView& out_conv, const ConvGeom& g, int Cin, int Cout, int pool, ConvMfmaPlan* plan);
 void conv_pw_pack_weights(const ConvMfmaPlan& p, int Cin, int Cout, const float* w_keras, float* dst);
+std::string conv_pw_label(const ConvMfmaPlan& p, bool out_blk, const PostOps& post);
 int launch_conv_pw(hipStream_t s, int64_t n, const ConvMfmaPlan& p, TView in, TView out, int Cin, int Cout, const float* wpk,
                    const float* bias, PreOp pre, PostOps post);
 

@@ -690,7 +690,7 @@ std::string conv_first_label(const ConvMfmaPlan& p, int Cin, const PostOps& post
     const size_t b = l.rfind('[');
     if (b != std::string::npos) {
         char buf[64];
-        if (p.first_wino) snprintf(buf, sizeof buf, "[k_conv_first_w<%d,%d,%d>]", (Cin + 1) / 2, pmode, geo);
+        if (p.first_wino) snprintf(buf, sizeof buf, "[k_conv_first_w<%d,%d,%d,0>]", (Cin + 1) / 2, pmode, geo);
         else snprintf(buf, sizeof buf, "[k_conv_first<%d,%d,%d,%d>]", kWaves, (Cin + 1) / 2, pmode, geo);
         l = l.substr(0, b) + buf;
     }

@@ -213,7 +213,9 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 // BLK: the chunk-blocked output form (TView::blk, POOL == 0 only) as its own instantiation — compiled into the plain kernels it
 // cost them registers (k_conv_pw2<12,2,0> spilled, <4,2,0> lost a workgroup per CU: 0.29 -> 0.56 ms for DenseCPD's first bottleneck)
-template <int KMAX, int NT, int POOL, int BLK = 0>
+// EPI: 0 the generic epilogue chain; 2 "BN-affine -> ReLU" (every DenseNet / DenseCPD bottleneck) as straight-line code with this
+// lane's constants in registers — as its own instantiation: next to the generic chain in one kernel it cost 40 registers and spills
+template <int KMAX, int NT, int POOL, int BLK = 0, int EPI = 0>
 __global__ void __launch_bounds__(256, (NT == 4 || KMAX == 16 || (BLK && KMAX == 12 && NT == 2)) ? 2 : ((BLK && KMAX == 4 && NT <= 2) ? 4 : 3)) k_conv_pw2(const ConvPwArgs a) {   // KMAX = 12: three per CU
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     const int tid = threadIdx.x;
@@ -275,10 +277,17 @@ __global__ void __launch_bounds__(256, (NT == 4 || KMAX == 16 || (BLK && KMAX ==
     // compiler cannot hoist it itself: the stores to `out` might alias)
     float bias_r[NT];
     const int npost = __builtin_amdgcn_readfirstlane(a.post.n);
+    // the epilogue chains of the DenseNet-style / TIMED-style blocks as straight-line code with this lane's BatchNorm constants in
+    // registers (a lane keeps its output channels for all its tiles): 1 = ELU -> BN-affine, 2 = BN-affine -> ReLU, 0 = generic
+    // (th_post16: op list decoded and constants fetched from memory for every tile — ~650 cycles per (tile, n-tile) in front of the
+    // stores of a tile that is worth 2 000 - 6 000 cycles of MFMAs)
+    float esc[NT], esh[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int co = nt * 32 + j;
         bias_r[nt] = a.bias ? a.bias[co < a.Cout ? co : 0] : 0.f;
+        esc[nt] = 1.f; esh[nt] = 0.f;
+        if (EPI == 2) { esc[nt] = a.post.scale[0][co < a.Cout ? co : 0]; esh[nt] = a.post.shift[0][co < a.Cout ? co : 0]; }
     }
     auto compute_store = [&](const u32x4 (&av)[KMAX], unsigned tile) {
         f32x16 acc[NT];
@@ -334,7 +343,12 @@ __global__ void __launch_bounds__(256, (NT == 4 || KMAX == 16 || (BLK && KMAX ==
             const float bv = bias_r[nt];
 #pragma unroll
             for (int r = 0; r < 16; ++r) x[r] = acc[nt][r] + bv;
-            if (npost) th_post16(x, cc, a.post);    // (its BatchNorm constants are loaded in the loop: layers with an epilogue chain pay the drain)
+            if (EPI == 2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) x[r] = fmaxf(fmaf(x[r], esc[nt], esh[nt]), 0.f);
+            } else if (npost) {
+                th_post16(x, cc, a.post);    // (generic chain: its BatchNorm constants are loaded in the loop)
+            }
             if (POOL == 0 && BLK) {
                 // chunk-blocked output ([C/4][voxel][4]): the accumulator layout has a lane own ONE channel of 16 rows — stored
                 // as it is, every instruction would write 16 separate 16-byte pieces.  The 32 x 32 tile goes through a per-wave
@@ -436,6 +450,14 @@ const PwKernel kPw2Blk[3][3] = {{k_conv_pw2<4, 1, 0, 1>, k_conv_pw2<4, 2, 0, 1>,
                                 {k_conv_pw2<8, 1, 0, 1>, k_conv_pw2<8, 2, 0, 1>, k_conv_pw2<8, 4, 0, 1>},
                                 {k_conv_pw2<16, 1, 0, 1>, k_conv_pw2<16, 2, 0, 1>, nullptr}};
 const PwKernel kPw2Blk_12[2] = {k_conv_pw2<12, 1, 0, 1>, k_conv_pw2<12, 2, 0, 1>};
+// "BN-affine -> ReLU" epilogue (EPI = 2), no pooling: [blk][kmax index][nt index], and the 12-slot pairs
+const PwKernel kPw2Relu[2][3][3] = {{{k_conv_pw2<4, 1, 0, 0, 2>, k_conv_pw2<4, 2, 0, 0, 2>, nullptr},
+                                     {k_conv_pw2<8, 1, 0, 0, 2>, k_conv_pw2<8, 2, 0, 0, 2>, nullptr},
+                                     {nullptr, nullptr, nullptr}},
+                                    {{k_conv_pw2<4, 1, 0, 1, 2>, k_conv_pw2<4, 2, 0, 1, 2>, nullptr},
+                                     {k_conv_pw2<8, 1, 0, 1, 2>, k_conv_pw2<8, 2, 0, 1, 2>, nullptr},
+                                     {nullptr, nullptr, nullptr}}};     // (up to 64 output / 96 input channels: the other shapes keep the generic chain)
+const PwKernel kPw2Relu_12[2][2] = {{k_conv_pw2<12, 1, 0, 0, 2>, k_conv_pw2<12, 2, 0, 0, 2>}, {k_conv_pw2<12, 1, 0, 1, 2>, k_conv_pw2<12, 2, 0, 1, 2>}};
 const int kPwKmax[3] = {4, 8, 16};
 const int kPwNt[3] = {1, 2, 4};
 constexpr size_t kPwLdsLimit = 64 * 1024;
@@ -473,7 +495,7 @@ bool conv_pw_plan(const TView& in, const TView& oc, const ConvGeom& g, int Cin, 
     const int kmax = (pipe && K8 > 8 && K8 <= 12 && nti <= 1) ? 12 : kPwKmax[kmi];
     snprintf(buf, sizeof buf, "conv_pw<k%d,nt%d,pool%d> K8=%d lds%zuK (streaming 1x1x1, weights in LDS%s) [k_conv_pw%s<%d,%d,%d%s>]",
              kmax, NT, pool, K8, lds / 1024, pipe ? ", next tile prefetched, buffer addressing" : "", pipe ? "2" : "",
-             kmax, NT, pool, pipe ? ",0" : "");
+             kmax, NT, pool, pipe ? ",0,0" : "");
     p->label = buf;
     (void)in;
     return true;
@@ -496,6 +518,23 @@ void conv_pw_pack_weights(const ConvMfmaPlan& p, int Cin, int Cout, const float*
                     }
                 }
         }
+}
+
+// the "BN-affine -> ReLU" instantiation exists for this plan and chain (launch_conv_pw and the step label agree through this)
+static bool pw_relu_epi(const ConvMfmaPlan& p, int K8, const PostOps& post) {
+    const int idx = p.cfg - 300, kmi = idx / 3, nti = idx % 3;
+    const bool relu_chain = post.n == 2 && post.type[0] == POP_AFFINE && post.type[1] == POP_ACT && post.act[1] == ACT_RELU;
+    if (p.pool != 0 || !relu_chain || getenv("TH_PW_NOEPI")) return false;
+    return (K8 > 8 && K8 <= 12 && nti <= 1) ? true : kPw2Relu[0][kmi][nti] != nullptr;
+}
+// the plan's label with the template arguments of the instantiation that runs (chunk-blocked output, epilogue chain)
+std::string conv_pw_label(const ConvMfmaPlan& p, bool out_blk, const PostOps& post) {
+    std::string l = p.label;
+    const size_t k = l.rfind(",0,0>]");
+    if (k == std::string::npos) return l;
+    l[k + 1] = out_blk ? '1' : '0';
+    l[k + 3] = pw_relu_epi(p, p.CI / 8, post) ? '2' : '0';
+    return l;
 }
 
 int launch_conv_pw(hipStream_t s, int64_t n, const ConvMfmaPlan& p, TView in, TView out, int Cin, int Cout, const float* wpk,
@@ -534,6 +573,11 @@ int launch_conv_pw(hipStream_t s, int64_t n, const ConvMfmaPlan& p, TView in, TV
         a.in_bytes = (unsigned)in_span; a.out_bytes = (unsigned)out_span;
         k = (a.K8 > 8 && a.K8 <= 12 && nti <= 1) ? kPw2_12[nti][p.pool] : kPw2[kmi][nti][p.pool];
         if (out.blk) k = (a.K8 > 8 && a.K8 <= 12 && nti <= 1) ? kPw2Blk_12[nti] : kPw2Blk[kmi][nti];
+        if (pw_relu_epi(p, a.K8, post)) {
+            const int bk = out.blk ? 1 : 0;
+            PwKernel kr = (a.K8 > 8 && a.K8 <= 12 && nti <= 1) ? kPw2Relu_12[bk][nti] : kPw2Relu[bk][kmi][nti];
+            if (kr) k = kr;
+        }
     }
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), p.lds_bytes + (out.blk ? 4 * 32 * 36 * 4 + 16 : 0), s, a);
     hipError_t e = hipGetLastError();

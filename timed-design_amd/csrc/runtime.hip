@@ -769,12 +769,8 @@ int plan(th_model* m) {
                         float* dw;
                         if ((rc = upload(M, packed.data(), packed.size(), &dw))) return rc;
                         st.exec_flops = mp.exec_flops;
-                        st.label = n.name + ": " + mp.label;
-                        if (N[dst].blk) {                                   // the chunk-blocked instantiation k_conv_pw2<K, N, 0, 1>
-                            const size_t k = st.label.rfind(",0>]");
-                            if (k != std::string::npos) st.label.replace(k, 4, ",1>]");
-                            st.label = label_note(st.label, " (output chunk-blocked)");
-                        }
+                        st.label = n.name + ": " + conv_pw_label(mp, N[dst].blk != 0, po);
+                        if (N[dst].blk) st.label = label_note(st.label, " (output chunk-blocked)");
                         st.run = [=](hipStream_t s, int64_t cnt) {
                             return launch_conv_pw(s, cnt, mp, M->view(src), M->view(dst), Cin, Cout, dw, dbias, pre, po);
                         };
