@@ -44,6 +44,7 @@ def test_single_layer_matches_the_float64_oracle(gpu, monkeypatch, cin, cout, n,
     """one Conv -> ELU -> BN block (with and without a BN -> ReLU prologue), frame counts around the 64-frame GEMM row block,
     Cout that is not a multiple of the 128-column block (96, 338): the layer's tensor against the oracle in float64"""
     monkeypatch.setenv("TH_WINOGRAD", "1")
+    monkeypatch.setenv("TH_NO_TAIL_FUSE", "1")     # the layer's tensor is fetched below: keep it (no pooling output transform)
     cfg, w, layer = _one_layer(cin, cout, seed=cin + cout, pre=pre)
     rng = np.random.default_rng(n)
     frames = (rng.standard_normal((n, 5, 5, 5, cin)) * (rng.random((n, 5, 5, 5, cin)) < 0.5)).astype(np.float32)
@@ -136,6 +137,7 @@ def test_timed_fixtures_with_the_seven_point_scheme(gpu, cnn_golden, monkeypatch
 @pytest.mark.parametrize("cin,cout,n", [(64, 128, 70), (128, 256, 3)])
 def test_single_layer_seven_point_scheme(gpu, monkeypatch, cin, cout, n):
     monkeypatch.setenv("TH_WINOGRAD", "2")
+    monkeypatch.setenv("TH_NO_TAIL_FUSE", "1")     # the layer's tensor is fetched below
     cfg, w, layer = _one_layer(cin, cout, seed=cin + cout)
     rng = np.random.default_rng(n)
     frames = (rng.standard_normal((n, 5, 5, 5, cin)) * (rng.random((n, 5, 5, 5, cin)) < 0.5)).astype(np.float32)
@@ -223,4 +225,29 @@ def test_fused_mid_transform_is_bit_identical(gpu, cnn_golden, monkeypatch, name
     assert not any("k_wino_mid" in s["label"] for s in plain.steps())
     assert np.array_equal(fused.predict(frames, logits=True), plain.predict(frames, logits=True))
     assert np.array_equal(fused.predict(frames), plain.predict(frames))
+    fused.close(); plain.close()
+
+
+@pytest.mark.parametrize("cin,cout,n", [(64, 338, 9), (32, 64, 70)])
+def test_output_transform_pools_for_a_global_average_tail(gpu, monkeypatch, cin, cout, n):
+    """Conv -> ELU -> BN -> GlobalAveragePooling3D -> Softmax with the convolution on conv_wino.hip: the output transform adds up
+    the 125 values of a (frame, channel) itself (k_wino_out<P, true>) and the 5^3 activation is never written.  Same summation
+    order as the pooling kernels: probabilities AND logits equal the unfused tail's bit for bit; against the oracle as usual."""
+    monkeypatch.setenv("TH_WINOGRAD", "1")
+    cfg, w, layer = _one_layer(cin, cout, seed=cin * 3 + cout, pre=False)
+    rng = np.random.default_rng(n)
+    frames = (rng.standard_normal((n, 5, 5, 5, cin)) * (rng.random((n, 5, 5, 5, cin)) < 0.5)).astype(np.float32)
+    fused = engine.HipFrameModel.from_keras(cfg, w, device=gpu)
+    labels = [s["label"] for s in fused.steps()]
+    assert any("wino_out + global_avg_pool" in l for l in labels) and not any("k_gap_softmax" in l for l in labels), labels
+    with pytest.raises(_lib.TimedHipError):
+        fused.predict(frames[:1]); fused.fetch(layer, 1, (5, 5, 5, cout))          # that tensor does not exist
+    monkeypatch.setenv("TH_NO_TAIL_FUSE", "1")
+    plain = engine.HipFrameModel.from_keras(cfg, w, device=gpu)
+    assert not any("global_avg_pool (" in s["label"] for s in plain.steps())
+    for k in (1, n):
+        assert np.array_equal(fused.predict(frames[:k]), plain.predict(frames[:k]))
+        assert np.array_equal(fused.predict(frames[:k], logits=True), plain.predict(frames[:k], logits=True))
+    ref = cnn_oracle.forward(cfg, w, frames[:8], np.float64)
+    np.testing.assert_allclose(fused.predict(frames[:8]), ref, atol=TIGHT, rtol=0)
     fused.close(); plain.close()

@@ -148,7 +148,8 @@ void conv_wino_pack_weights(const ConvWinoPlan& p, const float* w_keras, float* 
 // V, M: scratch for ceil(n / 64) * 64 frames (v_fpf / m_fpf floats each).  Three launches = three plan steps.
 int launch_wino_in(hipStream_t s, int64_t n, const ConvWinoPlan& p, TView in, float* V, PreOp pre);
 int launch_wino_gemm(hipStream_t s, int64_t n, const ConvWinoPlan& p, const float* V, float* M, const float* wpk);
-int launch_wino_out(hipStream_t s, int64_t n, const ConvWinoPlan& p, const float* M, TView out, const float* bias, PostOps post);
+// gap: `out` is the [n][Cout] tensor of a GlobalAveragePooling3D that is the layer's only reader (the 5^3 activation is not written)
+int launch_wino_out(hipStream_t s, int64_t n, const ConvWinoPlan& p, const float* M, TView out, const float* bias, PostOps post, bool gap = false);
 // launch_wino_out of layer p + launch_wino_in of the NEXT Winograd layer in one pass (the tensor between them is not written)
 int launch_wino_mid(hipStream_t s, int64_t n, const ConvWinoPlan& p, const float* M, float* V_next, const float* bias, PostOps post);
 

@@ -570,6 +570,7 @@ int plan(th_model* m) {
     th_model* M = m;
     int fused_tail = -1;     // the final Softmax node when it was folded into the GlobalAveragePooling3D step
     std::set<int> wino_in_done;   // Winograd convolutions whose input transform was fused into the previous layer's output transform
+    std::set<int> gap_done;       // GlobalAveragePooling3D nodes already computed by the output transform of the Winograd layer in front
     // does convolution i run on conv_wfused.hip?  (asked twice: by the layout pre-pass below and when its step is emitted)
     auto wf_plan_for = [&](int i, ConvWfPlan* fp) -> bool {
         const Node& n = N[i];
@@ -720,6 +721,31 @@ int plan(th_model* m) {
                             add_step(o);
                             wino_in_done.insert(next);
                             N[dst].materialised = false;        // th_model_fetch refuses it ("fused away")
+                            continue;
+                        }
+                        // the layer's only reader is a GlobalAveragePooling3D (TIMED's 338-class head): the output transform pools
+                        // (k_wino_out<P, true>), neither the 5^3 activation nor the pooling kernel's pass over it exist
+                        int gp = -1;
+                        if (!getenv("TH_NO_TAIL_FUSE") && dst != M->output_node) {
+                            int cur = dst;
+                            while (N[cur].consumers.size() == 1 && N[N[cur].consumers[0]].op == OP_IDENTITY && N[cur].consumers[0] != M->output_node)
+                                cur = N[cur].consumers[0];
+                            if (N[cur].consumers.size() == 1 && N[N[cur].consumers[0]].op == OP_GAP && N[N[cur].consumers[0]].materialised &&
+                                N[N[cur].consumers[0]].absorbed_by < 0) {
+                                bool single = true;          // every node of the chain has exactly one reader
+                                for (int k = dst; k != cur; k = N[k].consumers[0]) if (N[k].consumers.size() != 1) single = false;
+                                if (single) gp = N[cur].consumers[0];
+                            }
+                        }
+                        if (gp >= 0) {
+                            Step o;
+                            o.out_node = gp;
+                            o.label = n.name + ": wino_out + global_avg_pool (" + std::to_string(wp.P * wp.P) + " points -> bias + epilogue -> mean of the 125 voxels) [k_wino_out]";
+                            o.bytes = 4.0 * ((double)mf / wp.Coutp * Cout + Cout);
+                            o.run = [=](hipStream_t s, int64_t cnt) { return launch_wino_out(s, cnt, wp, Mp(), M->view(gp), dbias, po, true); };
+                            add_step(o);
+                            for (int k = dst; ; k = N[k].consumers[0]) { N[k].materialised = false; if (N[k].consumers[0] == gp) break; }
+                            gap_done.insert(gp);
                             continue;
                         }
                         Step o;
@@ -899,6 +925,23 @@ int plan(th_model* m) {
             case OP_GMP: {
                 const int src = n.in[0];
                 const int is_max = n.op == OP_GMP;
+                if (gap_done.count(i)) {
+                    // pooled by k_wino_out<P, true>; what is left of the tail is the softmax over the pooled logits
+                    if (n.consumers.size() == 1) {
+                        const int sm = n.consumers[0];
+                        if (N[sm].op == OP_ACT && N[sm].ip[0] == ACT_SOFTMAX && sm == M->output_node && N[sm].absorbed_by < 0 && N[sm].materialised) {
+                            st.out_node = sm;
+                            st.label = N[sm].name + ": softmax (logits pooled by the output transform) [k_softmax]";
+                            st.is_final_softmax = true;
+                            st.bytes = 8.0 * n.C;
+                            st.run = [=](hipStream_t s, int64_t cnt) { return launch_softmax(s, cnt, M->view(i), M->view(sm)); };
+                            M->logits_node = i;
+                            fused_tail = sm;
+                            break;
+                        }
+                    }
+                    continue;
+                }
                 // TIMED's tail GlobalAveragePooling3D -> Softmax (the model output): one launch, one wavefront per frame
                 if (!is_max && fuse && n.consumers.size() == 1 && n.C <= 512 && !getenv("TH_NO_TAIL_FUSE")) {
                     const int sm = n.consumers[0];
