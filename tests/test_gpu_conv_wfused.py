@@ -194,3 +194,36 @@ def test_wfused_chunk_blocked_input_is_bit_identical_to_channels_last(gpu, monke
     ref, rl = _run(cfg, weights, frames)
     assert not any("chunk-blocked" in l for l in rl), rl
     assert np.array_equal(got, ref)
+
+
+def _random_block_net(seed):
+    """a random two- or three-convolution net on 10^3 volumes around conv_wfused: random widths (multiples of 4 in, anything
+    out), pointwise or 3x3x3 producers, pre-activation or post-activation chains, optional pool, optional concat"""
+    rng = np.random.default_rng(seed)
+    cin = int(rng.choice([16, 20, 24, 32, 48]))
+    b = synth.KerasGraphBuilder((*SHAPE, cin), seed=seed, bias_std=0.2)
+    x = b.input_name
+    act = lambda t: [b.relu, b.elu, lambda u: b.leaky_relu(u, 0.2)][int(rng.integers(0, 3))](t)
+    for _ in range(int(rng.integers(1, 3))):
+        mid = int(rng.choice([16, 32, 40, 64]))
+        if rng.random() < 0.5:                                       # DenseNet-style: BN -> act -> 1x1x1 -> BN -> act -> 3x3x3, concat
+            y = b.conv3d(act(b.batchnorm(x)), mid, 1, padding="same", use_bias=False)
+            y = b.conv3d(act(b.batchnorm(y)), int(rng.choice([8, 16, 20])), 3, padding="same", use_bias=bool(rng.integers(0, 2)))
+            x = b.concat([x, y])
+        else:                                                        # TIMED-style: 3x3x3 -> act -> BN
+            x = b.batchnorm(act(b.conv3d(x, mid, 3, padding="same")))
+    if rng.random() < 0.5:
+        x = (b.maxpool if rng.random() < 0.5 else b.avgpool)(b.batchnorm(act(b.conv3d(x, int(rng.choice([12, 32, 36])), 3, padding="same"))), 2)
+    cfg, w = b.finish(b.flatten(x))
+    n = int(rng.integers(1, 12))
+    frames = (rng.standard_normal((n, *SHAPE, cin)) * (rng.random((n, *SHAPE, cin)) < 0.5)).astype(np.float32)
+    return cfg, w, frames
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_wfused_random_blocks(gpu, seed):
+    cfg, w, frames = _random_block_net(seed)
+    want = cnn_oracle.forward(cfg, w, frames, np.float32)
+    got, labels = _run(cfg, w, frames, chunk=1 + seed % 4)
+    assert any("k_conv_wf" in l for l in labels), labels
+    assert float(np.abs(got - want).max()) <= 2e-5 * max(1.0, float(np.abs(want).max())), labels
