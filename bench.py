@@ -130,7 +130,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP events (roofline omitted)")
     ap.add_argument("--no-extras", action="store_true", help="skip the e2e / sampler / other-topology legs (N=1 only)")
     ap.add_argument("--e2e-frames", type=int, default=100000, help="frames in the synthetic frame packs of the predict.py leg")
-    ap.add_argument("--e2e-hdf5-frames", type=int, default=20000, help="frames in the synthetic gzip .hdf5 of the predict.py leg")
+    ap.add_argument("--e2e-hdf5-frames", type=int, default=40000, help="frames in the synthetic gzip .hdf5 of the predict.py leg")
     ap.add_argument("--e2e-rotamer-frames", type=int, default=125000,
                     help="uint8 frames in the predict.py --predict_rotamers leg (config 4's per-GPU share: 1 M / 8)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 --pmc child passes (roofline.traffic stays null)")

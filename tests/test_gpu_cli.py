@@ -237,3 +237,43 @@ def test_grouping_batches_per_gpu_call_keeps_every_output_byte(gpu, tmp_path):
     for name, d in outs.items():
         for fn in ("keras_tiny.csv", "keras_tiny.fasta", "keras_tiny.txt", "dataset.fasta", "datasetmap.txt", "encoded_labels.csv"):
             assert (d / fn).read_bytes() == (ref / fn).read_bytes(), (name, fn)
+
+
+def test_frame_pack_rows_through_the_page_locked_staging_ring_keep_every_output_byte(gpu, tmp_path, monkeypatch):
+    """predict.py copies the memory-mapped rows of a frame pack into a ring of page-locked slots (engine.StagingRing, slots reused
+    as predictions complete) before th_predict_async reads them: 23 groups through 5 slots give the files that the mapped rows give
+    (TIMED_STAGING=0), byte for byte, for float32 and uint8 packs; the ring is kept for the next call and closed by
+    design_utils.utils.release_device_memory()."""
+    import sys
+    import warnings
+    from pathlib import Path
+    sys.path.insert(0, os.path.join(os.path.dirname(G), "..", "tools"))
+    import bench_legs
+    import predict
+    from design_utils import utils as du
+    from timed_hip import pack, synth
+    cfg, w = synth.timed_synth(20)
+    mp = tmp_path / "TIMED.pack"
+    mp.write_bytes(pack.keras_to_pack(cfg, w))
+    monkeypatch.setenv("TIMED_STAGING_THREADS", "3")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for gaussian in (True, False):
+            stem = str(tmp_path / ("f32" if gaussian else "u8"))
+            bench_legs.make_frame_pack(stem, 1111, gaussian=gaussian)
+            outs = {}
+            for mode in ("1", "0"):
+                monkeypatch.setenv("TIMED_STAGING", mode)
+                d = tmp_path / f"out_{gaussian}_{mode}"
+                d.mkdir()
+                predict.load_dataset_and_predict([mp], stem + ".framepack", batch_size=50, frames_per_call=50,
+                                                 dataset_map_path=d / "datasetmap.txt", path_to_output=d)
+                outs[mode] = d
+                if mode == "1":
+                    rings = list(du._STAGING_RINGS.values())
+                    assert len(rings) == 1 and rings[0].enabled and sum(rings[0]._pinned) == 5, "the staging ring was not used"
+                    du.release_device_memory()
+                    assert not du._STAGING_RINGS and not rings[0].enabled
+            for fn in ("TIMED.csv", "TIMED.fasta", "TIMED.txt", "dataset.fasta", "datasetmap.txt", "encoded_labels.csv"):
+                assert (outs["1"] / fn).read_bytes() == (outs["0"] / fn).read_bytes(), (gaussian, fn)
+            assert sum(1 for _ in open(outs["1"] / "TIMED.csv")) == 1111

@@ -351,14 +351,45 @@ class _DevicePool:
 _DEVICE_POOL = _DevicePool()
 
 
+# Staging rings (engine.StagingRing: page-locked slots between a mapped frame pack and the GPU) kept between predict calls: building
+# one costs ~50 ms (first-touch faults + page-locking 5 x 227 MB), taking it down 45 ms.  A run takes a ring out of the cache and
+# puts it back when it is done, so two runs never share slots.
+_STAGING_RINGS: dict = {}
+_STAGING_LOCK = __import__("threading").Lock()
+
+
+def take_staging_ring(slots: int, rows: int, frame_shape, dtype, threads: int):
+    from timed_hip import engine
+    key = (int(slots), int(rows), tuple(int(d) for d in frame_shape), np.dtype(dtype).str, int(threads))
+    with _STAGING_LOCK:
+        ring = _STAGING_RINGS.pop(key, None)
+    if ring is None:
+        ring = engine.StagingRing(slots, rows, frame_shape, dtype, threads=threads)
+        ring.key = key
+    return ring
+
+
+def give_back_staging_ring(ring) -> None:
+    with _STAGING_LOCK:
+        if ring.enabled and ring.key not in _STAGING_RINGS:
+            _STAGING_RINGS[ring.key] = ring
+            return
+    ring.close()
+
+
 def release_device_memory(devices=None) -> None:
     """Give back what load_batch_device keeps between calls so that the next call is fast: the pooled batch buffers (up to six of
-    frames_per_call frames each), the GPU decoder's scratch (token arena, ~5 bytes per uncompressed byte of a batch) and the device
+    frames_per_call frames each), the page-locked staging ring of frame-pack runs, the GPU decoder's scratch (token arena, ~5 bytes per uncompressed byte of a batch) and the device
     blocks of closed models (weights / arenas kept for the next load).  predict.py's
     CLI calls it when its run ends; a long-lived process (the UI) calls it when it is done predicting.  No reference counterpart
     (the reference holds no device memory)."""
     from timed_hip import _lib
     _DEVICE_POOL.drain()
+    with _STAGING_LOCK:
+        rings = list(_STAGING_RINGS.values())
+        _STAGING_RINGS.clear()
+    for ring in rings:
+        ring.close()
     lib = _lib.load()
     for d in (range(16) if devices is None else devices):
         lib.th_h5_release_scratch(int(d))

@@ -211,7 +211,35 @@ def _run_groups(models, dataset_path, flat_dataset_map, groups, consume, gpu_dec
 
     host_lock = threading.Lock()       # the host reader's buffer ring is filled by one loader at a time
 
+    # Memory-mapped rows of a frame pack go through a ring of page-locked buffers (engine.StagingRing): the copy to the device
+    # then runs at the PCIe rate instead of the rate at which the driver pins pages it has never seen.  3 groups per model
+    # outstanding + the one waiting to be submitted + the one being filled.  TIMED_STAGING=0 hands out the mapped rows as before.
+    staging = [None]
+
+    def _stage(X):
+        if staging[0] is False or not isinstance(X, np.memmap) or getattr(models[0], "device", None) is None:
+            return X, None
+        if staging[0] is None:
+            staging[0] = False
+            try:
+                from timed_hip import _lib, engine
+                cpus = int(_lib.load().th_host_cpus())
+                ranks_here = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))          # one process per GPU shares the host's cores
+                threads = int(os.environ.get("TIMED_STAGING_THREADS", str(min(8, (cpus - 2) // ranks_here))))
+                if os.environ.get("TIMED_STAGING", "1") != "0" and threads >= 2 and len(groups) > 2:
+                    staging[0] = du.take_staging_ring(3 * len(models) + 2, max_rows, X.shape[1:], X.dtype, threads)
+            except Exception:
+                staging[0] = False
+            if staging[0] is False:
+                return X, None
+        return staging[0].stage(X)
+
     def _load(k):
+        X, y = _load_rows(k)
+        X, slot = _stage(X)
+        return X, y, slot
+
+    def _load_rows(k):
         lo, hi = groups[k]
         if decode_on_gpu[0]:
             # gzip .hdf5: the chunks of this group are inflated ON the GPU that will predict it (th_h5_decode_device) — the
@@ -229,8 +257,18 @@ def _run_groups(models, dataset_path, flat_dataset_map, groups, consume, gpu_dec
                 ring.append(X)
             return X, y
 
-    def finish(ticket, labels):
-        consume(ticket.result(), labels)
+    write_seconds = [0.0, 0.0]
+
+    def finish(ticket, labels, slot=None):
+        import time
+        t0 = time.perf_counter()
+        probs = ticket.result()
+        if slot is not None:
+            staging[0].release(slot)
+        t1 = time.perf_counter()
+        consume(probs, labels)
+        write_seconds[0] += t1 - t0
+        write_seconds[1] += time.perf_counter() - t1
 
     pending = deque()          # tickets submitted to a GPU, oldest first
     writing = deque()          # futures of the writer thread, oldest first
@@ -238,14 +276,33 @@ def _run_groups(models, dataset_path, flat_dataset_map, groups, consume, gpu_dec
     # the writer for longer than a whole group takes on the GPU (4.6 ms per 1024 frames)
     switch = sys.getswitchinterval()
     sys.setswitchinterval(2e-4)
+    completed = False
     try:
-        # (one loader: two of them on GPU-inflated datasets — the host part and the pageable upload of batch g+2 under the inflate
-        # kernels of batch g+1 — were measured at the same 0.38 s per 40 k frames; TIMED_LOADERS is there to try again)
-        _pump(models, groups, load, finish, pending, writing, depth, loaders=max(1, int(os.environ.get("TIMED_LOADERS", "1"))))
+        # Two loaders on GPU-inflated datasets: the host part of batch g+2 (object headers, B-trees, descriptors, ~6 ms of Python
+        # per 4096 frames) and its pageable upload run while the inflate kernels of batch g+1 hold the decoder's scratch set.
+        # Measured on 40 k gzip float64 frames (tools/trace_predict_e2e.py): the loop takes 0.229 s with one loader, 0.178 s with
+        # two — 17.8 ms per 4096 frames, which is the inflate kernels (8 ms) plus the CNN (10.3 ms) one after the other on the
+        # GPU — and 0.19 s with three.  (When the CNN took twice as long the second loader bought nothing.)  One loader elsewhere:
+        # the host reader fills its ring under a lock anyway, and frame packs hand out mapped rows.
+        default_loaders = 2 if decode_on_gpu[0] else 1
+        _pump(models, groups, load, finish, pending, writing, depth,
+              loaders=max(1, int(os.environ.get("TIMED_LOADERS", str(default_loaders)))))
+        completed = True
     finally:
         sys.setswitchinterval(switch)
+        if staging[0]:
+            for ticket, *_rest in pending:           # after an error: nothing may still be copying out of a slot
+                try:
+                    ticket.result()
+                except Exception:
+                    pass
+            if completed:
+                du.give_back_staging_ring(staging[0])    # kept for the next call; du.release_device_memory() (the CLI, at its end) closes it
+            else:
+                staging[0].close()
     if os.environ.get("TIMED_PIPELINE_TRACE"):
-        print(f"[pipeline] load_batch calls took {load_seconds[0]:.3f} s in the loader thread", file=sys.stderr)
+        print(f"[pipeline] load_batch calls took {load_seconds[0]:.3f} s in the loader thread(s); the writer thread waited {write_seconds[0]:.3f} s "
+              f"for results and spent {write_seconds[1]:.3f} s formatting / appending", file=sys.stderr)
     del ring[:]
 
 
@@ -261,7 +318,7 @@ def _pump(models, groups, load, finish, pending, writing, depth, loaders=1):
         for k in range(len(groups)):
             if trace:
                 t0 = clock()
-            X, y = ahead.popleft().result()
+            X, y, *extra = ahead.popleft().result()
             if k + loaders < len(groups):
                 ahead.append(loader.submit(load, k + loaders))
             if trace:
@@ -274,7 +331,7 @@ def _pump(models, groups, load, finish, pending, writing, depth, loaders=1):
                 writing.popleft().result()
             if trace:
                 t2 = clock(); t_wait += t2 - t1
-            pending.append((models[k % len(models)].predict_async(X), y))
+            pending.append((models[k % len(models)].predict_async(X), y, *extra))
             del X
             if trace:
                 t_submit += clock() - t2

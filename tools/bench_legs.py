@@ -217,6 +217,8 @@ def predict_py_e2e(cfg, weights, n_pack=20000, n_hdf5=2000, batch_size=500, work
         elif n_hdf5 > 0:
             res["predict_py_hdf5_gzip_f64_fps"] = None
             res["hdf5_note"] = "no h5py in this image to write the synthetic .hdf5"
+    from design_utils import utils as du
+    du.release_device_memory()          # what predict.py's CLI does at its end: pooled batch buffers, decoder scratch, staging rings
     return res
 
 

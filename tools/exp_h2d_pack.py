@@ -1,0 +1,93 @@
+"""Experiment: how fast can float32 frames of a memory-mapped frame pack reach the GPU?  (a) predict_async straight from the
+mapped rows, (b) from an anonymous copy, (c) after th_host_register of the mapping, (d) through a ring of page-locked
+buffers filled by T copy threads.  Prints frames/s of each (kernels included: TIMED at ~390 k frames/s is not the limit)."""
+import os, sys, time, json, tempfile, ctypes as C
+from concurrent.futures import ThreadPoolExecutor
+ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "timed-design_amd")); sys.path.insert(0, os.path.join(ROOT, "tools"))
+import numpy as np
+from timed_hip import synth, pack, engine, _lib
+import bench_legs as b
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 30000
+G = 1024
+cfg, w = synth.timed_synth(20)
+m = engine.HipFrameModel(pack.keras_to_pack(cfg, w))
+td = tempfile.mkdtemp()
+stem = os.path.join(td, "f32")
+b.make_frame_pack(stem, n, gaussian=True)
+lib = _lib.load()
+res = {}
+
+def run(tag, get):
+    for rep in range(2):
+        t0 = time.perf_counter()
+        pend = []
+        for lo in range(0, n, G):
+            pend.append(m.predict_async(get(lo, min(n, lo + G))))
+            if len(pend) >= 3:
+                pend.pop(0).result()
+        for p_ in pend:
+            p_.result()
+        dt = time.perf_counter() - t0
+        res[f"{tag}_{rep}"] = round(n / dt)
+
+libc = C.CDLL(None, use_errno=True)
+libc.madvise.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+for advice, name in ((22, "populate_read"), (3, "willneed")):
+    X = np.load(stem + ".frames.npy", mmap_mode="r")
+    spent = [0.0]
+    def get_adv(lo, hi, X=X, advice=advice):
+        t0 = time.perf_counter()
+        a = X[lo:hi]
+        start = a.ctypes.data & ~4095
+        rc = libc.madvise(start, a.ctypes.data + a.nbytes - start, advice)
+        if rc: res[name + "_errno"] = C.get_errno()
+        spent[0] += time.perf_counter() - t0
+        return a
+    run("mapped_" + name, get_adv)
+    res[name + "_madvise_s_total_2passes"] = round(spent[0], 3)
+    del X
+X = np.load(stem + ".frames.npy", mmap_mode="r")
+run("mapped", lambda lo, hi: X[lo:hi])
+A = np.array(X)
+run("anonymous", lambda lo, hi: A[lo:hi])
+del A
+# (c) register the mapping
+addr = X.ctypes.data
+t0 = time.perf_counter()
+rc = lib.th_host_register(C.c_void_p(addr), X.nbytes)
+res["register_s"] = round(time.perf_counter() - t0, 3); res["register_rc"] = rc
+if rc == 0:
+    run("registered", lambda lo, hi: X[lo:hi])
+    t0 = time.perf_counter(); lib.th_host_unregister(C.c_void_p(addr)); res["unregister_s"] = round(time.perf_counter() - t0, 3)
+# (d) pinned ring with T copy threads
+frame = int(np.prod(X.shape[1:]))
+for T in (2, 4, 8):
+    R = 6
+    ptrs = []
+    t0 = time.perf_counter()
+    for _ in range(R):
+        p_ = C.c_void_p(); _lib.check(lib.th_host_alloc(G * frame * 4, C.byref(p_))); ptrs.append(p_)
+    res[f"ring_alloc_s_T{T}"] = round(time.perf_counter() - t0, 3)
+    bufs = [np.ctypeslib.as_array(C.cast(p_, C.POINTER(C.c_float)), shape=(G,) + X.shape[1:]) for p_ in ptrs]
+    pool = ThreadPoolExecutor(T)
+    def fill(slot, lo, hi):
+        dst = bufs[slot][:hi - lo]
+        cuts = np.linspace(0, hi - lo, T + 1).astype(int)
+        fs = [pool.submit(np.copyto, dst[cuts[i]:cuts[i + 1]], X[lo + cuts[i]:lo + cuts[i + 1]]) for i in range(T)]
+        for f in fs: f.result()
+        return dst
+    for rep in range(2):
+        t0 = time.perf_counter()
+        pend = []
+        k = 0
+        for lo in range(0, n, G):
+            if len(pend) >= R - 2:
+                pend.pop(0).result()
+            pend.append(m.predict_async(fill(k % R, lo, min(n, lo + G)))); k += 1
+        for p_ in pend: p_.result()
+        res[f"pinned_ring_T{T}_{rep}"] = round(n / (time.perf_counter() - t0))
+    pool.shutdown()
+    for p_ in ptrs: lib.th_host_free(p_)
+print(json.dumps(res))
