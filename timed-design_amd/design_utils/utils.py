@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import contextlib
 import os
+import threading
 import typing as t
 import warnings
 from collections.abc import Mapping
@@ -454,8 +455,13 @@ def load_batch_device(dataset_path: Path, data_point_batch, device: int = 0):
         return None
 
 
+_LOAD_TRACE = [0.0, 0.0, 0.0, 0.0]       # TIMED_PIPELINE_TRACE: seconds in (group links, resolve_many, buffer, decode) of load_batch_device
+
+
 def _load_batch_device(dataset, data_point_batch, n, device):
+    import time
     from timed_hip import engine, h5lite
+    t_0 = time.perf_counter()
     if True:
         dims = tuple(int(d) for d in np.asarray(dataset.attrs["frame_dims"]).ravel())
         gaussian = bool(dataset.attrs["voxels_as_gaussian"])
@@ -473,7 +479,9 @@ def _load_batch_device(dataset, data_point_batch, n, device):
             addrs[i] = links.get(str(residue_id), -1)
         if np.any(addrs < 0):
             return None
+        t_1 = time.perf_counter()
         res = h5lite.resolve_many(dataset, addrs, num_attr="encoded_residue", num_len=20)
+        t_2 = time.perf_counter()
         if res is None or not np.all((res["status"] & 3) == 3):
             return None
         g = res["geom"]
@@ -490,13 +498,18 @@ def _load_batch_device(dataset, data_point_batch, n, device):
         else:
             return None
         nbytes = n * int(np.prod(dims)) * np.dtype(dtype).itemsize
+        t_3 = time.perf_counter()
         buf = _DEVICE_POOL.acquire(nbytes, device)
+        t_4 = time.perf_counter()
         ok = False
         try:
             ok = h5lite.decode_resolved_device(dataset, res, buf.ptr, device, as_float32=as_f32)
         finally:
             if not ok:
                 _DEVICE_POOL.release(buf)
+        t_5 = time.perf_counter()
+        for i, dt in enumerate((t_1 - t_0, t_2 - t_1, t_4 - t_3, t_5 - t_4)):
+            _LOAD_TRACE[i] += dt
         if not ok:
             return None
         return engine.DeviceFrames(buf, (n, *dims), dtype, on_release=_DEVICE_POOL.release), np.asarray(res["num"], dtype=float)

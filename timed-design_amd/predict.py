@@ -303,6 +303,11 @@ def _run_groups(models, dataset_path, flat_dataset_map, groups, consume, gpu_dec
     if os.environ.get("TIMED_PIPELINE_TRACE"):
         print(f"[pipeline] load_batch calls took {load_seconds[0]:.3f} s in the loader thread(s); the writer thread waited {write_seconds[0]:.3f} s "
               f"for results and spent {write_seconds[1]:.3f} s formatting / appending", file=sys.stderr)
+        if decode_on_gpu[0] and any(du._LOAD_TRACE):
+            a = du._LOAD_TRACE
+            print(f"[pipeline] load_batch_device: group links {a[0]:.3f} s, object headers (resolve_many) {a[1]:.3f} s, device buffer {a[2]:.3f} s, "
+                  f"B-trees + upload + inflate {a[3]:.3f} s", file=sys.stderr)
+            a[:] = [0.0] * 4
     del ring[:]
 
 
