@@ -185,6 +185,38 @@ def test_full_size_properties(gpu):
     assert np.array_equal(fast.predict(frames), a)
 
 
+def test_fused_dense_tail_is_bit_identical(gpu, cnn_golden, monkeypatch):
+    """DenseCPD's tail BatchNormalization -> ReLU -> GlobalAveragePooling3D -> Dense -> Softmax runs as ONE launch (k_tail_dense:
+    one wavefront per frame, the pooled vector in LDS): probabilities AND logits equal the five-launch path bit for bit (same
+    per-element chain, summation, fmaf and reduction order), for one frame and for a count that is not a multiple of the 4 frames
+    per workgroup; the pooled vector and the logits stay fetchable, the elementwise nodes in front are fused away"""
+    z, meta = cnn_golden
+    cfg, weights, frames = _build(meta, "densecpd20")
+    frames = np.concatenate([frames, frames[:3][::-1]])
+    fused = engine.HipFrameModel.from_keras(cfg, weights, device=gpu)
+    labels = [s["label"] for s in fused.steps()]
+    assert sum("k_tail_dense" in l for l in labels) == 1, labels
+    assert "2 elementwise + global_avg_pool + dense + softmax" in labels[-1]
+    assert not any(l.endswith((": softmax", ": dense", ": global_avg_pool")) for l in labels)
+    monkeypatch.setenv("TH_NO_TAIL_FUSE", "1")
+    plain = engine.HipFrameModel.from_keras(cfg, weights, device=gpu)
+    assert not any("k_tail_dense" in s["label"] for s in plain.steps())
+    assert [s["label"] for s in plain.steps()][-1].endswith(": softmax")
+    for n in (1, len(frames)):
+        assert np.array_equal(fused.predict(frames[:n]), plain.predict(frames[:n]))
+        assert np.array_equal(fused.predict(frames[:n], logits=True), plain.predict(frames[:n], logits=True))
+    np.testing.assert_allclose(fused.predict(frames[:8]), z["densecpd20__torch64"][:8], atol=TOL, rtol=0)
+    gap = next(l["name"] for l in cfg["config"]["layers"] if l["class_name"] == "GlobalAveragePooling3D")
+    dense = next(l["name"] for l in cfg["config"]["layers"] if l["class_name"] == "Dense")
+    c = weights[dense][0].shape[0]
+    fused.predict(frames[:4]); plain.predict(frames[:4])
+    assert np.array_equal(fused.fetch(gap, 4, (c,)), plain.fetch(gap, 4, (c,)))
+    relu = [l["name"] for l in cfg["config"]["layers"] if l["class_name"] == "ReLU"][-1]
+    with pytest.raises(_lib.TimedHipError, match="fused away"):
+        fused.fetch(relu, 1, (1,))
+    fused.close(); plain.close()
+
+
 @pytest.mark.parametrize("name", ["timed20", "timed338"])
 def test_fused_gap_softmax_tail_is_bit_identical(gpu, cnn_golden, monkeypatch, name):
     """TIMED's tail GlobalAveragePooling3D -> Softmax runs as ONE launch (k_gap_softmax: one wavefront per frame, 20 or 338

@@ -93,6 +93,8 @@ int launch_dense(hipStream_t s, int64_t n, TView in, TView out, const float* w, 
 int launch_softmax(hipStream_t s, int64_t n, TView in, TView out);
 // GlobalAveragePooling3D -> Softmax in one launch (<= 512 channels): writes the pooled logits and the probabilities
 int launch_gap_softmax(hipStream_t s, int64_t n, TView in, TView logits, TView probs);
+int launch_tail_dense(hipStream_t s, int64_t n, TView in, PostOps pre, TView pooled, TView logits, TView probs, const float* w,
+                      const float* bias, PostOps post, int softmax);
 int launch_copy(hipStream_t s, int64_t n, TView in, TView out);
 int launch_add(hipStream_t s, int64_t n, TView a, TView b, TView out);
 int launch_synth_frames(hipStream_t s, float* d, int64_t n, int side, int channels, int atoms, uint64_t seed);

@@ -245,6 +245,59 @@ __global__ void __launch_bounds__(256) k_gap_softmax(int64_t n, TView in, TView 
     }
 }
 
+// ---- [BN / activation]* -> GlobalAveragePooling3D -> Dense -> Softmax tail in ONE launch: one wavefront per frame ------------
+// (DenseCPD's head: BatchNormalization -> ReLU -> GlobalAveragePooling3D -> Dense(20) -> Softmax; SURVEY Appendix A.)  Every stage
+// keeps the arithmetic AND the order of the kernel it replaces — th_post per element as k_eltwise, the voxel-order sum / V of
+// k_global_pool, k_dense's fmaf chain over the features, k_softmax's lane-partial + xor-shuffle reductions — so pooled values,
+// logits and probabilities are bit-identical to the five-launch path (tested).  The pooled vector lives in the wave's LDS row.
+__global__ void __launch_bounds__(256) k_tail_dense(int64_t n, TView in, PostOps pre, TView pooled, TView logits, TView probs,
+                                                     const float* __restrict__ w, const float* __restrict__ bias, PostOps post,
+                                                     int softmax) {
+    extern __shared__ float tail_lds[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int F = in.C, V = in.D * in.H * in.W, O = logits.C;
+    const int64_t f = (int64_t)blockIdx.x * (blockDim.x >> 6) + wv;
+    if (f >= n) return;                                  // (no workgroup barrier below: a wave works alone on its frame)
+    float* pw = tail_lds + (size_t)wv * F;
+    for (int c = lane; c < F; c += 64) {
+        const float* p = in.p + f * in.fs + in.coff + c;
+        float s = 0.f;
+        for (int v = 0; v < V; ++v) s += th_post(p[(int64_t)v * in.cs], c, pre);
+        s = s / (float)V;
+        pw[c] = s;
+        pooled.p[f * pooled.fs + pooled.coff + c] = s;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float x[8];
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int o = lane + 64 * k;
+        x[k] = -INFINITY;
+        if (o < O) {
+            float acc = bias ? bias[o] : 0.f;
+            for (int j = 0; j < F; ++j) acc = fmaf(pw[j], w[(int64_t)j * O + o], acc);
+            x[k] = th_post(acc, o, post);
+            logits.p[f * logits.fs + logits.coff + o] = x[k];
+            m = fmaxf(m, x[k]);
+        }
+    }
+    if (!softmax) return;
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (lane + 64 * k < O) s += expf(x[k] - m);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int o = lane + 64 * k;
+        if (o < O) probs.p[f * probs.fs + probs.coff + o] = expf(x[k] - m) / s;
+    }
+}
+
 // ---- synthetic frames generated on the device (bench: keeps 22 GB of input off PCIe) ----------
 __device__ inline uint32_t mix32(uint64_t x) {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
@@ -332,6 +385,15 @@ int launch_softmax(hipStream_t s, int64_t n, TView in, TView out) {
 int launch_gap_softmax(hipStream_t s, int64_t n, TView in, TView logits, TView probs) {
     if (n <= 0) return TH_OK;
     hipLaunchKernelGGL(k_gap_softmax, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, n, in, logits, probs);
+    LAUNCH_CHECK();
+    return TH_OK;
+}
+int launch_tail_dense(hipStream_t s, int64_t n, TView in, PostOps pre, TView pooled, TView logits, TView probs, const float* w,
+                      const float* bias, PostOps post, int softmax) {
+    if (n <= 0) return TH_OK;
+    const size_t lds = (size_t)4 * in.C * sizeof(float);
+    hipLaunchKernelGGL(k_tail_dense, dim3((unsigned)((n + 3) / 4)), dim3(256), lds, s, n, in, pre, pooled, logits, probs, w, bias, post,
+                       softmax);
     LAUNCH_CHECK();
     return TH_OK;
 }

@@ -571,6 +571,7 @@ int plan(th_model* m) {
     int fused_tail = -1;     // the final Softmax node when it was folded into the GlobalAveragePooling3D step
     std::set<int> wino_in_done;   // Winograd convolutions whose input transform was fused into the previous layer's output transform
     std::set<int> gap_done;       // GlobalAveragePooling3D nodes already computed by the output transform of the Winograd layer in front
+    std::set<int> tail_done;      // nodes computed by a k_tail_dense step ([BN / act]* -> GAP -> Dense -> Softmax in one launch)
     // does convolution i run on conv_wfused.hip?  (asked twice: by the layout pre-pass below and when its step is emitted)
     auto wf_plan_for = [&](int i, ConvWfPlan* fp) -> bool {
         const Node& n = N[i];
@@ -609,10 +610,71 @@ int plan(th_model* m) {
             if (shared) continue;
             sn.blk = 4;
         }
+    // DenseCPD's tail [BatchNormalization / activation]* -> GlobalAveragePooling3D -> Dense -> Softmax (the model output) as ONE
+    // launch, one wavefront per frame (k_tail_dense).  Called at the first node of the chain; fills *st and returns 1 when the
+    // pattern holds (0: no, < 0: error).  The pooled vector and the logits are still written to their nodes' buffers; the
+    // elementwise nodes in front of the pooling are fused away.
+    auto try_dense_tail = [&](int first, Step* st) -> int {
+        if (!fuse || getenv("TH_NO_TAIL_FUSE")) return 0;
+        std::vector<int> chain;
+        int j = first;
+        while ((N[j].op == OP_BN || (N[j].op == OP_ACT && N[j].ip[0] != ACT_SOFTMAX)) && (int)chain.size() < TH_MAX_POST) {
+            if (N[j].absorbed_by >= 0 || !N[j].materialised || N[j].consumers.size() != 1 || j == M->output_node) return 0;
+            chain.push_back(j);
+            j = N[j].consumers[0];
+        }
+        const int gp = j;
+        if (N[gp].op != OP_GAP || gap_done.count(gp) || N[gp].absorbed_by >= 0 || !N[gp].materialised || N[gp].consumers.size() != 1 ||
+            gp == M->output_node || N[gp].C > 2048)
+            return 0;
+        const int dn = N[gp].consumers[0];
+        if (N[dn].op != OP_DENSE || !fus.count(dn) || N[dn].C > 512 || N[dn].w[0] < 0) return 0;
+        const ConvFusion& f = fus[dn];
+        if (f.src != gp || !f.pre.empty() || !f.post.empty() || f.pool >= 0 || f.last != dn || !N[dn].materialised) return 0;
+        const int own_act = N[dn].ip[3];
+        int sm = -1;                                         // node that holds the probabilities
+        // (Dense(activation='softmax') keeps its two steps: logits and probabilities share the node there, and a TH_PREDICT_LOGITS
+        // call drops the in-place softmax step)
+        if (own_act == ACT_LINEAR) {
+            if (dn == M->output_node || N[dn].consumers.size() != 1) return 0;
+            sm = N[dn].consumers[0];
+            if (!(N[sm].op == OP_ACT && N[sm].ip[0] == ACT_SOFTMAX && sm == M->output_node && N[sm].absorbed_by < 0 && N[sm].materialised)) return 0;
+        } else return 0;
+        const int src = N[chain.empty() ? gp : chain[0]].in[0];
+        if (N[src].blk || !N[src].materialised || N[src].buf < 0) return 0;
+        const Node& gn = N[gp];
+        if (gn.cs != gn.C || gn.coff != 0) return 0;         // k_dense's contract: a contiguous feature vector
+        PostOps pre, post;
+        int rc;
+        for (int x : chain) if ((rc = add_post(M, &pre, N[x]))) return rc < 0 ? rc : 0;
+        const int F = gn.C, O = N[dn].C;
+        if (M->blob_count[N[dn].w[0]] != (size_t)F * O) return 0;   // (the Dense case reports the mismatch)
+        float *dw = nullptr, *dbias = nullptr;
+        if ((rc = upload(M, M->blob_host[N[dn].w[0]], (size_t)F * O, &dw))) return rc;
+        if (N[dn].ip[2]) {
+            if (N[dn].w[1] < 0) return 0;
+            if ((rc = upload(M, M->blob_host[N[dn].w[1]], M->blob_count[N[dn].w[1]], &dbias))) return rc;
+        }
+        const int V = N[src].D * N[src].H * N[src].W;
+        st->out_node = sm;
+        st->flops = st->exec_flops = 2.0 * F * O;
+        st->bytes = 4.0 * ((double)V * N[src].C + F + 2.0 * O);
+        st->label = N[first].name + ": " + (chain.empty() ? "" : std::to_string(chain.size()) + " elementwise + ") +
+                    "global_avg_pool + dense + softmax [k_tail_dense]";
+        st->run = [=](hipStream_t s, int64_t cnt) {
+            return launch_tail_dense(s, cnt, M->view(src), pre, M->view(gp), M->view(dn), M->view(sm), dw, dbias, post, 1);
+        };
+        M->logits_node = dn;
+        for (int x : chain) { tail_done.insert(x); N[x].materialised = false; }   // th_model_fetch refuses them ("fused away")
+        tail_done.insert(gp); tail_done.insert(dn); tail_done.insert(sm);
+        tail_done.erase(first);
+        return 1;
+    };
     for (int i = 0; i < nn; ++i) {
         Node& n = N[i];
         const bool emits = fus.count(i) || n.absorbed_by < 0;
         if (!emits) continue;
+        if (tail_done.count(i)) continue;
         Step st;
         st.out_node = i;
         switch (n.op) {
@@ -888,6 +950,7 @@ int plan(th_model* m) {
             case OP_ACT: {
                 const int src = n.in[0];
                 if (i == fused_tail) continue;                 // computed by the k_gap_softmax step of its input
+                if (int rc = try_dense_tail(i, &st)) { if (rc < 0) return rc; break; }
                 if (n.op == OP_ACT && n.ip[0] == ACT_SOFTMAX) {
                     st.label = n.name + ": softmax";
                     st.is_final_softmax = i == M->output_node;
@@ -942,6 +1005,7 @@ int plan(th_model* m) {
                     }
                     continue;
                 }
+                if (!is_max) if (int rc = try_dense_tail(i, &st)) { if (rc < 0) return rc; break; }
                 // TIMED's tail GlobalAveragePooling3D -> Softmax (the model output): one launch, one wavefront per frame
                 if (!is_max && fuse && n.consumers.size() == 1 && n.C <= 512 && !getenv("TH_NO_TAIL_FUSE")) {
                     const int sm = n.consumers[0];
