@@ -198,6 +198,15 @@ int th_sampler_draw(th_sampler* s, int64_t n_keys, const int64_t* row_off, int64
  * 'nan') into out; dtype is TH_F16 (preformatted table), TH_F32 or TH_F64.  Returns the number of bytes written,
  * or a negative TH_E* code (cap too small: 28 bytes per value always suffice). */
 int64_t th_format_csv(const void* data, int dtype, int64_t n, int64_t k, char* out, int64_t cap);
+/* The same text for a float32 matrix, formatted ON THE DEVICE (one lane per value): np.savetxt(f, y_pred_batch, delimiter=",") of
+ * predict.py:145-146 — the full-precision rotamer matrix, 338 values per residue, ~1 GB of text per 125 000 residues.  rows: host
+ * memory, [n, k] float32; out: host memory, cap >= 25 n k.  Every finite non-negative float32 below 2^24 (every probability) is
+ * exactly 24 characters in '%.18e' form, so the text is 25 n k bytes (returned).  TH_EUNSUP when a value does not have that form
+ * (negative, NaN, infinite, >= 2^24): the caller formats the block with th_format_csv instead — same bytes for every value both
+ * accept (csrc/fmt_e18_f32.h is compiled for host and device).  Keeps a stream and two device buffers for `device` between calls;
+ * th_format_csv_device_release gives them back.  Serialised internally (one formatter per process). */
+int64_t th_format_csv_device(int device, const float* rows, int64_t n, int64_t k, char* out, int64_t cap);
+int th_format_csv_device_release(void);
 /* argmax + residue letter per row: replaces max_idx = np.argmax(prediction_matrix, axis=1) and the per-residue string
  * appends of extract_sequence_from_pred_matrix — design_utils/utils.py:659, :689-692.  matrix [n, k] of dtype TH_F16 /
  * TH_F32 / TH_F64; np.argmax rules (first maximum; the first NaN of a row wins).  letters_out[i] = col_letters[argmax_i]

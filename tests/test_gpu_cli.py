@@ -205,6 +205,77 @@ def test_predict_rotamer_mode_end_to_end(gpu, tmp_path):
                                          dataset_map_path=tmp_path / "datasetmap.txt", path_to_output=tmp_path)
 
 
+def test_device_csv_formatter_equals_the_host_formatter(gpu):
+    """th_format_csv_device (one GPU lane per float32 value, fixed 25-byte records) against th_format_csv — itself pinned to
+    np.savetxt / Python's '%.18e' in tests/test_textio.py: probabilities (softmax rows of 338), every non-negative finite bit
+    pattern class below 2^24 (all exponents, subnormals, ties), sizes around the 256-value workgroup and the 4-byte store tail;
+    a block with a negative, NaN, infinite or large value is declined (TH_EUNSUP) and textio falls back to the host threads
+    for it — same bytes either way."""
+    import ctypes as C
+    from timed_hip import _lib, textio
+    lib = _lib.load()
+    rng = np.random.default_rng(23)
+
+    def dev(x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        x2 = x.reshape(-1, 1) if x.ndim == 1 else x
+        out = np.empty(x2.size * 25 + 8, np.uint8)
+        got = lib.th_format_csv_device(gpu, x2.ctypes.data_as(C.c_void_p), x2.shape[0], x2.shape[1], out.ctypes.data_as(C.c_void_p), out.size)
+        return got, out[:max(got, 0)].tobytes()
+
+    z = rng.standard_normal((1000, 338)).astype(np.float32) * 4
+    rot = np.exp(z - z.max(1, keepdims=True)); rot = (rot / rot.sum(1, keepdims=True)).astype(np.float32)
+    for x in (rot, rot[:1], rot[:3, :5], rot[:257, :1], rot[:1, :255], rot[:1, :257], rot[:7, :37]):
+        got, text = dev(x)
+        assert got == x.size * 25 and text == textio.format_csv(x)
+    bits = rng.integers(0, 151 << 23, 300000, dtype=np.uint64).astype(np.uint32)          # non-negative, below 2^24
+    got, text = dev(bits.view(np.float32))
+    assert got == bits.size * 25 and text == textio.format_csv(bits.view(np.float32))
+    ties = np.array([m / 2.0 ** k for k in range(1, 80) for m in range(1, 1 << 12, 2) if len(str(m * 5 ** k)) == 20], dtype=np.float32)
+    got, text = dev(ties)
+    assert got == ties.size * 25 and text == textio.format_csv(ties)
+    edge = np.array([0.0, 1.0, 0.5, 1e-45, 1.1754944e-38, 16777215.0, 0.99999994, 9.9999999e-5, 8388607.5], dtype=np.float32)
+    got, text = dev(edge)
+    assert got == edge.size * 25 and text == textio.format_csv(edge)
+    for bad in (-0.0, -1e-3, np.nan, np.inf, 16777216.0):
+        x = rot[:4].copy(); x[2, 17] = bad
+        got, _ = dev(x)
+        assert got == _lib.TH_EUNSUP, (bad, got)
+        with np.errstate(all="ignore"):
+            assert textio.format_csv(x, device=gpu) == textio.format_csv(x)            # the declined block comes from the host threads
+    assert textio.format_csv(rot, device=gpu) == textio.format_csv(rot)
+    assert textio.format_csv(rot.astype(np.float64), device=gpu) == textio.format_csv(rot.astype(np.float64))   # float64: host only
+    assert lib.th_format_csv_device_release() == 0
+    got, text = dev(rot[:9])                                                             # scratch comes back after a release
+    assert got == 9 * 338 * 25 and text == textio.format_csv(rot[:9])
+
+
+def test_rotamer_matrix_text_is_the_same_from_gpu_and_host_formatters(gpu, tmp_path, monkeypatch):
+    """predict.py --predict_rotamers formats <model>_rot.csv on the GPU (th_format_csv_device); TIMED_GPU_FORMAT=0 keeps the host
+    threads: every output file byte for byte the same"""
+    import warnings
+    import predict
+    from timed_hip import pack, synth
+    data_path = os.path.join(G, "frames_tiny.hdf5")
+    cfg, weights = synth.timed_synth(338, widths=(8, 16), side=7, in_channels=5, seed=4, bias_std=0.1)
+    mp = tmp_path / "ROT.pack"
+    mp.write_bytes(pack.keras_to_pack(cfg, weights))
+    outs = {}
+    for tag, env in (("gpu", "1"), ("host", "0")):
+        monkeypatch.setenv("TIMED_GPU_FORMAT", env)
+        out = tmp_path / tag
+        out.mkdir()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            predict.load_dataset_and_predict([mp], data_path, batch_size=9, predict_rotamers=True,
+                                             dataset_map_path=out / "datasetmap.txt", path_to_output=out)
+        outs[tag] = {f.name: f.read_bytes() for f in sorted(out.iterdir())}
+    assert outs["gpu"].keys() == outs["host"].keys() and "ROT_rot.csv" in outs["gpu"]
+    for name in outs["gpu"]:
+        assert outs["gpu"][name] == outs["host"][name], name
+    assert outs["gpu"]["ROT_rot.csv"].count(b"\n") == 26
+
+
 def test_grouping_batches_per_gpu_call_keeps_every_output_byte(gpu, tmp_path):
     """predict.py hands several reference batches to the GPU at once (frames_per_call): the per-batch appends
     concatenate to the same files, whatever the batch size and wherever a resume starts."""

@@ -31,6 +31,40 @@ def test_full_precision_rows_format_like_numpy(dtype):
     assert textio.format_csv(a) == _np_bytes(a)
 
 
+def _py_lines(x):
+    return "".join("%.18e\n" % v for v in np.asarray(x, dtype=np.float32).tolist()).encode()
+
+
+def test_float32_fixed_point_formatter_equals_python_on_every_kind_of_value():
+    """float32 values take th_fmt_e18_f32 (csrc/fmt_e18_f32.h: exact digits nine at a time from a fixed-point fraction, rounded to
+    nearest / ties to even on the exact value) instead of the general double formatter — the same function the GPU kernel of
+    th_format_csv_device runs.  Against Python's own '%.18e' (what np.savetxt applies): random bit patterns (every exponent,
+    subnormals, NaN / inf / integers >= 2^24 through the fallback), every exponent with edge mantissas in both signs, and
+    constructed TIES — odd m * 2^-k with exactly 20 significant digits, where the 19th digit is decided by round-half-even."""
+    rng = np.random.default_rng(17)
+    bits = rng.integers(0, 2 ** 32, 60000, dtype=np.uint64).astype(np.uint32)
+    with np.errstate(all="ignore"):
+        x = bits.view(np.float32)
+        assert textio.format_csv(x) == _py_lines(x)
+    p = np.concatenate([rng.random(30000, dtype=np.float32), (rng.random(30000) ** 8).astype(np.float32)])
+    assert textio.format_csv(p) == _py_lines(p)
+    sweep = [(s << 31) | (ex << 23) | man for ex in range(255) for man in (0, 1, 2, 3, 0x400000, 0x7fffff, 0x7ffffe, 0x555555, 0x2aaaaa)
+             for s in (0, 1)]
+    x = np.array(sweep, dtype=np.uint32).view(np.float32)
+    assert textio.format_csv(x) == _py_lines(x)
+    ties = [m / 2.0 ** k for k in range(1, 80) for m in range(1, 1 << 12, 2) if len(str(m * 5 ** k)) == 20]
+    assert len(ties) > 2000
+    x = np.array(ties, dtype=np.float64)
+    assert np.array_equal(x.astype(np.float32).astype(np.float64), x)                # all of them ARE float32 values
+    got = textio.format_csv(x.astype(np.float32))
+    assert got == _py_lines(x)
+    digits = [line.split(b"e")[0].replace(b".", b"") for line in got.split(b"\n")[:-1]]
+    assert all(int(d[-1:]) % 2 == 0 for d in digits)                                  # every tie went to the even neighbour
+    special = np.array([1, 10, 100, 0.5, 0.25, 9.5, 99.5, 16777215, 16777216, 33554432, 1e10, 3.4028235e38, 1e-45, 1.1754944e-38, -0.0, 0.0,
+                        123456.789, 8388607.5, 4194303.75, 9.9999999e-5, 0.99999994], dtype=np.float32)
+    assert textio.format_csv(special) == _py_lines(special)
+
+
 def test_probability_matrices_and_shapes():
     rng = np.random.default_rng(6)
     p = rng.dirichlet(np.full(20, 0.3), size=3000).astype(np.float32)

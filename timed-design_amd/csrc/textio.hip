@@ -1,4 +1,5 @@
-// Host-side text formatter for the prediction writers.  No device code.
+// Text formatter for the prediction writers: host code, plus one device kernel for the float32 matrix
+// (th_format_csv_device, at the end of the file).
 //
 // The reference writes probabilities with np.savetxt's default format: every value as '%.18e', ',' between
 // columns, '\n' after each row (design_utils/utils.py:768-771 for the float16-rounded <model>.csv,
@@ -10,6 +11,7 @@
 //     rows split over host threads.
 // NaN is written as 'nan' whatever its sign bit, like Python's % operator.
 #include "common.h"
+#include "fmt_e18_f32.h"
 
 #include <hip/hip_fp16.h>
 
@@ -33,6 +35,12 @@ inline int fmt_e18(double v, char* dst) {
     const std::to_chars_result r = std::to_chars(dst, dst + 32, v, std::chars_format::scientific, 18);
     if (r.ec != std::errc()) return snprintf(dst, 32, "%.18e", v);
     return (int)(r.ptr - dst);
+}
+
+// float32 values: th_fmt_e18_f32 (fmt_e18_f32.h, shared with the device kernel below); what it declines goes through fmt_e18
+inline int fmt_e18_f32(float f, char* dst) {
+    const int n = th_fmt_e18_f32(f, dst);
+    return n > 0 ? n : fmt_e18((double)f, dst);
 }
 
 float half_bits_to_float(uint16_t h) {
@@ -104,7 +112,7 @@ extern "C" int64_t th_format_csv(const void* data, int dtype, int64_t n, int64_t
                     std::memcpy(p, &tab->text[(size_t)h * 32], 28);   // fixed-size copy (entries are <= 25 chars), advance by the real length
                     p += tab->len[h];
                 } else {
-                    p += fmt_e18(load_value(data, dtype, i), p);
+                    p += dtype == TH_F32 ? fmt_e18_f32(((const float*)data)[i], p) : fmt_e18(load_value(data, dtype, i), p);
                 }
                 *p++ = (c + 1 < k) ? ',' : '\n';
             }
@@ -227,5 +235,120 @@ extern "C" int th_csv_fill(const char* text, int64_t len, char delim, int64_t ro
         if (c >= cols || w >= width) TH_FAIL(TH_EINVAL, "th_csv_fill: text does not match the shape th_csv_shape reported");
         out[((size_t)r * cols + c) * width + w++] = ch;
     }
+    return TH_OK;
+}
+
+// ---- th_format_csv_device: the float32 matrix formatted ON THE GPU -------------------------------------------------------------
+// Replaces np.savetxt(f, y_pred_batch, delimiter=",") of predict.py:145-146 for the full-precision rotamer matrix.  Every finite,
+// non-negative float32 below 2^24 — every probability — is exactly 24 characters in '%.18e' form, so value i owns bytes
+// [25 i, 25 i + 25) of the text (its separator included): no prefix sum, no compaction.  One lane per value (th_fmt_e18_f32, the
+// same function the host path calls), a workgroup's 6 400 bytes assembled in LDS and stored as whole dwords.  A value that does not
+// have the fixed form (negative, NaN, infinite, >= 2^24) raises a flag and the call returns TH_EUNSUP: the caller formats that
+// block with th_format_csv.  HBM-bound byte work in principle (4 bytes in, 25 out per value); in practice the digit arrays live in
+// scratch memory and the kernel takes ~0.1 ms per 338 000 values, against 2.2 ms for 13 host threads.
+namespace {
+
+constexpr int kFmtThreads = 256, kFmtBytes = 25;
+
+__global__ void __launch_bounds__(kFmtThreads) k_format_csv_f32(const float* __restrict__ x, long long total, int k, char* __restrict__ out,
+                                                                int* __restrict__ flag) {
+    __shared__ __attribute__((aligned(16))) char sh[kFmtThreads * kFmtBytes];
+    const long long i = (long long)blockIdx.x * kFmtThreads + threadIdx.x;
+    if (i < total) {
+        char t[32];
+        const int len = th_fmt_e18_f32(x[i], t);
+        char* d = sh + threadIdx.x * kFmtBytes;
+        if (len == 24) {
+            for (int j = 0; j < 24; ++j) d[j] = t[j];
+        } else {
+            atomicOr(flag, 1);
+            for (int j = 0; j < 24; ++j) d[j] = '?';
+        }
+        d[24] = (i % k == k - 1) ? '\n' : ',';
+    }
+    __syncthreads();
+    const long long base = (long long)blockIdx.x * (kFmtThreads * kFmtBytes);       // a multiple of 4
+    const long long left = total * kFmtBytes - base;
+    const int nbytes = (int)(left < (long long)(kFmtThreads * kFmtBytes) ? left : (long long)(kFmtThreads * kFmtBytes));
+    const uint32_t* s4 = (const uint32_t*)sh;
+    uint32_t* o4 = (uint32_t*)(out + base);
+    for (int j = threadIdx.x; j < (nbytes >> 2); j += kFmtThreads) o4[j] = s4[j];
+    for (int j = (nbytes & ~3) + threadIdx.x; j < nbytes; j += kFmtThreads) out[base + j] = sh[j];
+}
+
+struct FmtScratch {
+    std::mutex mu;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    float* d_in = nullptr;
+    char* d_out = nullptr;
+    int* d_flag = nullptr;
+    size_t cap_values = 0;
+    void release() {
+        if (device < 0) return;
+        (void)hipSetDevice(device);
+        if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+        (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_flag);
+        stream = nullptr; d_in = nullptr; d_out = nullptr; d_flag = nullptr; cap_values = 0; device = -1;
+    }
+};
+FmtScratch& fmt_scratch() {
+    static FmtScratch* s = new FmtScratch;      // never destroyed: no HIP calls from static destructors
+    return *s;
+}
+
+}  // namespace
+
+extern "C" int64_t th_format_csv_device(int device, const float* rows, int64_t n, int64_t k, char* out, int64_t cap) {
+    if (!rows || n < 0 || k <= 0 || k > 0x7fffffff || (!out && cap > 0)) { th_set_error("th_format_csv_device: bad argument"); return TH_EINVAL; }
+    if (n == 0) return 0;
+    const int64_t total = n * k, bytes = total * kFmtBytes;
+    if (cap < bytes) { th_set_error("th_format_csv_device: buffer of %lld bytes, need %lld (25 per value)", (long long)cap, (long long)bytes); return TH_EINVAL; }
+    FmtScratch& S = fmt_scratch();
+    std::lock_guard<std::mutex> lock(S.mu);
+    if (S.device >= 0 && S.device != device) S.release();
+    HIP_TRY(hipSetDevice(device));
+    if (S.device < 0) {
+        S.device = device;
+        // highest priority: the model's kernels keep every CU busy, and a formatter launch that queues behind them makes the
+        // writer thread wait for milliseconds per group; with priority its few hundred workgroups take the next free slots
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        hipError_t e = hipStreamCreateWithPriority(&S.stream, hipStreamNonBlocking, greatest);
+        if (e == hipSuccess) e = hipMalloc((void**)&S.d_flag, sizeof(int));
+        if (e != hipSuccess) { S.release(); th_set_error("th_format_csv_device: %s", hipGetErrorString(e)); return TH_EHIP; }
+    }
+    if (S.cap_values < (size_t)total) {
+        (void)hipFree(S.d_in); (void)hipFree(S.d_out);
+        S.d_in = nullptr; S.d_out = nullptr; S.cap_values = 0;
+        const size_t want = (size_t)total + (size_t)total / 4;
+        hipError_t e = hipMalloc((void**)&S.d_in, want * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void**)&S.d_out, want * kFmtBytes + 16);
+        if (e != hipSuccess) {
+            (void)hipFree(S.d_in); S.d_in = nullptr;
+            (void)hipGetLastError();
+            th_set_error("th_format_csv_device: hipMalloc: %s", hipGetErrorString(e));
+            return e == hipErrorOutOfMemory ? TH_ENOMEM : TH_EHIP;
+        }
+        S.cap_values = want;
+    }
+    int flag = 0;
+    HIP_TRY(hipMemsetAsync(S.d_flag, 0, sizeof(int), S.stream));
+    HIP_TRY(hipMemcpyAsync(S.d_in, rows, (size_t)total * sizeof(float), hipMemcpyHostToDevice, S.stream));
+    hipLaunchKernelGGL(k_format_csv_f32, dim3((unsigned)((total + kFmtThreads - 1) / kFmtThreads)), dim3(kFmtThreads), 0, S.stream, S.d_in,
+                       (long long)total, (int)k, S.d_out, S.d_flag);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&flag, S.d_flag, sizeof(int), hipMemcpyDeviceToHost, S.stream));
+    HIP_TRY(hipStreamSynchronize(S.stream));
+    if (flag) { th_set_error("th_format_csv_device: a value without the fixed 24-character form (negative, NaN, infinite or >= 2^24)"); return TH_EUNSUP; }
+    HIP_TRY(hipMemcpyAsync(out, S.d_out, (size_t)bytes, hipMemcpyDeviceToHost, S.stream));
+    HIP_TRY(hipStreamSynchronize(S.stream));
+    return bytes;
+}
+
+extern "C" int th_format_csv_device_release(void) {
+    FmtScratch& S = fmt_scratch();
+    std::lock_guard<std::mutex> lock(S.mu);
+    S.release();
     return TH_OK;
 }

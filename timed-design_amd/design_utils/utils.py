@@ -392,6 +392,7 @@ def release_device_memory(devices=None) -> None:
     for ring in rings:
         ring.close()
     lib = _lib.load()
+    lib.th_format_csv_device_release()      # the text formatter's stream and buffers (predict.py --predict_rotamers)
     for d in (range(16) if devices is None else devices):
         lib.th_h5_release_scratch(int(d))
         lib.th_dev_trim(int(d))              # device blocks of closed models, kept for the next load

@@ -78,15 +78,19 @@ class _OutputFiles:
     row order, and the float16 matrix the reference re-reads from the CSV afterwards (predict.py:163).  With a ``sink``
     (sharded runs) the text of this rank's rows is collected in memory instead of being appended to the files."""
 
-    def __init__(self, model_index, model_name, flat_dataset_map, path_to_output, predict_rotamers, codec, resume, sink=None):
+    def __init__(self, model_index, model_name, flat_dataset_map, path_to_output, predict_rotamers, codec, resume, sink=None,
+                 device=None):
         self.model_index, self.model_name = model_index, model_name
         self.flat_dataset_map, self.path_to_output = flat_dataset_map, path_to_output
         self.codec = codec
         self.sink = sink
+        # the GPU that formats the full-precision rotamer matrix (th_format_csv_device); None / TIMED_GPU_FORMAT=0: host threads
+        self.device = device if os.environ.get("TIMED_GPU_FORMAT", "1") != "0" else None
         self.matrix_path = path_to_output / (f"{model_name}_rot.csv" if predict_rotamers else f"{model_name}.csv")
         # rows already in the file (an earlier, interrupted or repeated run) are part of what the reference reads back
         self.must_reread = resume or (self.matrix_path.exists() and self.matrix_path.stat().st_size > 0)
         self._f16_rows = []
+        self._scratch = textio.TextScratch()        # the writer thread's text buffer (page-locked when the GPU formats into it)
         self._codec_matrix = (np.array([codec[k] for k in range(len(codec))], dtype=np.float16) if codec is not None else None)
 
     def paths(self):
@@ -105,12 +109,16 @@ class _OutputFiles:
             self._f16_rows.append(f16)      # (sharded runs take the matrix from the gather instead)
         if self.codec is not None:
             with self._open(self.matrix_path) as f:
-                textio.savetxt_csv(f, probs)            # = np.savetxt(f, y_pred_batch, delimiter=","), full precision
+                # = np.savetxt(f, y_pred_batch, delimiter=","), full precision: 338 '%.18e' values per residue, formatted on the GPU
+                textio.savetxt_csv(f, probs, device=self.device, scratch=self._scratch)     # (float32 rows only; anything else stays on the host threads)
             f16 = self._codec_matrix[np.argmax(probs, axis=1)]      # one-hot residue of the arg-max rotamer
         # the appends of utils.save_outputs_to_file, on arrays: no list-of-lists round trip under the GIL while the
         # submitter thread is waiting to launch the next group
         du.append_outputs(labels, f16, self.flat_dataset_map, self.model_index, self.model_name, self.path_to_output,
                           opener=self._open, write_map=self.sink is None)
+
+    def close(self):
+        self._scratch.close()
 
     def set_gathered(self, probs: np.ndarray):
         """sharded runs, rank 0: the [N, n_classes] float32 rows of every rank in map order (the RCCL gather)"""
@@ -434,6 +442,7 @@ def load_dataset_and_predict(
             if index + 1 < len(models):      # the next model loads while this one runs
                 pending_handles = side.submit(lambda m=models[index + 1]: [loader(Path(m), device=d) for d in device_ids])
             srb = None
+            files = None
             try:
                 for h in handles:
                     if h.n_classes != n_classes:
@@ -444,7 +453,7 @@ def load_dataset_and_predict(
                     srb = side.submit(du.convert_dataset_map_for_srb, flat_dataset_map, model_name, path_to_output)
                 if sharded:
                     files = _OutputFiles(index, model_name, flat_dataset_map, path_to_output, predict_rotamers, codec,
-                                         resume=start_batch > 0, sink=_TextSink())
+                                         resume=start_batch > 0, sink=_TextSink(), device=getattr(handles[0], "device", None))
                     gathered = _predict_sharded(handles[0], gather, rank, world, dataset_path, flat_dataset_map, batch_size,
                                                 start_batch, frames_per_call, files, gpu_decode=gpu_decode)
                     if rank != 0:
@@ -452,11 +461,13 @@ def load_dataset_and_predict(
                     files.set_gathered(gathered)
                 else:
                     files = _OutputFiles(index, model_name, flat_dataset_map, path_to_output, predict_rotamers, codec,
-                                         resume=start_batch > 0)
+                                         resume=start_batch > 0, device=getattr(handles[0], "device", None))
                     _run_groups(handles, dataset_path, flat_dataset_map,
                                 _row_groups(len(flat_dataset_map), batch_size, start_batch, frames_per_call), files.append,
                                 gpu_decode=gpu_decode)
             finally:
+                if files is not None:
+                    files.close()
                 for h in handles:
                     h.close()
                 if srb is not None:

@@ -65,6 +65,8 @@ PROTOTYPES = {
     "th_comm_barrier": (_i, [_vp]),
     "th_voxelise": (_i, [_i, _vp, _vp, _vp, _i64, _vp, _i64, _i, C.c_float, _i, _i, _vp, _i]),
     "th_format_csv": (_i64, [_vp, _i, _i64, _i64, _vp, _i64]),
+    "th_format_csv_device": (_i64, [_i, _vp, _i64, _i64, _vp, _i64]),
+    "th_format_csv_device_release": (_i, []),
     "th_csv_shape": (_i, [C.c_char_p, _i64, C.c_char, _pi64, _pi, _pi]),
     "th_csv_fill": (_i, [C.c_char_p, _i64, C.c_char, _i64, _i, _i, _vp]),
     "th_argmax_letters": (_i, [_vp, _i, _i64, _i64, C.c_char_p, _vp, _vp]),

@@ -12,7 +12,7 @@ from . import _lib
 _DTYPES = {np.dtype(np.float16): _lib.TH_F16, np.dtype(np.float32): _lib.TH_F32, np.dtype(np.float64): _lib.TH_F64}
 
 
-_BLOCK_VALUES = 1 << 18      # values formatted per native call: ~7 MB of text, stays cache/TLB friendly
+_BLOCK_VALUES = 1 << 19      # values formatted per native call: ~13 MB of text (a 1000-row group of the 338-class matrix is one call)
 
 
 def _check(matrix) -> np.ndarray:
@@ -24,8 +24,40 @@ def _check(matrix) -> np.ndarray:
     return np.ascontiguousarray(a)
 
 
-def _blocks(a: np.ndarray):
-    """memoryviews of the text of consecutive row blocks; the scratch buffer is reused between blocks"""
+class TextScratch:
+    """A text buffer kept between calls (a fresh 10 MB array per group costs its page faults every time), page-locked once a device
+    formats into it (the text then comes back at the PCIe rate).  One writer at a time; ``close()`` unlocks it.  The memoryviews
+    _blocks yields out of it are only valid until the next call — every caller writes or copies them at once."""
+
+    def __init__(self):
+        self._buf = None
+        self._pinned = False
+
+    def get(self, cap: int, lib, pin: bool) -> np.ndarray:
+        if self._buf is None or self._buf.size < cap:
+            self.close()
+            self._buf = np.empty(max(cap, 1 << 20), dtype=np.uint8)                # not zero-filled
+        if pin and not self._pinned:
+            self._buf.fill(0)                                                      # resident before it is locked
+            self._pinned = lib.th_host_register(C.c_void_p(self._buf.ctypes.data), self._buf.nbytes) == 0
+        return self._buf
+
+    def close(self) -> None:
+        if self._buf is not None and self._pinned:
+            _lib.load().th_host_unregister(C.c_void_p(self._buf.ctypes.data))
+        self._buf, self._pinned = None, False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _blocks(a: np.ndarray, device=None, scratch: "TextScratch | None" = None):
+    """memoryviews of the text of consecutive row blocks; the scratch buffer is reused between blocks.  With ``device`` (a HIP
+    device index) float32 blocks are formatted on that GPU (th_format_csv_device); a block holding a value without the fixed
+    24-character form — or any failure of the device path — is formatted by the host threads instead: same bytes either way."""
     n, k = a.shape
     if n == 0:
         return
@@ -34,10 +66,20 @@ def _blocks(a: np.ndarray):
         return
     rows = max(1, min(n, _BLOCK_VALUES // k))
     cap = rows * k * 28 + 32
-    buf = np.empty(cap, dtype=np.uint8)          # not zero-filled
     lib = _lib.load()
+    buf = (scratch.get(cap, lib, pin=device is not None and a.dtype == np.float32) if scratch is not None
+           else np.empty(cap, dtype=np.uint8))          # not zero-filled
+    on_device = device is not None and a.dtype == np.float32
     for lo in range(0, n, rows):
         blk = a[lo:lo + rows]
+        if on_device:
+            got = lib.th_format_csv_device(int(device), blk.ctypes.data_as(C.c_void_p), blk.shape[0], k,
+                                           buf.ctypes.data_as(C.c_void_p), cap)
+            if got >= 0:
+                yield memoryview(buf)[:got]
+                continue
+            if got != _lib.TH_EUNSUP:
+                on_device = False           # no device / out of memory: the host threads take over for the rest of the matrix
         got = lib.th_format_csv(blk.ctypes.data_as(C.c_void_p), _DTYPES[a.dtype], blk.shape[0], k,
                                 buf.ctypes.data_as(C.c_void_p), cap)
         if got < 0:
@@ -45,14 +87,15 @@ def _blocks(a: np.ndarray):
         yield memoryview(buf)[:got]
 
 
-def format_csv(matrix: np.ndarray) -> bytes:
+def format_csv(matrix: np.ndarray, device=None) -> bytes:
     """'%.18e' / ',' / '\\n' text of a 2-D float16/32/64 matrix (a 1-D array is one value per line, as np.savetxt)."""
-    return b"".join(bytes(m) for m in _blocks(_check(matrix)))
+    return b"".join(bytes(m) for m in _blocks(_check(matrix), device))
 
 
-def savetxt_csv(f, matrix: np.ndarray) -> None:
-    """Drop-in for ``np.savetxt(f, matrix, delimiter=",")`` on a file opened in text or binary mode."""
-    for m in _blocks(_check(matrix)):
+def savetxt_csv(f, matrix: np.ndarray, device=None, scratch: "TextScratch | None" = None) -> None:
+    """Drop-in for ``np.savetxt(f, matrix, delimiter=",")`` on a file opened in text or binary mode.  ``device``: format float32
+    matrices on that GPU (see ``_blocks``); ``scratch``: a TextScratch the caller keeps between calls."""
+    for m in _blocks(_check(matrix), device, scratch):
         try:
             f.write(m)
         except TypeError:       # text-mode handle
