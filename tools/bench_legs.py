@@ -300,9 +300,10 @@ def sampler_config5(device=0, n_res=300, n_samples=1000, temps=(0.1, 0.5, 1.0), 
     t_gpu = _best(lambda: (sm.load(q), sm.draw([0, n_res], n_samples, uniforms=r, letters=let, want_idx=False, want_metrics=True)), 10)
     d = sm.draw([0, n_res], n_samples, uniforms=r, letters=let, want_idx=False, want_metrics=True)
 
-    def tuples():
-        seqs = [row.tobytes().decode("ascii") for row in d["letters"].reshape(n_samples, n_res)]
-        return [(s_, float(m[0]), float(m[1]), float(m[2]), float(m[3])) for s_, m in zip(seqs, d["metrics"])]
+    def tuples():          # as design_utils/sampling_utils._sample_keys builds them
+        text = d["letters"][:n_samples * n_res].tobytes().decode("ascii")
+        seqs = [text[i * n_res:(i + 1) * n_res] for i in range(n_samples)]
+        return su._result_tuples(seqs, d["metrics"])
     t_py = _best(tuples, 5)
     out["api_breakdown_ms"] = {"numpy_legacy_rand": t_rand * 1e3, "gpu_load_draw_metrics_copies": t_gpu * 1e3, "python_result_tuples": t_py * 1e3}
     sm.close()

@@ -22,6 +22,6 @@ print("sm.draw philox let+met          %.3f ms" % T(lambda: sm.draw([0, 300], 10
 print("sm.draw mt19937 let+met         %.3f ms" % T(lambda: sm.draw([0, 300], 1000, rng="mt19937", seed=1, letters=let, want_idx=False, want_metrics=True)))
 d = sm.draw([0, 300], 1000, uniforms=r, letters=let, want_idx=False, want_metrics=True)
 def tuples():
-    block = d["letters"].reshape(1000, 300); seqs = [row.tobytes().decode("ascii") for row in block]; met = d["metrics"]
-    return [(s, float(m[0]), float(m[1]), float(m[2]), int(m[3]) if float(m[3]).is_integer() else float(m[3])) for s, m in zip(seqs, met)]
+    text = d["letters"][:300000].tobytes().decode("ascii"); seqs = [text[i * 300:(i + 1) * 300] for i in range(1000)]
+    return su._result_tuples(seqs, d["metrics"])
 print("python tuples                   %.3f ms" % T(tuples))

@@ -2,7 +2,7 @@
 pipeline trace on (TIMED_PIPELINE_TRACE; add TH_H5_TRACE=1 for the decoder's own breakdown).  With TRACE_PROFILE=1 every
 load_dataset_and_predict call also runs under cProfile and prints its 18 most expensive entries by cumulative time.
 
-    python tools/trace_predict_e2e.py [frames in the packs] [frames in the gzip .hdf5]
+    python tools/trace_predict_e2e.py [frames in the packs] [frames in the gzip .hdf5] [frames of the rotamer leg]
 """
 import os, sys, json
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
@@ -29,6 +29,7 @@ if os.environ.get("TRACE_PROFILE"):
 cfg, w = synth.timed_synth(20)
 n_pack = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 n_hdf5 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-for _ in range(2):
-    r = b.predict_py_e2e(cfg, w, n_pack=n_pack, n_hdf5=n_hdf5, batch_size=500)
+n_rot = int(sys.argv[3]) if len(sys.argv) > 3 else 0          # bench.py's order: packs, rotamer leg, config 1, then the .hdf5 calls
+for _ in range(int(os.environ.get("TRACE_REPEATS", "2"))):
+    r = b.predict_py_e2e(cfg, w, n_pack=n_pack, n_hdf5=n_hdf5, batch_size=500, n_rotamer=n_rot)
     print(json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()}))
