@@ -192,6 +192,12 @@ int th_sampler_draw(th_sampler* s, int64_t n_keys, const int64_t* row_off, int64
                     uint64_t rng_offset, const double* uniforms, const char* cat_letters, int32_t* idx_out, double* r_out,
                     char* letters_out, double* metrics_out);
 
+/* np.random.rand(n) of NumPy's GLOBAL legacy generator — the reference's source of uniforms, r = np.random.rand(n),
+ * sampling_utils.py:81 — replayed natively (host code): key = the 624 MT19937 state words and *pos the position in them, as
+ * np.random.get_state() returns them; out receives the same n doubles (genrand_res53) NumPy would produce and key / *pos are left
+ * as NumPy would leave them, so np.random.set_state((name, key, pos, has_gauss, cached)) continues the stream seamlessly. */
+int th_mt19937_rand(uint32_t* key, int* pos, int64_t n, double* out);
+
 /* ---- text output: replaces np.savetxt(f, matrix, delimiter=",") — design_utils/utils.py:768-771 (float16
  * probabilities) and predict.py:145-146 (full-precision rotamer matrix).  Host code only.  Formats the row-major
  * [n, k] matrix exactly as NumPy does (every value '%.18e', ',' between columns, '\n' after each row, NaN as

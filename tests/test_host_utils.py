@@ -216,3 +216,31 @@ def test_frame_pack_matches_hdf5(tmp_path):
         assert np.array_equal(np.asarray(Xa, dtype=np.float32), Xb.astype(np.float32)) and np.array_equal(ya, yb)
         assert len(fp) == 26 and fp.frame_dims == (7, 7, 7, 5)
     assert not framepack.is_pack(os.path.join(G, "frames_tiny.hdf5"))
+
+
+def test_legacy_rand_replays_numpys_global_generator():
+    """design_utils.sampling_utils._legacy_rand(n) = np.random.rand(n) (reference sampling_utils.py:81: the uniforms come from NumPy's
+    GLOBAL legacy generator): same values, and the generator continues exactly where np.random.rand would have left it — seeds,
+    start positions around the 624-word block boundary (an odd position makes a pair straddle two blocks), lengths below and above
+    the native threshold, a cached Gaussian left untouched"""
+    from design_utils import sampling_utils as su
+    for seed in (0, 1, 12345):
+        for pre in (0, 1, 311, 312, 623, 624, 625, 1000):
+            for n in (1, 4095, 4096, 4097, 5000, 300000):
+                np.random.seed(seed)
+                if pre:
+                    np.random.rand(pre)
+                want, after = np.random.rand(n), np.random.rand(7)
+                np.random.seed(seed)
+                if pre:
+                    np.random.rand(pre)
+                got, after2 = su._legacy_rand(n), np.random.rand(7)
+                assert np.array_equal(want, got) and np.array_equal(after, after2), (seed, pre, n)
+    np.random.seed(5)
+    np.random.randn(1)                                    # leaves a cached Gaussian in the state
+    st = np.random.get_state()
+    su._legacy_rand(10000)
+    assert np.random.get_state()[3:] == st[3:]
+    np.random.seed(5); np.random.randn(1); a = (np.random.rand(10000), np.random.randn(3))
+    np.random.seed(5); np.random.randn(1); b = (su._legacy_rand(10000), np.random.randn(3))
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])

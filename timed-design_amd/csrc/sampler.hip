@@ -547,3 +547,57 @@ int sampler_run(int device, const double* h_probs, int64_t n_res, int n_cls, int
     return sampler_draw(S, 1, row_off, n_samples, rng_mode, seed, rng_offset, h_uniforms, cat_letters, h_idx, h_r_out,
                         h_letters, nullptr);
 }
+
+// ---- th_mt19937_rand: np.random.rand(n) replayed natively (host code) ------------------------------------------------------------
+// The reference draws its uniforms from NumPy's GLOBAL legacy generator — r = np.random.rand(n), sampling_utils.py:81 — i.e. MT19937
+// and genrand_res53 ((a >> 5) * 2^26 + (b >> 6)) / 2^53 on one host core, value by value through NumPy's per-call machinery: 0.70 ms
+// for the 300 000 uniforms of one config-5 call, two thirds of the whole API call.  Given the generator's state (np.random.get_state():
+// 624 key words and the position in them) this fills `out` with the SAME n doubles and leaves key / pos as NumPy would have left them,
+// so the caller puts the state back (np.random.set_state) and the stream continues as if np.random.rand had been called: whole
+// 624-word blocks are regenerated with loops the compiler vectorises (the recurrence reaches back 227 words), tempered in bulk and
+// converted in pairs.  Checked against np.random.rand for seeds, start positions around the block boundary (odd positions: a pair
+// straddles two blocks) and lengths, including the values drawn AFTER the call (tests/test_host_utils.py).
+namespace {
+inline void mt19937_next_block(uint32_t* mt) {
+    constexpr int N = 624, M = 397;
+    constexpr uint32_t A = 0x9908b0dfU, UP = 0x80000000U, LO = 0x7fffffffU;
+    int kk = 0;
+    for (; kk < N - M; ++kk) { const uint32_t y = (mt[kk] & UP) | (mt[kk + 1] & LO); mt[kk] = mt[kk + M] ^ (y >> 1) ^ ((0u - (y & 1u)) & A); }
+    for (; kk < N - 1; ++kk) { const uint32_t y = (mt[kk] & UP) | (mt[kk + 1] & LO); mt[kk] = mt[kk + (M - N)] ^ (y >> 1) ^ ((0u - (y & 1u)) & A); }
+    const uint32_t y = (mt[N - 1] & UP) | (mt[0] & LO);
+    mt[N - 1] = mt[M - 1] ^ (y >> 1) ^ ((0u - (y & 1u)) & A);
+}
+inline uint32_t mt19937_temper(uint32_t y) {
+    y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680U; y ^= (y << 15) & 0xefc60000U; y ^= y >> 18;
+    return y;
+}
+inline double res53(uint32_t a, uint32_t b) {       // a, b already shifted: 27 and 26 bits; the scale is a power of two (exact)
+    return ((double)(int32_t)a * 67108864.0 + (double)(int32_t)b) * (1.0 / 9007199254740992.0);
+}
+}  // namespace
+
+extern "C" int th_mt19937_rand(uint32_t* key, int* pos_io, int64_t n, double* out) {
+    if (!key || !pos_io || n < 0 || (!out && n > 0)) TH_FAIL(TH_EINVAL, "th_mt19937_rand: null argument");
+    int pos = *pos_io;
+    if (pos < 0 || pos > 624) TH_FAIL(TH_EINVAL, "th_mt19937_rand: position %d outside 0..624", pos);
+    while (n > 0) {
+        if (pos >= 624) { mt19937_next_block(key); pos = 0; }
+        const int64_t pairs = std::min<int64_t>(n, (624 - pos) / 2);
+        if (pairs > 0) {
+            uint32_t tw[624];
+            const int cnt = 2 * (int)pairs;
+            for (int i = 0; i < cnt; ++i) tw[i] = mt19937_temper(key[pos + i]);
+            for (int64_t i = 0; i < pairs; ++i) out[i] = res53(tw[2 * i] >> 5, tw[2 * i + 1] >> 6);
+            out += pairs; n -= pairs; pos += cnt;
+        } else {                                    // one word left in this block: the pair straddles two blocks
+            const uint32_t a = mt19937_temper(key[pos]) >> 5;
+            mt19937_next_block(key);
+            pos = 0;
+            const uint32_t b = mt19937_temper(key[pos++]) >> 6;
+            *out++ = res53(a, b);
+            --n;
+        }
+    }
+    *pos_io = pos;
+    return TH_OK;
+}

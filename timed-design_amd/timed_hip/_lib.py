@@ -64,6 +64,7 @@ PROTOTYPES = {
     "th_comm_gather_rows": (_i, [_vp, _vp, _pi64, _i, _i, _vp]),
     "th_comm_barrier": (_i, [_vp]),
     "th_voxelise": (_i, [_i, _vp, _vp, _vp, _i64, _vp, _i64, _i, C.c_float, _i, _i, _vp, _i]),
+    "th_mt19937_rand": (_i, [_vp, _pi, _i64, _vp]),
     "th_format_csv": (_i64, [_vp, _i, _i64, _i64, _vp, _i64]),
     "th_format_csv_device": (_i64, [_i, _vp, _i64, _i64, _vp, _i64]),
     "th_format_csv_device_release": (_i, []),

@@ -296,7 +296,8 @@ def sampler_config5(device=0, n_res=300, n_samples=1000, temps=(0.1, 0.5, 1.0), 
     q = su.apply_temp_to_probs(p, 0.5)
     r = np.random.rand(draws)
     let = "".join(letters)
-    t_rand = _best(lambda: np.random.rand(draws), 5)
+    t_rand = _best(lambda: su._legacy_rand(draws), 5)        # np.random.rand's values and state, replayed natively (th_mt19937_rand)
+    t_np = _best(lambda: np.random.rand(draws), 5)
     t_gpu = _best(lambda: (sm.load(q), sm.draw([0, n_res], n_samples, uniforms=r, letters=let, want_idx=False, want_metrics=True)), 10)
     d = sm.draw([0, n_res], n_samples, uniforms=r, letters=let, want_idx=False, want_metrics=True)
 
@@ -305,7 +306,7 @@ def sampler_config5(device=0, n_res=300, n_samples=1000, temps=(0.1, 0.5, 1.0), 
         seqs = [text[i * n_res:(i + 1) * n_res] for i in range(n_samples)]
         return su._result_tuples(seqs, d["metrics"])
     t_py = _best(tuples, 5)
-    out["api_breakdown_ms"] = {"numpy_legacy_rand": t_rand * 1e3, "gpu_load_draw_metrics_copies": t_gpu * 1e3, "python_result_tuples": t_py * 1e3}
+    out["api_breakdown_ms"] = {"legacy_rand_replay": t_rand * 1e3, "np_random_rand_itself": t_np * 1e3, "gpu_load_draw_metrics_copies": t_gpu * 1e3, "python_result_tuples": t_py * 1e3}
     sm.close()
     out["cpu_cores"] = 1
     from timed_hip import _lib
