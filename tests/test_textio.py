@@ -65,6 +65,25 @@ def test_float32_fixed_point_formatter_equals_python_on_every_kind_of_value():
     assert textio.format_csv(special) == _py_lines(special)
 
 
+def test_text_scratch_is_reused_across_calls_and_sizes():
+    """textio.TextScratch: the writer's buffer kept between groups (predict.py hands one to every savetxt_csv call of a run); grows when
+    a later matrix needs more room, never changes the bytes written, close() is idempotent"""
+    rng = np.random.default_rng(9)
+    sc = textio.TextScratch()
+    for shape in ((3, 5), (1000, 338), (7, 20), (1, 1), (2000, 338)):
+        a = rng.random(shape).astype(np.float32)
+        b = io.BytesIO()
+        textio.savetxt_csv(b, a, scratch=sc)
+        assert b.getvalue() == _np_bytes(a)
+        h = a.astype(np.float16)
+        b = io.BytesIO()
+        textio.savetxt_csv(b, h, scratch=sc)
+        assert b.getvalue() == _np_bytes(h)
+    sc.close(); sc.close()
+    b = io.BytesIO(); textio.savetxt_csv(b, a[:2], scratch=sc)          # usable again after close()
+    assert b.getvalue() == _np_bytes(a[:2])
+
+
 def test_probability_matrices_and_shapes():
     rng = np.random.default_rng(6)
     p = rng.dirichlet(np.full(20, 0.3), size=3000).astype(np.float32)
