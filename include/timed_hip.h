@@ -213,11 +213,6 @@ int64_t th_format_csv(const void* data, int dtype, int64_t n, int64_t k, char* o
  * th_format_csv_device_release gives them back.  Serialised internally (one formatter per process). */
 int64_t th_format_csv_device(int device, const float* rows, int64_t n, int64_t k, char* out, int64_t cap);
 int th_format_csv_device_release(void);
-/* argmax + residue letter per row: replaces max_idx = np.argmax(prediction_matrix, axis=1) and the per-residue string
- * appends of extract_sequence_from_pred_matrix — design_utils/utils.py:659, :689-692.  matrix [n, k] of dtype TH_F16 /
- * TH_F32 / TH_F64; np.argmax rules (first maximum; the first NaN of a row wins).  letters_out[i] = col_letters[argmax_i]
- * (col_letters: k bytes, the one-letter code of every probability column); idx_out (int32[n]) optional; either output
- * may be NULL.  Host code, rows split over host threads. */
 /* dataset-map text -> string table: replaces np.genfromtxt(dataset_map_path, delimiter=",", dtype="str") — predict.py:99.
  * th_csv_shape validates plain ASCII text with the same number of `delim`-separated, non-empty fields on every line and
  * reports (rows, cols, longest field); TH_EUNSUP for anything NumPy treats specially (comments, quotes, '\r', non-ASCII,
@@ -225,6 +220,11 @@ int th_format_csv_device_release(void);
  * UCS-4 code units into out[rows][cols][width], zero padded — the memory of a NumPy '<U{width}' array.  Host code. */
 int th_csv_shape(const char* text, int64_t len, char delim, int64_t* rows_out, int* cols_out, int* width_out);
 int th_csv_fill(const char* text, int64_t len, char delim, int64_t rows, int cols, int width, uint32_t* out);
+/* argmax + residue letter per row: replaces max_idx = np.argmax(prediction_matrix, axis=1) and the per-residue string
+ * appends of extract_sequence_from_pred_matrix — design_utils/utils.py:659, :689-692.  matrix [n, k] of dtype TH_F16 /
+ * TH_F32 / TH_F64; np.argmax rules (first maximum; the first NaN of a row wins).  letters_out[i] = col_letters[argmax_i]
+ * (col_letters: k bytes, the one-letter code of every probability column); idx_out (int32[n]) optional; either output
+ * may be NULL.  Host code, rows split over host threads. */
 int th_argmax_letters(const void* matrix, int dtype, int64_t n, int64_t k, const char* col_letters, char* letters_out,
                       int32_t* idx_out);
 
