@@ -205,7 +205,7 @@ def test_fused_dense_tail_is_bit_identical(gpu, cnn_golden, monkeypatch):
     for n in (1, len(frames)):
         assert np.array_equal(fused.predict(frames[:n]), plain.predict(frames[:n]))
         assert np.array_equal(fused.predict(frames[:n], logits=True), plain.predict(frames[:n], logits=True))
-    np.testing.assert_allclose(fused.predict(frames[:8]), z["densecpd20__torch64"][:8], atol=TOL, rtol=0)
+    np.testing.assert_allclose(fused.predict(frames[:8]), z["densecpd20__torch64"][:8], atol=TIGHT, rtol=0)
     gap = next(l["name"] for l in cfg["config"]["layers"] if l["class_name"] == "GlobalAveragePooling3D")
     dense = next(l["name"] for l in cfg["config"]["layers"] if l["class_name"] == "Dense")
     c = weights[dense][0].shape[0]
@@ -214,6 +214,52 @@ def test_fused_dense_tail_is_bit_identical(gpu, cnn_golden, monkeypatch):
     relu = [l["name"] for l in cfg["config"]["layers"] if l["class_name"] == "ReLU"][-1]
     with pytest.raises(_lib.TimedHipError, match="fused away"):
         fused.fetch(relu, 1, (1,))
+    fused.close(); plain.close()
+
+
+@pytest.mark.parametrize("shape,chain,units,bias,arena", [
+    ((1, 1, 1, 1), "", 1, True, False),                  # one voxel, one feature, one class
+    ((2, 2, 2, 63), "b", 20, True, False),
+    ((3, 3, 3, 64), "br", 20, False, False),             # DenseCPD's own chain, no Dense bias
+    ((2, 3, 1, 65), "eb", 64, True, False),              # ELU -> BN (TIMED's block order) in front of the pooling
+    ((2, 2, 2, 200), "blrb", 65, True, False),           # four elementwise nodes (the fusion limit), 65 classes: two lanes rounds
+    ((1, 2, 2, 130), "br", 338, True, False),            # rotamer-sized Dense
+    ((2, 2, 2, 24), "br", 512, True, False),             # widest Dense the kernel takes
+    ((2, 2, 2, 40), "br", 20, True, True),               # the chain reads a zero-copy concat arena (channel stride 88)
+    ((2, 2, 2, 40), "", 20, True, True),                 # pooling straight off the arena
+])
+def test_dense_tail_kernel_shapes_against_the_unfused_plan_and_the_oracle(gpu, monkeypatch, shape, chain, units, bias, arena):
+    """k_tail_dense over feature counts around the 64-lane rounds, voxel counts from 1 to 27, 1 to 512 classes, every elementwise
+    chain length it fuses (b = BatchNormalization, r = ReLU, e = ELU, l = LeakyReLU), with and without a Dense bias, reading a plain
+    tensor or a concat arena: bit-identical to the unfused plan (probabilities and logits) and within 5e-6 of the float64 oracle"""
+    b = synth.KerasGraphBuilder(shape, seed=sum(shape) + units, bias_std=0.3)
+    x = b.input_name
+    if arena:
+        y = b.conv3d(x, 48, 1, padding="same", activation="relu")
+        x = b.concat([x, y])
+    for c in chain:
+        x = {"b": b.batchnorm, "r": b.relu, "e": b.elu, "l": lambda v: b.leaky_relu(v, 0.2)}[c](x)
+    x = b.gap(x)
+    x = b.dense(x, units, use_bias=bias)
+    x = b.softmax(x)
+    cfg, w = b.finish(x)
+    rng = np.random.default_rng(units)
+    frames = rng.standard_normal((11, *shape)).astype(np.float32)
+    fused = engine.HipFrameModel.from_keras(cfg, w, device=gpu)
+    labels = [s["label"] for s in fused.steps()]
+    assert sum("k_tail_dense" in l for l in labels) == 1, labels
+    if chain:
+        assert f"{len(chain)} elementwise + " in labels[-1], labels[-1]
+    monkeypatch.setenv("TH_NO_TAIL_FUSE", "1")
+    plain = engine.HipFrameModel.from_keras(cfg, w, device=gpu)
+    assert not any("k_tail_dense" in s["label"] for s in plain.steps())
+    for n in (1, 11):
+        assert np.array_equal(fused.predict(frames[:n]), plain.predict(frames[:n]))
+        assert np.array_equal(fused.predict(frames[:n], logits=True), plain.predict(frames[:n], logits=True))
+    want = cnn_oracle.forward(cfg, w, frames, np.float64)
+    got = fused.predict(frames)
+    np.testing.assert_allclose(got, want, atol=TIGHT, rtol=0)
+    np.testing.assert_allclose(got.sum(1), 1.0, atol=1e-5)
     fused.close(); plain.close()
 
 
