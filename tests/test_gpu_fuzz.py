@@ -11,7 +11,7 @@ from timed_hip import _lib, engine, synth
 pytestmark = pytest.mark.gpu
 
 
-def _random_net(seed):
+def _random_net(seed, dense_tail=False):
     rng = np.random.default_rng(1000 + seed)
     shape = tuple(int(rng.integers(3, 9)) for _ in range(3))
     cin = int(rng.choice([1, 3, 5, 6, 8]))
@@ -75,7 +75,11 @@ def _random_net(seed):
                 x = b.avgpool(x, 2)
     head = rng.integers(0, 3)
     ncls = int(rng.choice([20, 338, 5]))
-    if head == 0:
+    if dense_tail:         # DenseCPD's head: [BN / activation]* -> GlobalAveragePooling3D -> Dense -> Softmax (the random body's draws are unchanged)
+        for c in ("", "b", "br", "eb", "rb", "blrb")[seed % 6]:
+            x = {"b": b.batchnorm, "r": b.relu, "e": b.elu, "l": lambda v: b.leaky_relu(v, 0.1)}[c](x)
+        x = b.softmax(b.dense(b.gap(x), ncls, use_bias=bool(seed % 2)))
+    elif head == 0:
         x = b.softmax(b.gap(b.conv3d(x, ncls, 3, padding="same")))
     elif head == 1:
         x = b.dense(b.flatten(x), ncls, activation="softmax")
@@ -103,6 +107,27 @@ def test_random_graph_matches_oracle(gpu, seed):
         top2 = np.sort(want, axis=1)[:, -2:]
         clear = (top2[:, 1] - top2[:, 0]) > 1e-4
         assert np.array_equal(got.argmax(1)[clear], want.argmax(1)[clear]), (seed, labels)
+
+
+@pytest.mark.parametrize("seed", range(100, 118))
+def test_random_graph_with_a_dense_tail(gpu, seed):
+    """random bodies (dense blocks, strided / valid convolutions, transitions: whatever tensor they end in — a concat arena, a pooled
+    tensor, a plain one) under DenseCPD's head; the tail runs as ONE launch (k_tail_dense) and agrees with the oracle like every
+    other plan"""
+    cfg, weights, frames = _random_net(seed, dense_tail=True)
+    want = cnn_oracle.forward(cfg, weights, frames, np.float32)
+    m = engine.HipFrameModel.from_keras(cfg, weights)
+    m.set_chunk(int(1 + seed % 5))
+    got = m.predict(frames)
+    labels = [s["label"] for s in m.steps()]
+    m.close()
+    # (a Winograd layer in front of the pooling pools in its output transform instead: then Dense and Softmax keep their steps)
+    assert sum("k_tail_dense" in l for l in labels) == 1 or any("wino_out + global_avg_pool" in l for l in labels), (seed, labels)
+    err = float(np.abs(got - want).max())
+    assert got.shape == want.shape and err <= 2e-5, (seed, err, labels)
+    top2 = np.sort(want, axis=1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 1e-4
+    assert np.array_equal(got.argmax(1)[clear], want.argmax(1)[clear]), (seed, labels)
 
 
 @pytest.mark.parametrize("seed", [3, 11, 19, 27])
