@@ -107,7 +107,9 @@ def _legacy_rand(n: int) -> np.ndarray:
     same generator state afterwards, produced by th_mt19937_rand: the state (MT19937 key + position) is taken out with
     np.random.get_state(), advanced natively (vectorised block regeneration, bulk tempering) and put back.  NumPy's own path costs
     0.70 ms for the 300 000 uniforms of a config-5 call, two thirds of the call.  Short draws, a generator that is not MT19937 and
-    any native failure go through np.random.rand itself."""
+    any native failure go through np.random.rand itself.  Like the reference's own use of the global generator this is for one
+    drawing thread at a time: calls through this function are serialised, but a thread that calls np.random directly between the
+    get_state and the set_state here would see its draws replayed."""
     n = int(n)
     if n < 4096:
         return np.random.rand(n)
