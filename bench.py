@@ -134,7 +134,7 @@ def main():
     ap.add_argument("--e2e-rotamer-frames", type=int, default=125000,
                     help="uint8 frames in the predict.py --predict_rotamers leg (config 4's per-GPU share: 1 M / 8)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 --pmc child passes (roofline.traffic stays null)")
-    ap.add_argument("--other-frames", type=int, default=40960, help="frames for the densecpd / timed_rotamer legs")
+    ap.add_argument("--other-frames", type=int, default=100000, help="frames for the densecpd / timed_rotamer legs (BASELINE config 3: 100 k frames)")
     args = ap.parse_args()
 
     # stdout carries exactly one JSON line: gloo / RCCL banners written to fd 1 by native code go to stderr
