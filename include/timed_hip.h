@@ -120,6 +120,16 @@ int th_model_profile(th_model* m, int enable);
  * algorithmic FLOPs and bytes per frame attributed to the step */
 int th_model_step_info(const th_model* m, int i, char* label, size_t label_len, double* ms, int64_t* launches,
                        double* flops_per_frame, double* exec_flops_per_frame, double* bytes_per_frame);
+/* Load-time guard.  th_model_load checks the plan it built — Winograd layers, the bf16x3-split GEMMs — against a direct fp32-MFMA
+ * plan of the same pack on four internally generated frames: the logits must agree to 1e-5 x max(1, max |logit|).  If they do
+ * not, fast features are dropped (split GEMM, 5^3 Winograd, fused 10^3 Winograd, first-layer F(2,3), in that order) until they
+ * do.  state: 0 not run (TH_GUARD=0 or nothing to check), 1 passed, 2 tripped — `note` then says what was measured and dropped.
+ * max_dlogit: the kept plan's distance from the direct plan; logit_scale: max |logit| of the direct plan on the guard frames. */
+int th_model_guard_info(const th_model* m, int* state, double* max_dlogit, double* logit_scale, char* note, size_t note_len);
+
+/* the A/B and test knobs (TH_* environment variables) this handle was loaded under, as "NAME=value ..." — empty when every
+ * knob had its default.  They are read once, by th_model_load, and never again (a later setenv does not reach a loaded handle). */
+int th_model_knobs(const th_model* m, char* buf, size_t buf_len);
 
 /* ---- device memory helpers (so host code needs no torch/hip-python for resident buffers) -- */
 int th_dev_alloc(int device, size_t bytes, void** d_out);

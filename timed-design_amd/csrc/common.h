@@ -30,6 +30,37 @@ void th_set_error(const char* fmt, ...);
         }                                                                                        \
     } while (0)
 
+// ---- A/B and test knobs ---------------------------------------------------------------------
+// Every TH_* environment variable that changes what a MODEL plans or launches is read exactly once, by th_model_load, into the
+// handle (th_knobs_read).  Planners take the snapshot of the load in progress (th_knobs_planning) and leave a pointer to it
+// in their plan structs, launchers read it from there: no getenv in a launch path, no process-wide static caches — two models
+// loaded under different environments keep their own settings, whatever the call order.  `nondefault` lists what was set
+// ("TH_WINOGRAD=0 TH_WF_DBG=3"); th_model_knobs() returns it and bench.py prints it.
+struct ThKnobs {
+    int winograd = 1;          // TH_WINOGRAD: 0 direct kernels, 1 F(3,3)+F(2,3) in-plane (default), 2 F(5,3) (opt-in)
+    int wino_split = 1;        // TH_WINO_SPLIT: Winograd GEMMs on bf16 MFMA with exactly split operands (0: fp32-input MFMA)
+    int wfused = 1;            // TH_WFUSED: 10^3 layers on conv_wfused.hip
+    int lanes = 1, lane_lag = 1;   // TH_LANES, TH_LANE_LAG
+    int guard = 1;             // TH_GUARD: load-time check of the fast plans against the direct fp32 plan (0: off)
+    int first_wino = 1;        // TH_FIRST_WINO=0: k_conv_first instead of k_conv_first_w
+    int first_zb = 0;          // TH_FIRST_ZB: brick depth of the first-layer kernel (tuning)
+    int first_dbg = 0;         // TH_FIRST_DBG: timing knock-outs (results wrong)
+    int no_pool_first = 0;     // TH_NO_POOL_FIRST: act / BN before the max-pool even when the chain is monotone
+    int no_tail_fuse = 0;      // TH_NO_TAIL_FUSE: keep GAP / Dense / Softmax as separate launches
+    int conv_nogeo = 0, n16_nogeo = 0, conv_noxc = 0, conv_notail = 0, conv_nozmajor = 0, conv_nocompact = 0, conv_nopw = 0;
+    int conv_bmode = 0;        // TH_CONV_BMODE: 1 dbuf, 2 stream8, 3 no16
+    int conv_dbg = 0, conv_ldspad = 0, n16_resident = 0;
+    int pw_nopipe = 0, pw_noepi = 0, pw_dbg = 0;
+    int wf_resident = 0, wf_dbg = 0, wf_noblk = 0;
+    long long wino_piece = 0;
+    int wino_dbg = 0, wino_var = 3, wino_b3var = 0, wino_nomid = 0;
+    std::string nondefault;
+};
+void th_knobs_read(ThKnobs* k);                 // the process environment, now
+const ThKnobs& th_knobs_planning();             // the snapshot of the th_model_load in progress on this thread (defaults outside one)
+void th_knobs_set_planning(const ThKnobs* k);   // runtime.hip, around the planner
+inline const ThKnobs& th_knobs_of(const ThKnobs* k) { static const ThKnobs dflt; return k ? *k : dflt; }
+
 // CPUs this process may actually use: min(hardware threads, scheduler affinity, cgroup CPU quota).  Containers often
 // expose every host core but enforce a quota (cpu.max); more runnable threads than the quota are throttled in 100 ms
 // periods — measured on the GPU box (256 cores visible, quota 16): 20 k frames/s inflated with 16 threads, a bimodal
@@ -119,6 +150,7 @@ struct ConvMfmaPlan {
     int first_wino = 0;           // first-layer kernel only: F(2,3) along x (k_conv_first_w), rows are x pairs
     double own_flops = 0;         // first_wino: the algorithm's own multiply-adds x 2 per frame (4 points per x pair and (dz, dy) tap)
     int geo = 0;                  // > 0: the kernel instantiation with Hp = Wp = geo at compile time (tap offsets as immediates)
+    const ThKnobs* knobs = nullptr;   // the owning model's A/B knobs (launch-time ones: dbg, resident, ...)
     std::string label;
 };
 // choose a tiling for this convolution; returns false when the MFMA kernel does not apply
@@ -143,9 +175,13 @@ struct ConvWinoPlan {
     int64_t v_fpf = 0, m_fpf = 0;                // scratch floats per frame: transformed input V, GEMM output M
     double gemm_flops = 0;                       // the algorithm's multiply-adds x 2 per frame: P^2 positions x 13 z-tap pairs x Cin x Cout
     double exec_flops = 0;                       // MFMA FLOPs issued per frame (Cout padded to the column block)
+    int split = 0;                               // 1: the GEMM runs on bf16 MFMA with both operands split exactly into three bf16 pieces
+                                                 // (x = h + m + l) and six of the nine piece products summed in fp32 (k_wino_gemm_b3)
+    const ThKnobs* knobs = nullptr;
     std::string label;
 };
-bool conv_wino_plan(const TView& in, const TView& out_conv, const ConvGeom& g, int Cin, int Cout, int scheme, ConvWinoPlan* plan);
+// split: 0 = fp32 MFMA (exact fp32 products), 1 = bf16x3 split operands (see ConvWinoPlan::split)
+bool conv_wino_plan(const TView& in, const TView& out_conv, const ConvGeom& g, int Cin, int Cout, int scheme, ConvWinoPlan* plan, int split = 0);
 void conv_wino_pack_weights(const ConvWinoPlan& p, const float* w_keras, float* dst);
 // V, M: scratch for ceil(n / 64) * 64 frames (v_fpf / m_fpf floats each).  Three launches = three plan steps.
 int launch_wino_in(hipStream_t s, int64_t n, const ConvWinoPlan& p, TView in, float* V, PreOp pre);
@@ -163,6 +199,7 @@ struct ConvWfPlan {
     size_t wpk_floats = 0, lds_bytes = 0;
     double own_flops = 0;            // the algorithm's multiply-adds x 2 per frame (16 positions x 3 z taps per 2 x 2 tile)
     double exec_flops = 0;           // MFMA FLOPs issued per frame
+    const ThKnobs* knobs = nullptr;
     std::string label;
 };
 bool conv_wf_plan(const TView& in, const TView& out_conv, const ConvGeom& g, int Cin, int Cout, int pool, ConvWfPlan* plan);

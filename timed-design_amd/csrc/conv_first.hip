@@ -588,7 +588,9 @@ bool conv_first_plan(int Din, int Hin, int Win, int Cin, const TView& oc, const 
     p->Hp = p->Hc + 2;
     p->Wp = p->Wc + 2;
     // F(2,3) along x (k_conv_first_w): 'same' padding, an even number of computed columns; rows are x pairs
-    const bool no_wino = getenv("TH_FIRST_WINO") && atoi(getenv("TH_FIRST_WINO")) == 0;   // read at every model load (A/B runs, tests)
+    const ThKnobs& kn = th_knobs_planning();
+    p->knobs = &kn;
+    const bool no_wino = !kn.first_wino;
     const bool wino = !no_wino && g.pz == 1 && g.py == 1 && g.px == 1 && p->Wc % 2 == 0 && p->Wc >= 2;
     p->first_wino = wino ? 1 : 0;
     auto rows_for = [&](int zb) {
@@ -613,8 +615,8 @@ bool conv_first_plan(int Din, int Hin, int Win, int Cin, const TView& oc, const 
     if (!ZB) return false;
     for (int zb = ZB; zb >= step && zb * 10 >= ZB * 6; zb -= step)
         if (p->Dc % zb == 0) { ZB = zb; break; }
-    if (const char* e = getenv("TH_FIRST_ZB")) {  // tuning experiments
-        const int zb = atoi(e);
+    if (kn.first_zb) {  // tuning experiments
+        const int zb = kn.first_zb;
         if (zb >= step && zb % step == 0 && zb <= p->Dc && lds_for(zb) <= (size_t)160 * 1024) ZB = zb;
     }
     p->ZB = ZB;
@@ -665,11 +667,12 @@ namespace {
 // the instantiation a plan runs with a given epilogue chain: pool-first (PMODE 3) when the chain is monotone, the
 // compile-time geometry when there is one for this frame size
 FirstKernel pick_first_kernel(const ConvMfmaPlan& p, int nst, const PostOps& post, int* pmode, int* geo) {
-    const bool no_pool_first = getenv("TH_NO_POOL_FIRST") != nullptr;   // A/B comparisons and tests
+    const ThKnobs& kn = th_knobs_of(p.knobs);
+    const bool no_pool_first = kn.no_pool_first != 0;   // A/B comparisons and tests
     *pmode = (p.pool == 1 && post.monotone && !no_pool_first) ? 3 : p.pool;
     *geo = 0;
     FirstKernel k = p.first_wino ? kFirstWKernels[nst - 1][*pmode] : kFirstKernels[nst - 1][*pmode];
-    if (p.Hp == p.Wp && p.Hc == p.Hp - 2 && p.Wc == p.Wp - 2 && !getenv("TH_CONV_NOGEO")) {
+    if (p.Hp == p.Wp && p.Hc == p.Hp - 2 && p.Wc == p.Wp - 2 && !kn.conv_nogeo) {
         if (p.first_wino) {
             for (const FirstGeo& ge : kFirstWGeo)
                 if (ge.nst == nst && ge.pmode == *pmode && ge.geo == p.Hp) { k = ge.k; *geo = ge.geo; }
@@ -721,7 +724,7 @@ int launch_conv_first(hipStream_t s, int64_t n, const ConvMfmaPlan& p, const voi
     int pmode, geo;
     FirstKernel k = pick_first_kernel(p, nst, post, &pmode, &geo);
     {   // timing experiments only (tools/bench_layer.py): knock-out instantiations of k_conv_first_w<3,3,22>
-        static const int dbg = getenv("TH_FIRST_DBG") ? atoi(getenv("TH_FIRST_DBG")) : 0;
+        const int dbg = th_knobs_of(p.knobs).first_dbg;
         if (dbg > 0 && dbg < 8 && kFirstWDbg[dbg] && p.first_wino && nst == 3 && pmode == 3 && geo == 22) k = kFirstWDbg[dbg];
     }
     HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

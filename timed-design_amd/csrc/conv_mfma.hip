@@ -1311,6 +1311,7 @@ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 static bool plan_with_cfg(int cfg, size_t lds_limit, bool whole_frames_only, const TView& in, const TView& oc,
                           const ConvGeom& g, int Cin, int Cout, int pool, ConvMfmaPlan* p) {
     const CfgDesc& c = kCfgs[cfg];
+    p->knobs = &th_knobs_planning();
     p->cfg = cfg;
     p->CI = c.CI;
     p->CS = c.CI == 8 ? 8 : c.CI + 4;  // CI=8: unpadded (2-way ds_read_b128 conflict, but the brick fits)
@@ -1387,7 +1388,7 @@ static bool plan_with_cfg(int cfg, size_t lds_limit, bool whole_frames_only, con
     }
     if ((int64_t)FB * oc.fs > 0x7fffffffLL || (int64_t)FB * in.D * in.H * in.W * std::max(in.cs, in.C) > 0x7fffffffLL) return false;
     p->geo = 0;
-    if (g.kd == 3 && g.kh == 3 && g.kw == 3 && g.sd == 1 && g.sh == 1 && g.sw == 1 && p->Hp == p->Wp && p->CS == 20 && !getenv("TH_CONV_NOGEO"))
+    if (g.kd == 3 && g.kh == 3 && g.kw == 3 && g.sd == 1 && g.sh == 1 && g.sw == 1 && p->Hp == p->Wp && p->CS == 20 && !th_knobs_planning().conv_nogeo)
         for (const MfmaGeo& ge : kMfmaGeo)
             if (ge.cfg == cfg && ge.pool == pool && ge.geo == p->Hp) p->geo = ge.geo;
     char buf[224], geo[16];
@@ -1423,6 +1424,7 @@ const ConvKernelN16 kN16Kernels[kNumN16][3] = {
 bool plan_n16(int variant, size_t lds_limit, const TView& in, const TView& oc, const ConvGeom& g, int Cin, int Cout, int pool,
               ConvMfmaPlan* p) {
     const N16Cfg& c = kN16[variant];
+    p->knobs = &th_knobs_planning();
     p->cfg = 200 + variant;
     p->CI = 16; p->CS = 20; p->BN = 16; p->nnb = 1; p->nchunks = (Cin + 15) / 16; p->pool = pool; p->bres = 3;
     p->Dc = pool ? (oc.D / 2) * 2 : oc.D;
@@ -1451,7 +1453,7 @@ bool plan_n16(int variant, size_t lds_limit, const TView& in, const TView& oc, c
     p->exec_flops = 2.0 * (double)p->rows_pf * p->nzb * 16.0 * (double)(p->nchunks * 16) * 27;   // MFMA only
     if ((int64_t)FB * oc.fs > 0x7fffffffLL || (int64_t)FB * in.D * in.H * in.W * std::max(in.cs, in.C) > 0x7fffffffLL) return false;
     p->geo = 0;
-    if (pool == 0 && p->Hp == p->Wp && !getenv("TH_N16_NOGEO"))
+    if (pool == 0 && p->Hp == p->Wp && !th_knobs_planning().n16_nogeo)
         for (const N16Geo& ge : kN16Geo)
             if (ge.variant == variant && ge.geo == p->Hp) p->geo = ge.geo;
     char buf[224], geo[24];
@@ -1475,10 +1477,9 @@ bool conv_mfma_plan(const TView& in, const TView& oc, const ConvGeom& g, int Cin
     // TH_CONV_BMODE=dbuf keeps the LDS double-buffered weight slabs, =stream8 the 8-wave streamed kernels
     // (A/B comparisons); default: weights streamed L2 -> registers, two 4-wave workgroups per CU when whole
     // frames fit in half the LDS
-    const char* mode = getenv("TH_CONV_BMODE");
-    const bool dbuf = mode && std::strcmp(mode, "dbuf") == 0;
-    const bool stream8 = mode && std::strcmp(mode, "stream8") == 0;
-    const bool no16 = mode && std::strcmp(mode, "no16") == 0;
+    const ThKnobs& kn = th_knobs_planning();
+    p->knobs = &kn;
+    const bool dbuf = kn.conv_bmode == 1, stream8 = kn.conv_bmode == 2, no16 = kn.conv_bmode == 3;
     if (!dbuf && !stream8 && !strided && Cout <= 16 && Cin > 8 && g.kd == 3 && g.kh == 3 && g.kw == 3 && !no16) {
         if (plan_n16(1, kLdsLimit / 2, in, oc, g, Cin, Cout, pool, p)) return true;   // two 4-wave workgroups per CU
         if (plan_n16(0, kLdsLimit, in, oc, g, Cin, Cout, pool, p)) return true;       // one 8-wave workgroup
@@ -1486,7 +1487,7 @@ bool conv_mfma_plan(const TView& in, const TView& oc, const ConvGeom& g, int Cin
     // Cout 17..20 (a 20-class head): 16 channels on the matrix pipe + up to 4 on the VALU pipe underneath,
     // instead of a 32-wide tile with 12 zero columns
     if (!dbuf && !stream8 && !strided && Cout > 16 && Cout <= 20 && Cin > 8 && pool == 0 && g.kd == 3 && g.kh == 3 && g.kw == 3 && !no16 &&
-        !getenv("TH_CONV_NOXC")) {
+        !kn.conv_noxc) {
         if (plan_n16(2, kLdsLimit / 2, in, oc, g, Cin, Cout, pool, p)) return true;
     }
     if (!dbuf && cfg >= 1 && cfg <= 3) {
@@ -1506,7 +1507,7 @@ bool conv_mfma_plan(const TView& in, const TView& oc, const ConvGeom& g, int Cin
 // head (256 -> 338 at 5^3, half of that model's time): 128 + 128 + 96 = 352 columns instead of 3 x 128 = 384.
 bool conv_mfma_plan_tail(const TView& in, const TView& oc, const ConvGeom& g, int Cin, int Cout, int pool, const ConvMfmaPlan& main,
                          ConvMfmaPlan* tail, int* cout_main) {
-    const bool off = getenv("TH_CONV_NOTAIL") != nullptr;     // A/B comparisons and tests (read at every model load)
+    const bool off = th_knobs_planning().conv_notail != 0;     // A/B comparisons and tests
     if (off || main.cfg != 9 || main.nnb < 2) return false;
     const int done = (main.nnb - 1) * main.BN, rest = Cout - done;
     if (rest <= 0 || rest > 96) return false;
@@ -1599,8 +1600,9 @@ int launch_conv_mfma(hipStream_t s, int64_t n, const ConvMfmaPlan& p, TView in, 
     a.rows_pf = p.rows_pf; a.nrows = p.FB * p.rows_pf; a.n_mtiles = a.nrows / 32;
     a.CS = p.CS; a.nchunks = p.nchunks; a.nnb = p.nnb;
     a.tab_off = (int)p.tab_off;
-    { static const bool nozm = getenv("TH_CONV_NOZMAJOR") != nullptr; a.zmajor = (!nozm && !n16 && p.pool == 0 && p.bres == 2 && c.CI == 16 && g.sd == 1 && g.sh == 1 && g.sw == 1) ? 1 : 0; }
-    { static const int dbg = getenv("TH_CONV_DBG") ? atoi(getenv("TH_CONV_DBG")) : 0; a.dbg = dbg; }
+    const ThKnobs& kn = th_knobs_of(p.knobs);
+    { const bool nozm = kn.conv_nozmajor != 0; a.zmajor = (!nozm && !n16 && p.pool == 0 && p.bres == 2 && c.CI == 16 && g.sd == 1 && g.sh == 1 && g.sw == 1) ? 1 : 0; }
+    a.dbg = kn.conv_dbg;
     a.wpk = wpk; a.Cout = Cout; a.bias = bias; a.pre = pre; a.post = post;
     a.wx = n16 ? wpk + ((size_t)p.nchunks * 27 + 9) * 256 : wpk;
     a.in_grp_bytes = (unsigned)std::min<int64_t>(0xfffffff0LL, ((int64_t)(p.FB - 1) * in.fs + ((int64_t)in.D * in.H * in.W - 1) * in.cs + Cin) * 4);
@@ -1616,7 +1618,7 @@ int launch_conv_mfma(hipStream_t s, int64_t n, const ConvMfmaPlan& p, TView in, 
             HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
         }
         int64_t resident = (int64_t)ncu * (c.WAVES == 4 ? 2 : 1);
-        if (const char* e = getenv("TH_N16_RESIDENT")) resident = std::max(1, atoi(e));   // tests: force multi-trip workgroups
+        if (kn.n16_resident) resident = std::max(1, kn.n16_resident);   // tests: force multi-trip workgroups
         // units = (frame group, slab); equal trip counts: ceil(units / ceil(units / resident)) workgroups, and a
         // workgroup keeps its slab: the stride is a multiple of nzb
         const int64_t units = groups * p.nzb;
@@ -1631,13 +1633,13 @@ int launch_conv_mfma(hipStream_t s, int64_t n, const ConvMfmaPlan& p, TView in, 
             if (ge.cfg == p.cfg && ge.pool == p.pool && ge.geo == p.geo) {
                 k = ge.k;
                 a.geo_compact = (g.pz == 1 && g.py == 1 && g.px == 1 && p.nzb == 1 && p.Zp == in.D + 2 && in.H == ge.geo - 2 && in.W == ge.geo - 2 &&
-                                 a.vec_ok && Cin % 16 == 0 && !getenv("TH_CONV_NOCOMPACT")) ? 1 : 0;
+                                 a.vec_ok && Cin % 16 == 0 && !kn.conv_nocompact) ? 1 : 0;
             }
     if (n16 && p.geo)
         for (const N16Geo& ge : kN16Geo)
             if (ge.variant == p.cfg - 200 && ge.geo == p.geo) k = ge.k;
     HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
-    static const size_t lds_pad = getenv("TH_CONV_LDSPAD") ? (size_t)atoi(getenv("TH_CONV_LDSPAD")) : 0;  // occupancy experiments
+    const size_t lds_pad = (size_t)std::max(0, kn.conv_ldspad);  // occupancy experiments
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(c.WAVES * 64), std::min(p.lds_bytes + lds_pad, kLdsLimit), s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) TH_FAIL(TH_EHIP, "conv_mfma launch failed: %s (%s)", hipGetErrorString(e), p.label.c_str());

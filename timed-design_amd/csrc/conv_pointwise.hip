@@ -61,8 +61,9 @@ constexpr size_t kPwLdsLimit = 64 * 1024;
 
 // plan encoding (ConvMfmaPlan): cfg = 300 + 3*kmax_index + nt_index, CI = 8*K8 (padded Cin), BN = 32*NT, bres = 4
 bool conv_pw_plan(const TView& in, const TView& oc, const ConvGeom& g, int Cin, int Cout, int pool, ConvMfmaPlan* p) {
-    static const bool off = getenv("TH_CONV_NOPW") != nullptr;   // A/B comparisons against conv_mfma
-    if (off) return false;
+    const ThKnobs& kn = th_knobs_planning();
+    if (kn.conv_nopw) return false;                             // A/B comparisons against conv_mfma
+    p->knobs = &kn;
     if (g.kd != 1 || g.kh != 1 || g.kw != 1) return false;
     if (g.sd != 1 || g.sh != 1 || g.sw != 1 || g.dd != 1 || g.dh != 1 || g.dw != 1) return false;
     if (pool && (oc.D < 2 || oc.H < 2 || oc.W < 2)) return false;
@@ -86,7 +87,7 @@ bool conv_pw_plan(const TView& in, const TView& oc, const ConvGeom& g, int Cin, 
     p->exec_flops = 2.0 * (double)p->rows_pf * (double)(32 * NT) * (double)(K8 * 8);
     char buf[224];
     // the pipelined kernel when the layer allows it (launch_conv_pw falls back to k_conv_pw for unaligned or > 4 GiB views)
-    const bool pipe = !getenv("TH_PW_NOPIPE") && kPw2[kmi][nti][pool] && Cin % 8 == 0 && K8 <= kPwKmax[kmi];
+    const bool pipe = !kn.pw_nopipe && kPw2[kmi][nti][pool] && Cin % 8 == 0 && K8 <= kPwKmax[kmi];
     const int kmax = (pipe && K8 > 8 && K8 <= 12 && nti <= 1) ? 12 : kPwKmax[kmi];
     snprintf(buf, sizeof buf, "conv_pw<k%d,nt%d,pool%d> K8=%d lds%zuK (streaming 1x1x1, weights in LDS%s) [k_conv_pw%s<%d,%d,%d%s>]",
              kmax, NT, pool, K8, lds / 1024, pipe ? ", next tile prefetched, buffer addressing" : "", pipe ? "2" : "",
@@ -119,7 +120,7 @@ void conv_pw_pack_weights(const ConvMfmaPlan& p, int Cin, int Cout, const float*
 static bool pw_relu_epi(const ConvMfmaPlan& p, int K8, const PostOps& post) {
     const int idx = p.cfg - 300, kmi = idx / 3, nti = idx % 3;
     const bool relu_chain = post.n == 2 && post.type[0] == POP_AFFINE && post.type[1] == POP_ACT && post.act[1] == ACT_RELU;
-    if (p.pool != 0 || !relu_chain || getenv("TH_PW_NOEPI")) return false;
+    if (p.pool != 0 || !relu_chain || th_knobs_of(p.knobs).pw_noepi) return false;
     return conv_pw2_extra(0, 2, kmi, nti, (K8 > 8 && K8 <= 12 && nti <= 1) ? 1 : 0) != nullptr;
 }
 // the plan's label with the template arguments of the instantiation that runs (chunk-blocked output, epilogue chain)
@@ -155,14 +156,14 @@ int launch_conv_pw(hipStream_t s, int64_t n, const ConvMfmaPlan& p, TView in, TV
     if (nrows >= 0x7fffffffLL) TH_FAIL(TH_EINVAL, "conv_pw: %lld rows per launch exceed the 32-bit row index; lower the chunk size", (long long)nrows);
     a.nrows = (unsigned)nrows;
     a.ntiles = (unsigned)((nrows + 31) / 32);
-    { static const int dbg = getenv("TH_PW_DBG") ? atoi(getenv("TH_PW_DBG")) : 0; a.dbg = dbg; }
+    a.dbg = th_knobs_of(p.knobs).pw_dbg;
     const unsigned want = (a.ntiles + 3) / 4;
     const unsigned grid = std::min(want, 256u * 8u);   // persistent: up to 8 workgroups per CU queued, waves stride over tiles
     PwKernel k = kPw[kmi][nti][p.pool];
     // the pipelined buffer-addressing kernel when the views allow it (see k_conv_pw2)
     const int64_t in_span = ((n - 1) * in.fs + (int64_t)(a.V - 1) * in.cs + in.coff + Cin) * 4;
     const int64_t out_span = ((n - 1) * out.fs + (out_v - 1) * out.cs + out.coff + Cout) * 4;
-    static const bool no_pw2 = getenv("TH_PW_NOPIPE") != nullptr;   // A/B comparisons
+    const bool no_pw2 = th_knobs_of(p.knobs).pw_nopipe != 0;   // A/B comparisons
     if (!no_pw2 && kPw2[kmi][nti][p.pool] && a.vec_ok && Cin % 8 == 0 && a.K8 <= kPwKmax[kmi] && in_span < 0xfffffff0LL &&
         out_span < 0xfffffff0LL) {
         a.in_bytes = (unsigned)in_span; a.out_bytes = (unsigned)out_span;

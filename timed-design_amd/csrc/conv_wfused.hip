@@ -495,6 +495,7 @@ bool conv_wf_plan(const TView& in, const TView& out, const ConvGeom& g, int Cin,
     if (geo < 0) return false;
     const int NT = (in.H / 2) * (in.W / 2);
     p->geo = geo; p->pool = pool;
+    p->knobs = &th_knobs_planning();
     p->Cin = Cin; p->Cout = Cout;
     p->ncb = (Cout + 15) / 16;
     p->nchunks = Cin / 4;
@@ -571,7 +572,8 @@ int launch_conv_wf(hipStream_t s, int64_t n, const ConvWfPlan& p, TView in, TVie
         HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
     }
     int64_t resident = ncu;                              // one 8-wave workgroup per CU (154 KB of LDS)
-    if (const char* e = getenv("TH_WF_RESIDENT")) resident = std::max(1, atoi(e));       // tests: force multi-trip workgroups
+    const ThKnobs& kn = th_knobs_of(p.knobs);
+    if (kn.wf_resident) resident = std::max(1, kn.wf_resident);       // tests: force multi-trip workgroups
     const int64_t trips = (nslots + resident - 1) / resident;
     int64_t grid = (nslots + trips - 1) / trips;
     grid = (grid + 7) / 8 * 8;
@@ -579,7 +581,7 @@ int launch_conv_wf(hipStream_t s, int64_t n, const ConvWfPlan& p, TView in, TVie
     WfKernel k = kWfGeo[p.geo].k[p.pool][pre_kind];
     const size_t lds = p.lds_bytes;
     {   // timing experiments only (tools/bench_layer.py): knock-out instantiations of the plain 10^3 kernel
-        static const int dbg = getenv("TH_WF_DBG") ? atoi(getenv("TH_WF_DBG")) : 0;
+        const int dbg = kn.wf_dbg;
         if (dbg > 0 && p.geo == 0 && p.pool == 0 && pre_kind == 0)
             for (const WfDbg& d : kWfDbg) if (d.code == dbg) k = d.k;
     }

@@ -44,6 +44,8 @@ PROTOTYPES = {
     "th_model_fetch": (_i, [_vp, C.c_char_p, _i64, _vp, _i64]),
     "th_model_profile": (_i, [_vp, _i]),
     "th_model_step_info": (_i, [_vp, _i, C.c_char_p, _sz, _pd, _pi64, _pd, _pd, _pd]),
+    "th_model_knobs": (_i, [_vp, C.c_char_p, _sz]),
+    "th_model_guard_info": (_i, [_vp, C.POINTER(C.c_int), _pd, _pd, C.c_char_p, _sz]),
     "th_dev_alloc": (_i, [_i, _sz, C.POINTER(_vp)]),
     "th_dev_free": (_i, [_i, _vp]),
     "th_dev_upload": (_i, [_i, _vp, _vp, _sz]),

@@ -184,6 +184,20 @@ class HipFrameModel:
                             exec_flops=ef.value, bytes=by.value))
         return out
 
+    def guard(self) -> dict:
+        """what the load-time guard found: state 0 not run / 1 passed / 2 tripped, the kept plan's max |dlogit| against the
+        direct fp32 plan on the guard frames, the logit scale, and a note when it tripped (include/timed_hip.h)"""
+        st, d, sc = C.c_int(), C.c_double(), C.c_double()
+        note = C.create_string_buffer(512)
+        _lib.check(self._lib.th_model_guard_info(self._h, C.byref(st), C.byref(d), C.byref(sc), note, 512))
+        return dict(state=st.value, max_dlogit=d.value, logit_scale=sc.value, note=note.value.decode())
+
+    def knobs(self) -> str:
+        """the non-default TH_* knobs this handle was loaded under ("" when none): read once at load, never again"""
+        buf = C.create_string_buffer(1024)
+        _lib.check(self._lib.th_model_knobs(self._h, buf, 1024))
+        return buf.value.decode()
+
     def fetch(self, layer_name: str, n: int, shape) -> np.ndarray:
         out = np.empty((n, *shape), dtype=np.float32)
         _lib.check(self._lib.th_model_fetch(self._h, layer_name.encode(), n, out.ctypes.data, out.size))
