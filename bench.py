@@ -262,6 +262,8 @@ def main():
             assert not np.array_equal(parts[0], parts[1]), "ranks produced identical shards"
 
     if rank == 0:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_legs
         cost = model.cost()
         kernel_flops = sum(s["flops"] for s in model.steps())
         total_frames = n * world * args.steps
@@ -278,13 +280,22 @@ def main():
                        "rows_verified": n,
                        "algo_mflop_per_frame": cost["algo_flops"] / 1e6, "kernel_mflop_per_frame": kernel_flops / 1e6,
                        "exec_mflop_per_frame": cost["exec_flops"] / 1e6, "winograd_layers": sum("k_wino_gemm" in s["label"] for s in model.steps()),
+                       "split_gemm_layers": sum("bf16x3" in s["label"] for s in model.steps()),
+                       "arithmetic": "fp32-input MFMA; Winograd GEMMs: operands split exactly into 3 bf16 pieces, 6 products on bf16 MFMA, "
+                                     "fp32 accumulate (tests hold the same 5e-6 bound)",
+                       "knobs": model.knobs(), "guard": {k: (round(v, 9) if isinstance(v, float) else v) for k, v in model.guard().items() if k != "note"},
                        "device": f"{model.device_arch} {model.device_cus} CUs"},
             # FLOPs the kernels really compute per frame (the SURVEY §8d direct-form count, except that layers on the Cook-Toom /
             # Winograd path count their own, fewer multiply-adds) priced against the fp32-MFMA peak; the direct-form equivalent —
             # what a direct convolution would have to sustain for the same frames/s — is reported beside it and may exceed the peak
-            "model_tflops": fps / world * kernel_flops / 1e12,
-            "model_frac_of_fp32_mfma_peak": fps / world * kernel_flops / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-            "model_direct_equiv_tflops": fps / world * cost["algo_flops"] / 1e12,
+            # schema 5: `model_tflops` has its round 1-3 meaning again — SURVEY §8d's direct-form FLOPs x frames/s, which
+            # minimal-filtering layers do not execute (it may exceed the fp32 peak); what the kernels compute is in the two keys
+            # after it: their own fp32-equivalent multiply-adds, and the share of the wall time the matrix pipes would need for
+            # them at their dense peaks (fp32-input MFMA 157.3 TFLOP/s; bf16x3-split GEMMs: 6 products on the 2500 TFLOP/s bf16 pipe)
+            "schema": 5,
+            "model_tflops": fps / world * cost["algo_flops"] / 1e12,
+            "model_kernel_tflops_fp32_equiv": fps / world * kernel_flops / 1e12,
+            "model_pipe_time_frac": bench_legs.pipe_time_frac(model.steps(), fps / world),
             "hbm": {"algo_bytes_per_frame": algo_bytes, "achieved_GBps": fps / world * algo_bytes / 1e9,
                     "frac": fps / world * algo_bytes / 1e9 / PEAK_HBM_GBS},
         }
@@ -292,11 +303,12 @@ def main():
             dom = max((s for s in model.steps() if s["launches"]), key=lambda s: s["ms"])   # timed region: dominant step only
             avg_ms = dom["ms"] / dom["launches"]
             frames_per_launch = n * args.steps / dom["launches"]
-            achieved = dom["flops"] * frames_per_launch / (avg_ms * 1e-3) / 1e12
-            line["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+            pipe, peak, pflops = bench_legs.step_pipe(dom)       # a bf16x3-split step is priced on the bf16 pipe (6 products)
+            achieved = pflops * frames_per_launch / (avg_ms * 1e-3) / 1e12
+            line["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "pipe": pipe,
+                                "frac": achieved / peak, "traffic": None,
                                 "kernel": dom["label"], "avg_launch_ms": avg_ms, "launches": dom["launches"],
-                                "frames_per_launch": frames_per_launch, "algorithmic_flops_per_launch": dom["flops"] * frames_per_launch,
+                                "frames_per_launch": frames_per_launch, "algorithmic_flops_per_launch": pflops * frames_per_launch,
                                 "measured": "HIP events around every launch of this kernel inside the timed region",
                                 "exec_tflops": dom["exec_flops"] * frames_per_launch / (avg_ms * 1e-3) / 1e12}
             if warm_steps:
@@ -306,17 +318,18 @@ def main():
                     line["roofline"]["share_of_device_time"] = wdom[0]["ms"] / tot_ms
                 line["kernels_from"] = f"{args.warmup} warm-up step(s), every plan step bracketed by HIP events"
                 line["kernels"] = [{"label": s["label"], "ms_total": round(s["ms"], 3), "launches": s["launches"],
-                                    "tflops_algo": (s["flops"] * n * args.warmup / (s["ms"] * 1e-3) / 1e12) if s["ms"] else 0.0}
+                                    "tflops_algo": (s["flops"] * n * args.warmup / (s["ms"] * 1e-3) / 1e12) if s["ms"] else 0.0,
+                                    "pipe": bench_legs.step_pipe(s)[0] if s["flops"] else None,
+                                    "frac_of_pipe_peak": (bench_legs.step_pipe(s)[2] * n * args.warmup / (s["ms"] * 1e-3) / 1e12 /
+                                                          bench_legs.step_pipe(s)[1]) if s["ms"] and s["flops"] else None}
                                    for s in warm_steps]
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(cfg, weights, f"{model.name}-synth")
         if world == 1 and not args.no_extras:
             # secondary legs, outside the timed region (tools/bench_legs.py): each is reported, none feeds `value`
-            sys.path.insert(0, os.path.join(ROOT, "tools"))
-            import bench_legs
             model.profile(0)
             t_legs = time.perf_counter()
-            others = [t for t in ("densecpd", "timed_rotamer") if t != args.topology]
+            others = [t for t in ("densecpd", "timed_rotamer", "prodconn") if t != args.topology]
             # HBM bytes of every kernel of every topology, measured now (two rocprofv3 --pmc child passes on this build)
             pmc = bench_legs.pmc_traffic_inrun([args.topology] + others, args.chunk) if not args.no_pmc else {"error": "--no-pmc"}
             line["pmc"] = {k: v for k, v in pmc.items() if k in ("error", "source")}
@@ -340,9 +353,9 @@ def main():
             base = None if args.no_cpu_baseline else (lambda c, w, t: cpu_baseline(c, w, t, budget_s=8.0, min_s=5.0))
             line["other_configs"] = [bench_legs.topology_rate(t, device, d_frames.ptr, min(n, args.other_frames), args.chunk,
                                                               traffic=pmc.get(t), cpu_baseline=base) for t in others]
-            # the opt-in 7-point Cook-Toom scheme (TH_WINOGRAD=2: F(5,3) in-plane, ~4x the rounding error of the default plan — never
-            # the headline): same frames, its rate and its logits against the default plan's
-            line["other_configs"] += [bench_legs.topology_rate(t, device, d_frames.ptr, min(n, args.other_frames), args.chunk, winograd=2)
+            # the same plans with the Winograd GEMMs on the fp32-input matrix pipe (TH_WINO_SPLIT=0: exact fp32 products instead of
+            # the bf16x3 split): same frames, the rate and the logits against the default plan's
+            line["other_configs"] += [bench_legs.topology_rate(t, device, d_frames.ptr, min(n, args.other_frames), args.chunk, env={"TH_WINO_SPLIT": "0"})
                                       for t in (args.topology, "timed_rotamer") if t in ("timed", "timed_rotamer")]
             line["extras_wall_s"] = time.perf_counter() - t_legs
         # the full record (per-kernel tables of every topology, all e2e/sampler legs) goes to a side file and stderr;

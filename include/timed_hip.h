@@ -120,6 +120,10 @@ int th_model_profile(th_model* m, int enable);
  * algorithmic FLOPs and bytes per frame attributed to the step */
 int th_model_step_info(const th_model* m, int i, char* label, size_t label_len, double* ms, int64_t* launches,
                        double* flops_per_frame, double* exec_flops_per_frame, double* bytes_per_frame);
+/* the SURVEY §8(d) direct-form FLOPs per frame of step i when they differ from what the step's kernel computes (Cook-Toom /
+ * Winograd steps: flops_per_frame of th_model_step_info is their own, smaller count); -1 for every other step */
+int th_model_step_direct_flops(const th_model* m, int i, double* direct_flops_per_frame);
+
 /* Load-time guard.  th_model_load checks the plan it built — Winograd layers, the bf16x3-split GEMMs — against a direct fp32-MFMA
  * plan of the same pack on four internally generated frames: the logits must agree to 1e-5 x max(1, max |logit|).  If they do
  * not, fast features are dropped (split GEMM, 5^3 Winograd, fused 10^3 Winograd, first-layer F(2,3), in that order) until they
@@ -155,6 +159,9 @@ int th_apply_temp_on(int device, const double* probs, int64_t n_res, int n_cls, 
 #define TH_RNG_HOST 0
 #define TH_RNG_PHILOX 1
 #define TH_RNG_MT19937 2
+#define TH_RNG_MT_WORDS 3 /* th_sampler_run only: `uniforms` holds RAW MT19937 state words (uint32, two per draw, as th_mt19937_words
+                           * returns them); the draw kernel tempers them and forms genrand_res53 itself — the doubles are the ones
+                           * np.random.rand returns, the host only advances the recurrence */
 int th_sample(const double* probs, int64_t n_res, int n_cls, int64_t n_samples, double temperature,
               int rng_mode, uint64_t seed, const double* uniforms, int32_t* idx_out);               /* device 0 */
 /* optionally also return the uniforms the device drew (r_out [n_samples,n_res], may be NULL) and
@@ -202,11 +209,32 @@ int th_sampler_draw(th_sampler* s, int64_t n_keys, const int64_t* row_off, int64
                     uint64_t rng_offset, const double* uniforms, const char* cat_letters, int32_t* idx_out, double* r_out,
                     char* letters_out, double* metrics_out);
 
+/* A whole sample.py run in ONE submission (reference sampling_utils.py:118-133 for every key at once): the rows [n_rows, n_cls]
+ * are used as they are (sample.py tempers the matrix first, sample.py:40-41), their running sums (in cum_dtype), every draw, the
+ * one-letter codes and the per-sequence metrics are computed by two kernels between ONE host->device copy (rows, offsets and
+ * letters travel together) and ONE device->host copy; caller-supplied uniforms (TH_RNG_HOST) add the copy of those.  Keys must
+ * cover rows 0..n_rows.  want: bit 0 indices (int32 [total]), bit 1 letters (char [total]), bit 2 metrics (double [n_keys *
+ * n_samples][4]) — in th_sampler_draw's draw order.  *block_out points at a page-locked block owned by the sampler (valid until
+ * its next call); offsets_out[0..2] = byte offset of indices / letters / metrics in it, -1 when not requested.  Indices and
+ * letters are bit-identical to th_sampler_load + th_sampler_draw on the same rows, uniforms / generator settings. */
+/* a page-locked buffer of at least `bytes` owned by the sampler (grow-only, valid until the next call of this function on it or
+ * th_sampler_free): uniforms or raw generator words written here reach the device by direct DMA instead of through HIP's
+ * pageable staging copy */
+int th_sampler_uniform_buffer(th_sampler* s, size_t bytes, void** out);
+int th_sampler_run(th_sampler* s, const double* probs, int64_t n_rows, int n_cls, int cum_dtype, int64_t n_keys, const int64_t* row_off,
+                   int64_t n_samples, int rng_mode, uint64_t seed, uint64_t rng_offset, const double* uniforms, const char* cat_letters,
+                   unsigned want, const void** block_out, int64_t* offsets_out);
+
 /* np.random.rand(n) of NumPy's GLOBAL legacy generator — the reference's source of uniforms, r = np.random.rand(n),
  * sampling_utils.py:81 — replayed natively (host code): key = the 624 MT19937 state words and *pos the position in them, as
  * np.random.get_state() returns them; out receives the same n doubles (genrand_res53) NumPy would produce and key / *pos are left
  * as NumPy would leave them, so np.random.set_state((name, key, pos, has_gauss, cached)) continues the stream seamlessly. */
 int th_mt19937_rand(uint32_t* key, int* pos, int64_t n, double* out);
+/* the same walk through the generator, but `out` receives the 2 n RAW state words the n doubles are made of (untempered, in
+ * consumption order: double i = res53(temper(out[2 i]) >> 5, temper(out[2 i + 1]) >> 6)); key / *pos advance exactly as in
+ * th_mt19937_rand.  For TH_RNG_MT_WORDS: the recurrence stays on the host (it is sequential), tempering and conversion — two
+ * thirds of th_mt19937_rand's time — move into the draw kernel. */
+int th_mt19937_words(uint32_t* key, int* pos, int64_t n, uint32_t* out);
 
 /* ---- text output: replaces np.savetxt(f, matrix, delimiter=",") — design_utils/utils.py:768-771 (float16
  * probabilities) and predict.py:145-146 (full-precision rotamer matrix).  Host code only.  Formats the row-major

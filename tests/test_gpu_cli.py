@@ -67,6 +67,10 @@ def test_predict_cli_parser_matches_reference_flags():
     s = sample.build_parser().parse_args([])
     assert (s.sample_n, s.save_as, s.workers, s.temperature, s.support_old_datasetmap, s.seed, s.predict_rotamers,
             s.path_to_datasetmap) == (100, "all", 8, 1, False, 42, False, "datasetmap.txt")
+    assert s.rng == "numpy"                       # opt-in flag of this build: the default is the reference's stream
+    assert sample.build_parser().parse_args(["--rng", "philox"]).rng == "philox"
+    with pytest.raises(SystemExit):
+        sample.build_parser().parse_args(["--rng", "lcg"])
 
 
 @pytest.mark.parametrize("name", ["dir20_f64", "dir20_f16", "dir338_f16", "edge20"])
@@ -145,6 +149,14 @@ def test_sample_cli_end_to_end(gpu, tmp_path, monkeypatch, temperature):
     assert again == got
     args.seed = 7
     assert json.load(open(sample.main_sample(args)[0])) != got
+    # --rng philox / mt19937: the uniforms are drawn on the GPU from --seed; mt19937 with the same seed IS the numpy stream
+    args.seed = 42
+    args.rng = "mt19937"
+    assert json.load(open(sample.main_sample(args)[0])) == got
+    args.rng = "philox"
+    ph = json.load(open(sample.main_sample(args)[0]))
+    assert ph != got and json.load(open(sample.main_sample(args)[0])) == ph
+    assert [len(v) for v in ph.values()] == [len(v) for v in got.values()]
 
 
 def test_predict_from_frame_pack_equals_hdf5(gpu, tmp_path):

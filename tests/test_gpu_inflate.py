@@ -157,6 +157,29 @@ def test_hdf5_frames_decoded_on_the_gpu_equal_the_host_reader(gpu, tmp_path, gau
     assert np.array_equal(d2.buffer.download(d2.shape, d2.dtype).astype(np.float32), X2.astype(np.float32)) and np.array_equal(y2, yy2)
 
 
+@pytest.mark.parametrize("tok_kb", [64, 1000])
+def test_decode_in_pieces_of_a_bounded_token_arena(gpu, tmp_path, monkeypatch, tok_kb):
+    """the decoder's token arena is bounded (2 GB; the kernels run over pieces of the chunk list that fit it): with the bound forced
+    down to one chunk per piece (64 KB) and to a ragged few (1000 KB: 15 chunks of 16.5 KB x 4 bytes per byte) the frames are the
+    ones the host reader returns, whole batch and arbitrary selection"""
+    import warnings
+    from design_utils import utils
+    monkeypatch.setenv("TH_INFLATE_TOK_KB", str(tok_kb))
+    p = tmp_path / "d.hdf5"
+    frames, labels, flat = _write_dataset(p, gaussian=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fmap, _ = utils.create_flat_dataset_map(p)
+        X, y = utils.load_batch(p, fmap, dtype=np.float32)
+        dev, yd = utils.load_batch_device(p, np.array(fmap), device=gpu)
+        assert np.array_equal(dev.buffer.download(dev.shape, dev.dtype).astype(np.float32), X.astype(np.float32)) and np.array_equal(yd, y)
+        sub = np.array(fmap)[[9, 2, 31, 4, 17]]
+        d2, y2 = utils.load_batch_device(p, sub, device=gpu)
+        X2, yy2 = utils.load_batch(p, sub, dtype=np.float32)
+    assert np.array_equal(d2.buffer.download(d2.shape, d2.dtype).astype(np.float32), X2.astype(np.float32)) and np.array_equal(y2, yy2)
+    utils.release_device_memory()
+
+
 def test_predict_py_with_gpu_inflate_writes_the_same_files(gpu, tmp_path, monkeypatch):
     import warnings
     import predict

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import sampler_oracle as so
-from timed_hip import sampler
+from timed_hip import _lib, sampler
 
 pytestmark = pytest.mark.gpu
 CASES = ["dir20_f64", "dir20_f16", "dir338_f64", "dir338_f16", "edge20"]
@@ -286,3 +286,117 @@ def test_sample_with_multiprocessing_is_one_stream_in_key_order(gpu):
     assert one["a"] == out["a"]
     with pytest.raises(ValueError):
         su.sample_with_multiprocessing(1, ["z"], 2, {"z": []}, None)
+
+
+# ---- th_sampler_run: one submission (round 5) --------------------------------------------------------------------------------
+@pytest.mark.parametrize("n_cls,cum", [(20, np.float64), (20, np.float16), (338, np.float32), (338, np.float64)])
+def test_one_submission_run_equals_load_plus_draw(gpu, n_cls, cum):
+    """th_sampler_run (rows + offsets + letters up in one copy, k_cumsum_draw + k_seq_metrics, one page-locked block back) against
+    th_sampler_load + th_sampler_draw on the same rows and uniforms: indices, letters and metrics bit for bit — ragged keys (1 ..
+    300 residues: several keys inside one 8-row workgroup, keys across workgroup boundaries), float16-rounded rows that sum to
+    less than 1 (fall-through to 0), an all-zero row and a NaN row, running sums in float16 / float32 / float64"""
+    rng = np.random.default_rng(n_cls + np.dtype(cum).itemsize)
+    sizes = [3, 1, 300, 7, 76, 2]
+    mats, off = _keys(rng, n_cls, sizes)
+    rows = np.concatenate(mats).astype(np.float16).astype(np.float64)
+    rows[5] = 0.0
+    rows[11] = np.nan
+    letters = "".join("ACDEFGHIKLMNPQRSTVWY"[i % 20] for i in range(n_cls))
+    n_s = 9
+    r = rng.random(n_s * rows.shape[0])
+    sm = sampler.Sampler(gpu)
+    sm.load(rows, cum_dtype=cum)
+    a = sm.draw(off, n_s, uniforms=r, letters=letters, want_idx=True, want_metrics=True)
+    a = {k: (np.array(v) if isinstance(v, np.ndarray) else v) for k, v in a.items()}
+    b = sm.run(rows, off, n_s, uniforms=r, letters=letters, want_idx=True, want_letters=True, want_metrics=True, cum_dtype=cum)
+    assert np.array_equal(b["idx"], a["idx"]) and np.array_equal(b["letters"], a["letters"])
+    assert np.array_equal(b["metrics"], a["metrics"], equal_nan=True)
+    # the device generators number their draws the same way in both paths
+    for mode, seed in (("philox", 12345), ("mt19937", 7)):
+        a2 = sm.draw(off, n_s, rng=mode, seed=seed, letters=letters)
+        b2 = sm.run(rows, off, n_s, rng=mode, seed=seed, letters=letters, want_metrics=False, cum_dtype=cum)
+        assert np.array_equal(np.array(b2["idx"]), a2["idx"]) and np.array_equal(np.array(b2["letters"]), a2["letters"]), mode
+    # parts that are not requested are absent, the others unchanged
+    c = sm.run(rows, off, n_s, uniforms=r, letters=letters, want_idx=False, want_letters=True, want_metrics=True, cum_dtype=cum)
+    assert c["idx"] is None and np.array_equal(c["letters"], a["letters"]) and np.array_equal(c["metrics"], a["metrics"], equal_nan=True)
+    d = sm.run(rows, off, n_s, uniforms=r, want_idx=True, want_letters=False, want_metrics=False, cum_dtype=cum)
+    assert d["letters"] is None and d["metrics"] is None and np.array_equal(d["idx"], a["idx"])
+    sm.close()
+
+
+def test_run_rejects_bad_arguments(gpu):
+    rng = np.random.default_rng(0)
+    rows = rng.dirichlet(np.full(20, 0.3), size=10)
+    sm = sampler.Sampler(gpu)
+    with pytest.raises(_lib.TimedHipError):
+        sm.run(rows, [0, 4], 2, rng="philox", seed=1, letters="ACDEFGHIKLMNPQRSTVWY")          # keys do not cover the rows
+    with pytest.raises(_lib.TimedHipError):
+        sm.run(rows, [0, 10, 10], 2, rng="philox", seed=1, letters="ACDEFGHIKLMNPQRSTVWY")     # an empty key
+    with pytest.raises(ValueError):
+        sm.run(rows, [0, 10], 2, uniforms=np.zeros(3), letters="ACDEFGHIKLMNPQRSTVWY")
+    with pytest.raises(ValueError):
+        sm.run(rows, [0, 10], 2, rng="philox", seed=1, want_metrics=True)                      # metrics without letters
+    sm.close()
+
+
+@pytest.mark.parametrize("mode", ["philox", "mt19937"])
+def test_device_generators_from_the_reference_entry_points(gpu, mode):
+    """sample_with_multiprocessing(..., rng=, seed=) — the keyword sample.py's --rng passes: uniforms drawn ON the device (rocRAND
+    Philox4x32-10, or MT19937(seed) = np.random.seed(seed); np.random.rand), nothing generated or uploaded by the host.  The
+    sequences are the inverse-CDF draws of exactly those uniforms (checked with the oracle against the generator's own stream),
+    the result depends on the seed only, and NumPy's global generator is left alone."""
+    from design_utils import sampling_utils as su
+    rng = np.random.default_rng(5)
+    sizes = dict(a=17, b=300, c=1)
+    p2p = {k: rng.dirichlet(np.full(20, 0.3), size=n).astype(np.float16).astype(np.float64) for k, n in sizes.items()}
+    np.random.seed(99)
+    before = np.random.get_state()[1].copy()
+    out = su.sample_with_multiprocessing(8, list(p2p), 6, p2p, None, rng=mode, seed=4242)
+    assert np.array_equal(np.random.get_state()[1], before)
+    again = su.sample_with_multiprocessing(8, list(p2p), 6, p2p, None, rng=mode, seed=4242)
+    other = su.sample_with_multiprocessing(8, list(p2p), 6, p2p, None, rng=mode, seed=4243)
+    assert out == again and out != other
+    total = 6 * sum(sizes.values())
+    if mode == "mt19937":
+        stream = so.legacy_uniforms(4242, total)
+    else:
+        stream = sampler.sample_indices(np.full((total, 2), 0.5), 1, rng="philox", seed=4242, return_uniforms=True)[1].ravel()
+    letters = np.array(list("ACDEFGHIKLMNPQRSTVWY"))
+    pos = 0
+    for k, n in sizes.items():
+        r = stream[pos:pos + 6 * n].reshape(6, n)
+        pos += 6 * n
+        want = ["".join(letters[i]) for i in so.choice_indices(p2p[k], r)]
+        assert [t[0] for t in out[k]] == want, k
+    with pytest.raises(ValueError):
+        su.sample_with_multiprocessing(8, list(p2p), 6, p2p, None, rng="xorshift")
+
+
+def test_raw_mt19937_words_mode_is_np_random_rand(gpu):
+    """TH_RNG_MT_WORDS: the host walks the MT19937 recurrence only (th_mt19937_words), the draw kernel tempers the raw words and
+    forms genrand_res53 — the doubles are np.random.rand's, the generator's state afterwards is NumPy's, and a run drawn this way
+    equals the run drawn from the doubles.  Start positions around the 624-word block boundary, odd positions (a pair straddles two
+    blocks), lengths above and below the replay threshold."""
+    from design_utils import sampling_utils as su
+    rng = np.random.default_rng(1)
+    rows = rng.dirichlet(np.full(20, 0.3), size=37).astype(np.float16).astype(np.float64)
+    letters = "ACDEFGHIKLMNPQRSTVWY"
+    sm = sampler.Sampler(gpu)
+    for seed, burn, n_s in ((0, 0, 120), (5, 311, 200), (42, 623, 130), (7, 1, 111)):
+        np.random.seed(seed)
+        np.random.rand(burn) if burn else None
+        if burn % 2 == 0 and burn:
+            np.random.randint(0, 10)              # an odd word position: the next double's pair starts on an odd index
+        state = np.random.get_state()
+        want = np.random.rand(n_s * 37)
+        after = np.random.get_state()
+        np.random.set_state(state)
+        words = su._legacy_words(n_s * 37)
+        now = np.random.get_state()
+        assert now[2] == after[2] and np.array_equal(now[1], after[1])
+        assert np.random.rand() == (np.random.set_state(after), np.random.rand())[1]
+        a = sm.run(rows, [0, 37], n_s, uniforms=want, rng="host", letters=letters)
+        a = {k: np.array(v) for k, v in a.items() if isinstance(v, np.ndarray)}
+        b = sm.run(rows, [0, 37], n_s, uniforms=words, rng="mt_words", letters=letters)
+        assert np.array_equal(b["idx"], a["idx"]) and np.array_equal(b["letters"], a["letters"])
+    sm.close()

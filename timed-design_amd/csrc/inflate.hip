@@ -895,6 +895,9 @@ inline RingGeom ring_geom(int64_t max_len) {
     return {65536u, 65535u, 0u};
 }
 
+// upper bound of the decoder's token arena per device (inflate_place_device decodes in pieces that fit it)
+constexpr size_t kTokArenaBytes = (size_t)8 << 30;
+
 struct DevBuf {
     void* p = nullptr; size_t cap = 0;
     int ensure(size_t bytes) {
@@ -1042,10 +1045,17 @@ int inflate_place_device(int device, hipStream_t stream, const void* span, int64
     // a chunk that fits the LDS window whole is placed by k_lz_resolve itself: no raw bytes in HBM, no placement kernel
     const bool fused = ring_geom(chunk_bytes).mask == 0xffffffffu && chunk_bytes / esz < (1ll << 31);
     if (shuffle && !fused) TH_FAIL(TH_EUNSUP, "inflate: a shuffled chunk of %lld bytes does not fit the LDS window", (long long)chunk_bytes);
+    // The token arena holds 4 bytes per UNCOMPRESSED byte (worst case: every byte a literal) — 7.3 GB for a 4096-frame call of
+    // float64 frames, whose hipMalloc was most of a cold process's first call.  The two decode kernels therefore run over pieces of
+    // the chunk list that need at most kTokArenaBytes of tokens (1152 float64 frames: 36 864 streams per launch, still 18 waves per
+    // SIMD of work); the pieces queue on the stream back to back and reuse the arena.
+    size_t arena = kTokArenaBytes;
+    if (const char* e = getenv("TH_INFLATE_TOK_KB")) arena = (size_t)std::max(1, atoi(e)) << 10;    // tests: force many pieces (read at every call)
+    const int64_t piece = std::max<int64_t>(1, std::min<int64_t>(n_chunks, (int64_t)(arena / sizeof(unsigned)) / std::max<int64_t>(chunk_bytes, 1)));
     if ((rc = d_comp.ensure((size_t)span_len + 16)) || (rc = d_raw.ensure(fused ? 16 : (size_t)(n_chunks * cb8) + 16)) ||
         (rc = d_desc.ensure((size_t)n_chunks * sizeof(InfDesc))) || (rc = d_st.ensure((size_t)n_chunks * sizeof(int))) ||
         (rc = d_ds.ensure((size_t)n_chunks * sizeof(int))) || (rc = d_coff.ensure((size_t)n_chunks * 8 * sizeof(int))) ||
-        (rc = d_tok.ensure((size_t)(n_chunks * chunk_bytes + 16) * sizeof(unsigned))) || (rc = d_nt.ensure((size_t)n_chunks * sizeof(long long))) ||
+        (rc = d_tok.ensure((size_t)(piece * chunk_bytes + 16) * sizeof(unsigned))) || (rc = d_nt.ensure((size_t)n_chunks * sizeof(long long))) ||
         (rc = d_ad.ensure((size_t)n_chunks * sizeof(unsigned)))) {
         // out of device memory (TH_ENOMEM) or a failed allocation: keep nothing — the caller retries with fewer datasets or reads
         // through the host, and the model's arenas / the pooled batch buffers get the memory back
@@ -1056,15 +1066,12 @@ int inflate_place_device(int device, hipStream_t stream, const void* span, int64
     const auto t_begin = std::chrono::steady_clock::now();
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
     std::vector<InfDesc> desc((size_t)n_chunks);
-    for (int64_t i = 0; i < n_chunks; ++i) desc[(size_t)i] = {src_off[i], csize[i], i * cb8, chunk_bytes, i * chunk_bytes};
+    for (int64_t i = 0; i < n_chunks; ++i) desc[(size_t)i] = {src_off[i], csize[i], i * cb8, chunk_bytes, (i % piece) * chunk_bytes};
     HIP_TRY(hipMemcpyAsync(d_comp.p, span, (size_t)span_len, hipMemcpyHostToDevice, stream));
     const double t_span = since();
     HIP_TRY(hipMemcpyAsync(d_desc.p, desc.data(), (size_t)n_chunks * sizeof(InfDesc), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(d_ds.p, ds, (size_t)n_chunks * sizeof(int), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(d_coff.p, coff8, (size_t)n_chunks * 8 * sizeof(int), hipMemcpyHostToDevice, stream));
-    launch_tokens(stream, (const unsigned char*)d_comp.p, (long long)span_len, (const InfDesc*)d_desc.p, (long long)n_chunks, (unsigned*)d_tok.p,
-                  (long long*)d_nt.p, (int*)d_st.p, (unsigned*)d_ad.p, 1);
-    HIP_TRY(hipGetLastError());
     PlaceArgs a;
     a.raw = (const unsigned char*)d_raw.p; a.chunk_bytes = cb8; a.ds = (const int*)d_ds.p; a.coff = (const int*)d_coff.p;
     a.rank = rank; a.esz = esz; a.conv = conv; a.out = (unsigned char*)d_out; a.out_elems = 1;
@@ -1075,10 +1082,18 @@ int inflate_place_device(int device, hipStream_t stream, const void* span, int64
     {
         const RingGeom rg = ring_geom(chunk_bytes);
         HIP_TRY(hipFuncSetAttribute((const void*)k_lz_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-        hipLaunchKernelGGL(k_lz_resolve, dim3((unsigned)n_chunks), dim3(kLanes), rg.lds + rg.spare, stream, (const unsigned*)d_tok.p, (const long long*)d_nt.p,
-                           (const InfDesc*)d_desc.p, (long long)n_chunks, (unsigned char*)d_raw.p, (int*)d_st.p, rg.mask, a, fused ? 1 : 0,
-                           (const unsigned*)d_ad.p, 1, rg.lds);
-        HIP_TRY(hipGetLastError());
+        for (int64_t i0 = 0; i0 < n_chunks; i0 += piece) {       // both kernels index their per-chunk arrays from the piece's first chunk
+            const int64_t cnt = std::min(piece, n_chunks - i0);
+            launch_tokens(stream, (const unsigned char*)d_comp.p, (long long)span_len, (const InfDesc*)d_desc.p + i0, (long long)cnt, (unsigned*)d_tok.p,
+                          (long long*)d_nt.p + i0, (int*)d_st.p + i0, (unsigned*)d_ad.p + i0, 1);
+            HIP_TRY(hipGetLastError());
+            PlaceArgs ap = a;
+            ap.ds = a.ds + i0; ap.coff = a.coff + 8 * i0;
+            hipLaunchKernelGGL(k_lz_resolve, dim3((unsigned)cnt), dim3(kLanes), rg.lds + rg.spare, stream, (const unsigned*)d_tok.p, (const long long*)d_nt.p + i0,
+                               (const InfDesc*)d_desc.p + i0, (long long)cnt, (unsigned char*)d_raw.p, (int*)d_st.p + i0, rg.mask, ap, fused ? 1 : 0,
+                               (const unsigned*)d_ad.p + i0, 1, rg.lds);
+            HIP_TRY(hipGetLastError());
+        }
     }
     if (!fused) {
         hipLaunchKernelGGL(k_place_chunks, dim3((unsigned)n_chunks), dim3(256), 0, stream, a, (long long)n_chunks);

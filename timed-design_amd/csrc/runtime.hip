@@ -818,7 +818,8 @@ int plan(th_model* m) {
                         }
                         st.flops = wp.gemm_flops;
                         st.direct_flops = direct;
-                        st.exec_flops = wp.exec_flops;
+                        // split GEMM: six bf16 piece products per fp32 multiply-add — what the bf16 matrix pipe issues
+                        st.exec_flops = wp.split ? 6.0 * wp.exec_flops : wp.exec_flops;
                         st.bytes = 4.0 * ((double)vf + (double)mf);
                         st.label = n.name + ": " + wp.label + (wp.split ? " [k_wino_gemm_b3]" : " [k_wino_gemm]");
                         st.run = [=](hipStream_t s, int64_t cnt) { return launch_wino_gemm(s, cnt, wp, Vp(), Mp(), dw); };
@@ -999,6 +1000,35 @@ int plan(th_model* m) {
                     st.bytes = 4.0 * (F + O);
                     st.label = n.name + ": dense";
                     st.run = [=](hipStream_t s, int64_t cnt) { return launch_dense(s, cnt, M->view(src), M->view(dst), dw, dbias, po); };
+                }
+                if (n.op == OP_CONV3D) {
+                    // a 3x3x3 stride-1 layer that stays on a direct kernel says why no minimal-filtering form took it (tools/plan_report.py)
+                    const Node& sn = N[src];
+                    const ConvGeom g = geom_of(n, sn);
+                    const bool k333 = g.kd == 3 && g.kh == 3 && g.kw == 3 && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.dd == 1 && g.dh == 1 && g.dw == 1;
+                    const bool fast = st.label.find("conv_wf<") != std::string::npos || st.label.find("conv_first_w<") != std::string::npos;
+                    if (k333 && !fast) {
+                        std::string why;
+                        const bool same = g.pz == 1 && g.py == 1 && g.px == 1;
+                        const bool first = src == M->input_node;
+                        if (!use_mfma || !fuse) why = "load flags select the direct kernels";
+                        else if (!same) why = "'valid' padding (the Cook-Toom forms are built for 'same')";
+                        else if (first && sn.C <= 8 && n.C <= 32) why = M->knobs.first_wino ? "odd computed width" : "TH_FIRST_WINO=0";
+                        else if (sn.D == 5 && sn.H == 5 && sn.W == 5) {
+                            if (!M->winograd) why = "TH_WINOGRAD=0";
+                            else if (f.pool >= 0) why = "a pooling layer is fused behind it";
+                            else if (sn.C < 32 || sn.C % 32) why = "Cin is not a multiple of 32";
+                            else if (n.C < 64) why = "Cout < 64 (a 128-column GEMM block would run mostly empty)";
+                            else why = "softmax fused into the layer";
+                        } else if (sn.H % 2 == 0 && sn.W % 2 == 0 && sn.D * (sn.H / 2) * (sn.W / 2) <= 250) {
+                            if (!M->wfused) why = "TH_WFUSED=0";
+                            else if (sn.C < 16 || sn.C % 4) why = "Cin < 16 or not a multiple of 4";
+                            else if (!(sn.D == 10 && sn.H == 10 && sn.W == 10)) why = "conv_wf is instantiated for 10^3 volumes only";
+                            else why = "input view is not 16-byte aligned";
+                        } else why = "no minimal-filtering kernel for a " + std::to_string(sn.D) + "x" + std::to_string(sn.H) + "x" + std::to_string(sn.W) +
+                                     " volume (conv_wf: 10^3, conv_wino: 5^3)";
+                        st.label = label_note(st.label, (" (direct form: " + why + ")").c_str());
+                    }
                 }
                 add_step(st);
                 if (split_softmax) {
@@ -1786,6 +1816,12 @@ int th_model_step_info(const th_model* m, int i, char* label, size_t label_len, 
     if (flops_per_frame) *flops_per_frame = s.flops;
     if (exec_flops_per_frame) *exec_flops_per_frame = s.exec_flops;
     if (bytes_per_frame) *bytes_per_frame = s.bytes;
+    return TH_OK;
+}
+
+int th_model_step_direct_flops(const th_model* m, int i, double* direct_flops_per_frame) {
+    if (!m || i < 0 || i >= (int)m->steps.size() || !direct_flops_per_frame) TH_FAIL(TH_EINVAL, "bad step index");
+    *direct_flops_per_frame = m->steps[i].direct_flops;
     return TH_OK;
 }
 

@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <memory>
 #include <mutex>
 #include <vector>
@@ -142,6 +143,93 @@ __global__ void __launch_bounds__(256) k_draw(const double* __restrict__ c, cons
         }
         idx[d] = first;
         if (r_out) r_out[d] = r;
+        if (letters_out) letters_out[d] = letters[first];
+    }
+}
+
+// ---- one launch for a whole run (th_sampler_run): running sums + draws + letters -----------------------------------------------
+// k_temper_cumsum + k_draw of a resident sampler are two launches with the running sums written to and read back from HBM in
+// between, and on a 300 x 20 matrix k_temper_cumsum is 5 workgroups of 64 sequential row-walkers: 16 us, half the device time
+// of a config-5 call.  Here a workgroup owns R = 8 rows: eight threads walk them (the same strictly left-to-right sum in the
+// rows' own dtype, the same finite / non-decreasing flag) into LDS, then all 256 threads draw for those rows — thread (row
+// t % 8, sample t / 8 + 32 j) — with k_draw's own compare, bisection rule and Philox subsequence numbering (draw d of the
+// reference's order), so indices and letters are bit-identical to the two-launch path.  Rows are used as they are
+// (TH_TEMPER_NONE): sample.py tempers the whole matrix before it is cut into keys (sample.py:40-41).
+constexpr int kFusedRows = 8;
+__global__ void __launch_bounds__(256) k_cumsum_draw(const double* __restrict__ p, int64_t n_rows, int n_cls, int cum_dtype,
+                                                     const int64_t* __restrict__ row_off, int n_keys, int64_t n_samples, int rng_mode,
+                                                     uint64_t seed, uint64_t rng_offset, const double* __restrict__ uniforms,
+                                                     int32_t* __restrict__ idx, const char* __restrict__ letters,
+                                                     char* __restrict__ letters_out) {
+    extern __shared__ double lds[];                        // [R][n_cls | 1] running sums, then R flags, R key starts, R key lengths
+    const int ld = n_cls | 1;
+    const int64_t row0 = (int64_t)blockIdx.x * kFusedRows;
+    const int rows = (int)min<int64_t>(kFusedRows, n_rows - row0);
+    int64_t* meta = reinterpret_cast<int64_t*>(lds + (size_t)kFusedRows * ld);     // [3][R]: monotone flag, first row of the key, rows of the key
+    for (int k = threadIdx.x; k < rows * n_cls; k += 256) lds[(k / n_cls) * ld + k % n_cls] = p[row0 * n_cls + k];
+    __syncthreads();
+    if ((int)threadIdx.x < rows) {
+        double* cr = lds + (size_t)threadIdx.x * ld;
+        double run = 0.;
+        bool mono = true;
+        for (int j = 0; j < n_cls; ++j) {
+            const double x = cr[j];
+            double nx = (j == 0) ? x : run + x;
+            if (cum_dtype == TH_F32) nx = (j == 0) ? x : (double)((float)run + (float)x);
+            else if (cum_dtype == TH_F16) nx = (j == 0) ? x : (double)(_Float16)((float)(_Float16)run + (float)(_Float16)x);
+            mono = mono && (nx >= run || j == 0) && (nx - nx == 0.0);
+            run = nx;
+            cr[j] = run;
+        }
+        const int64_t row = row0 + threadIdx.x;
+        int lo = 0, hi = n_keys;                           // the key that owns this row
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (row_off[mid] <= row) lo = mid; else hi = mid;
+        }
+        meta[threadIdx.x] = mono ? 1 : 0;
+        meta[kFusedRows + threadIdx.x] = row_off[lo];
+        meta[2 * kFusedRows + threadIdx.x] = row_off[lo + 1] - row_off[lo];
+    }
+    __syncthreads();
+    const int r = threadIdx.x % kFusedRows;
+    if (r >= rows) return;
+    const double* cr = lds + (size_t)r * ld;
+    const bool mono = meta[r] != 0;
+    const int64_t k0 = meta[kFusedRows + r], n_res = meta[2 * kFusedRows + r];
+    const int64_t i = row0 + r - k0;
+    // blockIdx.y cuts the samples into slices of gridDim.y-strided groups of 32: a 300 x 1000 run is 38 x 32 workgroups with ONE
+    // draw per thread (a workgroup that looped over all samples of its rows ran 31 dependent uniform loads per thread: 85 us)
+    for (int64_t s = (int64_t)blockIdx.y * (256 / kFusedRows) + threadIdx.x / kFusedRows; s < n_samples; s += (int64_t)gridDim.y * (256 / kFusedRows)) {
+        const int64_t d = n_samples * k0 + s * n_res + i;
+        double u;
+        if (rng_mode == TH_RNG_PHILOX) {
+            rocrand_state_philox4x32_10 st;
+            rocrand_init(seed, rng_offset + (uint64_t)d, 0, &st);
+            u = rocrand_uniform_double(&st);
+        } else if (rng_mode == TH_RNG_MT_WORDS) {            // raw MT19937 words: temper + genrand_res53 here (exact: a 53-bit integer / 2^53)
+            const uint2 w = reinterpret_cast<const uint2*>(uniforms)[d];
+            uint32_t a = w.x, b = w.y;
+            a ^= a >> 11; a ^= (a << 7) & 0x9d2c5680u; a ^= (a << 15) & 0xefc60000u; a ^= a >> 18;
+            b ^= b >> 11; b ^= (b << 7) & 0x9d2c5680u; b ^= (b << 15) & 0xefc60000u; b ^= b >> 18;
+            u = ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
+        } else {
+            u = uniforms[d];
+        }
+        int first = 0;
+        if (mono && n_cls > 32) {
+            int a = 0, b = n_cls;
+            while (a < b) {
+                const int mid = (a + b) >> 1;
+                if (cr[mid] > u) b = mid; else a = mid + 1;
+            }
+            first = a < n_cls ? a : 0;
+        } else {
+            for (int j = 0; j < n_cls; ++j) {
+                if (cr[j] > u) { first = j; break; }
+            }
+        }
+        if (idx) idx[d] = first;
         if (letters_out) letters_out[d] = letters[first];
     }
 }
@@ -333,6 +421,8 @@ struct th_sampler {
     int n_cls = 0;
     Scratch dp, dq, dc, dflags, drow, du, di, dr, dlet, dcat, dmet, dtab;
     Scratch hq;                     // host buffer for the powered rows
+    Scratch hu;                     // page-locked buffer handed to the caller for its uniforms / raw generator words (th_sampler_uniform_buffer)
+    Scratch hin, din, hout, dout;   // th_sampler_run: ONE page-locked input block / device copy, ONE device output block / page-locked copy
     bool tables = false;
     std::mutex mu;
 };
@@ -468,6 +558,98 @@ int sampler_draw(th_sampler* S, int64_t n_keys, const int64_t* row_off, int64_t 
     return TH_OK;
 }
 
+// th_sampler_run: a whole sample.py run as ONE submission.  Inputs (row offsets, category letters, probability rows) go through one
+// page-locked block and one host->device copy; k_cumsum_draw and k_seq_metrics write into one device block — [metrics | idx |
+// letters] — that comes back in one copy into a page-locked block owned by the sampler (valid until its next call).  With a
+// device generator that is two copies and two kernels per call; caller-supplied uniforms add the copy of those.
+inline size_t up16(size_t x) { return (x + 15) / 16 * 16; }
+
+int sampler_run_fused(th_sampler* S, const double* probs, int64_t n_rows, int n_cls, int cum_dtype, int64_t n_keys, const int64_t* row_off,
+                      int64_t n_samples, int rng_mode, uint64_t seed, uint64_t rng_offset, const double* uniforms, const char* cat_letters,
+                      unsigned want, const void** block_out, int64_t* offsets_out) {
+    if (!S || !probs || !row_off || !block_out || !offsets_out || n_rows <= 0 || n_cls <= 0 || n_keys <= 0 || n_samples < 0)
+        TH_FAIL(TH_EINVAL, "th_sampler_run: bad argument");
+    if (cum_dtype != TH_F64 && cum_dtype != TH_F32 && cum_dtype != TH_F16) TH_FAIL(TH_EINVAL, "th_sampler_run: running-sum dtype %d", cum_dtype);
+    if (n_keys > 0x7fffffff) TH_FAIL(TH_EINVAL, "th_sampler_run: too many keys");
+    if (row_off[0] != 0 || row_off[n_keys] != n_rows) TH_FAIL(TH_EINVAL, "th_sampler_run: the keys must cover rows 0..n_rows");
+    for (int64_t k = 0; k < n_keys; ++k)
+        if (row_off[k + 1] <= row_off[k]) TH_FAIL(TH_EINVAL, "th_sampler_run: key %lld has no rows", (long long)k);
+    if (rng_mode < TH_RNG_HOST || rng_mode > TH_RNG_MT_WORDS) TH_FAIL(TH_EINVAL, "th_sampler_run: rng_mode %d", rng_mode);
+    if ((rng_mode == TH_RNG_HOST || rng_mode == TH_RNG_MT_WORDS) && n_samples > 0 && !uniforms)
+        TH_FAIL(TH_EINVAL, "th_sampler_run: rng_mode %d needs uniforms", rng_mode);
+    if (rng_mode == TH_RNG_MT19937 && seed > 0xffffffffULL) TH_FAIL(TH_EINVAL, "th_sampler_run: MT19937 seed must fit 32 bits");
+    const bool want_idx = want & 1u, want_let = (want & 2u) != 0, want_met = (want & 4u) != 0;
+    if ((want_let || want_met) && !cat_letters) TH_FAIL(TH_EINVAL, "th_sampler_run: letters / metrics need cat_letters");
+    if (!(want & 7u)) TH_FAIL(TH_EINVAL, "th_sampler_run: nothing requested");
+    HIP_TRY(hipSetDevice(S->device));
+    StreamDrain drain{S->stream};
+    const int64_t total = n_samples * n_rows, n_seq = n_keys * n_samples;
+    // ---- input block: [row_off][letters][rows]
+    const size_t o_off = 0, o_cat = up16((size_t)(n_keys + 1) * 8), o_p = o_cat + up16((size_t)n_cls),
+                 in_bytes = o_p + (size_t)n_rows * n_cls * 8;
+    S->hin.host = true;
+    int rc;
+    if ((rc = S->hin.ensure(in_bytes)) || (rc = S->din.ensure(in_bytes))) return rc;
+    char* hi = (char*)S->hin.p;
+    std::memcpy(hi + o_off, row_off, (size_t)(n_keys + 1) * 8);
+    if (cat_letters) std::memcpy(hi + o_cat, cat_letters, (size_t)n_cls);
+    std::memcpy(hi + o_p, probs, (size_t)n_rows * n_cls * 8);
+    HIP_TRY(hipMemcpyAsync(S->din.p, hi, in_bytes, hipMemcpyHostToDevice, S->stream));
+    const char* di = (const char*)S->din.p;
+    // ---- uniforms
+    if (rng_mode != TH_RNG_PHILOX && total > 0) {
+        if ((rc = S->du.ensure((size_t)total * sizeof(double)))) return rc;
+        if (rng_mode == TH_RNG_HOST || rng_mode == TH_RNG_MT_WORDS) {      // doubles, or two raw 32-bit words per draw: 8 bytes either way
+            HIP_TRY(hipMemcpyAsync(S->du.p, uniforms, (size_t)total * sizeof(double), hipMemcpyHostToDevice, S->stream));
+        } else {
+            hipLaunchKernelGGL(k_mt19937_uniforms, dim3(1), dim3(256), 0, S->stream, (uint32_t)seed, rng_offset, total, (double*)S->du.p);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    // ---- output block: [metrics n_seq x 4 doubles][idx total x int32][letters total bytes]; only the requested parts exist
+    const size_t m_bytes = want_met ? up16((size_t)n_seq * 4 * sizeof(double)) : 0;
+    const size_t i_bytes = want_idx ? up16((size_t)total * sizeof(int32_t)) : 0;
+    const bool dev_letters = want_let || want_met;
+    const size_t l_bytes = dev_letters ? up16((size_t)total) : 0;
+    const size_t out_bytes = m_bytes + i_bytes + l_bytes;
+    S->hout.host = true;
+    if ((rc = S->dout.ensure(out_bytes + 16)) || (rc = S->hout.ensure(out_bytes + 16))) return rc;
+    char* dout = (char*)S->dout.p;
+    offsets_out[0] = want_idx ? (int64_t)m_bytes : -1;
+    offsets_out[1] = want_let ? (int64_t)(m_bytes + i_bytes) : -1;
+    offsets_out[2] = want_met ? 0 : -1;
+    if (total > 0) {
+        const size_t lds = ((size_t)kFusedRows * (n_cls | 1)) * sizeof(double) + 3 * kFusedRows * sizeof(int64_t);
+        if (lds > 160 * 1024) TH_FAIL(TH_EUNSUP, "th_sampler_run: %d categories per row exceed the LDS budget", n_cls);
+        if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_cumsum_draw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const int64_t row_groups = (n_rows + kFusedRows - 1) / kFusedRows;
+        const int64_t slices = std::max<int64_t>(1, std::min<int64_t>({(n_samples + 31) / 32, 65535, (8192 + row_groups - 1) / row_groups}));
+        hipLaunchKernelGGL(k_cumsum_draw, dim3((unsigned)row_groups, (unsigned)slices), dim3(256), lds, S->stream,
+                           (const double*)(di + o_p), n_rows, n_cls, cum_dtype, (const int64_t*)(di + o_off), (int)n_keys, n_samples, rng_mode,
+                           seed, rng_offset, (const double*)S->du.p, want_idx ? (int32_t*)(dout + m_bytes) : nullptr, di + o_cat,
+                           dev_letters ? dout + m_bytes + i_bytes : nullptr);
+        HIP_TRY(hipGetLastError());
+        if (want_met) {
+            if (!S->tables) {
+                std::unique_ptr<MetricTables> T(new MetricTables);
+                build_metric_tables(T.get());
+                if ((rc = S->dtab.ensure(sizeof(MetricTables)))) return rc;
+                HIP_TRY(hipMemcpy(S->dtab.p, T.get(), sizeof(MetricTables), hipMemcpyHostToDevice));
+                S->tables = true;
+            }
+            hipLaunchKernelGGL(k_seq_metrics, dim3((unsigned)((n_seq + 3) / 4)), dim3(256), 0, S->stream, (const char*)(dout + m_bytes + i_bytes),
+                               (const int64_t*)(di + o_off), (int)n_keys, n_samples, (const MetricTables*)S->dtab.p, (double*)dout);
+            HIP_TRY(hipGetLastError());
+        }
+        // one copy back: the letters are last, so a call that does not return them copies the prefix in front of them only
+        const size_t back = want_let ? out_bytes : m_bytes + i_bytes;
+        if (back) HIP_TRY(hipMemcpyAsync(S->hout.p, dout, back, hipMemcpyDeviceToHost, S->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(S->stream));
+    *block_out = S->hout.p;
+    return TH_OK;
+}
+
 // one lazily created sampler per device behind the one-shot entry points (th_apply_temp / th_sample / th_sample_ex)
 std::mutex g_default_mu;
 std::vector<th_sampler*> g_default;
@@ -502,7 +684,8 @@ void th_sampler_free(th_sampler* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    for (Scratch* b : {&s->dp, &s->dq, &s->dc, &s->dflags, &s->drow, &s->du, &s->di, &s->dr, &s->dlet, &s->dcat, &s->dmet, &s->dtab, &s->hq})
+    for (Scratch* b : {&s->dp, &s->dq, &s->dc, &s->dflags, &s->drow, &s->du, &s->di, &s->dr, &s->dlet, &s->dcat, &s->dmet, &s->dtab, &s->hq,
+                       &s->hin, &s->din, &s->hout, &s->dout, &s->hu})
         b->release();
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
@@ -522,6 +705,25 @@ int th_sampler_draw(th_sampler* s, int64_t n_keys, const int64_t* row_off, int64
     std::lock_guard<std::mutex> lock(s->mu);
     return sampler_draw(s, n_keys, row_off, n_samples, rng_mode, seed, rng_offset, uniforms, cat_letters, idx_out, r_out,
                         letters_out, metrics_out);
+}
+
+int th_sampler_uniform_buffer(th_sampler* s, size_t bytes, void** out) {
+    if (!s || !out) TH_FAIL(TH_EINVAL, "null argument");
+    std::lock_guard<std::mutex> lock(s->mu);
+    HIP_TRY(hipSetDevice(s->device));
+    s->hu.host = true;
+    if (int rc = s->hu.ensure(bytes)) return rc;
+    *out = s->hu.p;
+    return TH_OK;
+}
+
+int th_sampler_run(th_sampler* s, const double* probs, int64_t n_rows, int n_cls, int cum_dtype, int64_t n_keys, const int64_t* row_off,
+                   int64_t n_samples, int rng_mode, uint64_t seed, uint64_t rng_offset, const double* uniforms, const char* cat_letters,
+                   unsigned want, const void** block_out, int64_t* offsets_out) {
+    if (!s) TH_FAIL(TH_EINVAL, "null sampler");
+    std::lock_guard<std::mutex> lock(s->mu);
+    return sampler_run_fused(s, probs, n_rows, n_cls, cum_dtype, n_keys, row_off, n_samples, rng_mode, seed, rng_offset, uniforms, cat_letters,
+                             want, block_out, offsets_out);
 }
 
 }  // extern "C"
@@ -575,6 +777,21 @@ inline double res53(uint32_t a, uint32_t b) {       // a, b already shifted: 27 
     return ((double)(int32_t)a * 67108864.0 + (double)(int32_t)b) * (1.0 / 9007199254740992.0);
 }
 }  // namespace
+
+extern "C" int th_mt19937_words(uint32_t* key, int* pos_io, int64_t n, uint32_t* out) {
+    if (!key || !pos_io || n < 0 || (!out && n > 0)) TH_FAIL(TH_EINVAL, "th_mt19937_words: null argument");
+    int pos = *pos_io;
+    if (pos < 0 || pos > 624) TH_FAIL(TH_EINVAL, "th_mt19937_words: position %d outside 0..624", pos);
+    int64_t words = 2 * n;
+    while (words > 0) {
+        if (pos >= 624) { mt19937_next_block(key); pos = 0; }
+        const int cnt = (int)std::min<int64_t>(words, 624 - pos);
+        std::memcpy(out, key + pos, (size_t)cnt * sizeof(uint32_t));
+        out += cnt; words -= cnt; pos += cnt;
+    }
+    *pos_io = pos;
+    return TH_OK;
+}
 
 extern "C" int th_mt19937_rand(uint32_t* key, int* pos_io, int64_t n, double* out) {
     if (!key || !pos_io || n < 0 || (!out && n > 0)) TH_FAIL(TH_EINVAL, "th_mt19937_rand: null argument");

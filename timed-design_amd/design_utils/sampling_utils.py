@@ -127,11 +127,41 @@ def _legacy_rand(n: int) -> np.ndarray:
         return out
 
 
-def _sample_keys(keys, sample_n: int, pdb_to_probability: dict, rotamer_categories, device: int = 0) -> dict:
-    """All ``keys`` in ONE resident-sampler pass: rows of every key concatenated and uploaded once, one draw launch
-    over (key, sample, residue), metrics reduced on the device, three arrays copied back.  Uniforms come from the
-    global legacy generator in the reference's order — for key: for sample: rand(n_res) — which one rand() call of the
-    total length reproduces exactly (the stream is consumed value by value)."""
+def _legacy_words(n: int, out=None):
+    """The RAW state words behind ``np.random.rand(n)`` (two per double), the global generator advanced exactly as rand(n) would
+    have advanced it: th_mt19937_words walks the recurrence on the host — it is sequential — and leaves tempering and the 53-bit
+    conversion (two thirds of _legacy_rand's time) to the draw kernel (TH_RNG_MT_WORDS).  None when the generator is not MT19937
+    or the native call fails: the caller falls back to _legacy_rand."""
+    n = int(n)
+    with _RAND_LOCK:
+        st = np.random.get_state()
+        if st[0] != "MT19937":
+            return None
+        from timed_hip import _lib
+        key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
+        pos = C.c_int(int(st[2]))
+        if out is None:
+            out = np.empty(2 * n, dtype=np.uint32)
+        if _lib.load().th_mt19937_words(key.ctypes.data_as(C.c_void_p), C.byref(pos), n, out.ctypes.data_as(C.c_void_p)) != 0:
+            return None
+        np.random.set_state((st[0], key, int(pos.value), st[3], st[4]))
+        return out
+
+
+RNG_CHOICES = ("numpy", "philox", "mt19937")
+
+
+def _sample_keys(keys, sample_n: int, pdb_to_probability: dict, rotamer_categories, device: int = 0, rng: str = "numpy",
+                 seed: int = 0) -> dict:
+    """All ``keys`` in ONE submission (th_sampler_run): rows of every key, offsets and letters uploaded together, the running
+    sums, every draw over (key, sample, residue), the letters and the per-sequence metrics computed by two kernels, one
+    page-locked block copied back.  ``rng="numpy"`` (the default): uniforms from the global legacy generator in the reference's
+    order — for key: for sample: rand(n_res) — which one rand() call of the total length reproduces exactly (the stream is
+    consumed value by value).  ``"philox"`` (rocRAND Philox4x32-10, one subsequence per draw) and ``"mt19937"`` (MT19937 seeded
+    with ``seed`` like np.random.seed, generated ON the device) draw their uniforms on the GPU: nothing is generated or uploaded
+    by the host, the result depends on ``seed`` only and is NOT the reference's stream."""
+    if rng not in RNG_CHOICES:
+        raise ValueError(f"rng must be one of {RNG_CHOICES}, got {rng!r}")
     keys = list(keys)
     if not keys:
         return {}
@@ -148,13 +178,27 @@ def _sample_keys(keys, sample_n: int, pdb_to_probability: dict, rotamer_categori
     row_off = np.concatenate([[0], np.cumsum([m.shape[0] for m in mats])]).astype(np.int64)
     cats = _category_letters(rotamer_categories, n_cls)
     one_letter = all(len(c) == 1 for c in cats[:n_cls])
-    r = _legacy_rand(int(sample_n) * int(row_off[-1]))
     sm = _sampler.default_sampler(device)
     on_device = one_letter and METRICS_SOURCE != "ampal"
-    with sm.lock:       # the process-wide sampler is shared between threads: load + draw is one operation
-        sm.load(np.concatenate(mats).astype(np.float64), cum_dtype=cum)
-        d = sm.draw(row_off, sample_n, uniforms=r, letters="".join(cats[:n_cls]) if one_letter else None,
-                    want_idx=not one_letter, want_metrics=on_device)
+    out = {}
+    with sm.lock:       # the process-wide sampler is shared between threads; the arrays of run() are views of ITS result block
+        r, mode = None, rng
+        if rng == "numpy":
+            # the recurrence of the global generator is walked on the host straight into the sampler's page-locked buffer; the kernel
+            # tempers the words and forms the doubles (short draws and other generators: np.random.rand's own doubles)
+            n_draws = int(sample_n) * int(row_off[-1])
+            r = _legacy_words(n_draws, out=sm.uniform_buffer(2 * n_draws, np.uint32)) if n_draws >= 4096 else None
+            mode = "mt_words"
+            if r is None:
+                r, mode = _legacy_rand(n_draws), "host"
+        d = sm.run(np.concatenate(mats).astype(np.float64), row_off, sample_n, uniforms=r, rng=mode, seed=seed,
+                   letters="".join(cats[:n_cls]) if one_letter else None, want_idx=not one_letter, want_letters=one_letter,
+                   want_metrics=on_device, cum_dtype=cum)
+        out = _collect(keys, d, row_off, sample_n, cats, one_letter, on_device)
+    return out
+
+
+def _collect(keys, d, row_off, sample_n, cats, one_letter, on_device) -> dict:
     out = {}
     for k, key in enumerate(keys):
         lo, hi = int(row_off[k]), int(row_off[k + 1])
@@ -204,9 +248,10 @@ def apply_temp_to_probs(probs: np.ndarray, t: float = 1.0):
     return _sampler.apply_temperature(np.array(probs, dtype=np.float64), t)
 
 
-def sample_with_multiprocessing(workers, pdb_codes, sample_n, pdb_to_probability, flat_categories):
+def sample_with_multiprocessing(workers, pdb_codes, sample_n, pdb_to_probability, flat_categories, rng: str = "numpy", seed: int = 0):
     """reference sampling_utils.py:164-197.  The reference fans PDB keys over a process Pool (every forked worker
     inherits the SAME generator state, so different PDBs can receive identical uniform streams — Appendix C-1).  Here
     all keys are drawn together on the GPU from one continuous stream in key order; ``workers`` is accepted and
-    ignored."""
-    return _sample_keys(pdb_codes, sample_n, pdb_to_probability, flat_categories)
+    ignored.  Opt-in ``rng`` / ``seed`` (not in the reference): "numpy" replays np.random.rand bit for bit (default);
+    "philox" / "mt19937" draw the uniforms on the device from ``seed`` (see _sample_keys)."""
+    return _sample_keys(pdb_codes, sample_n, pdb_to_probability, flat_categories, rng=rng, seed=seed)

@@ -52,7 +52,8 @@ def main_sample(args):
         dataset_map, probabilities, rotamers_categories=categories, old_datasetmap=args.support_old_datasetmap)
     keys = list(pdb_to_probability)
     print(f"Drawing {args.sample_n} sequence(s) for each of {len(keys)} structure(s) in {matrix_path.name}")
-    sampled = su.sample_with_multiprocessing(args.workers, keys, args.sample_n, pdb_to_probability, categories)
+    sampled = su.sample_with_multiprocessing(args.workers, keys, args.sample_n, pdb_to_probability, categories,
+                                             rng=getattr(args, "rng", "numpy"), seed=args.seed)
     stem = f"{matrix_path.stem}_temp_{args.temperature}_n_{args.sample_n}_{keys[0]}"
     return su.save_as(sampled, filename=stem, mode=args.save_as)
 
@@ -68,7 +69,10 @@ CLI_FLAGS = (
     ("--workers", dict(type=int, default=8, help="accepted for compatibility; the draws run on the GPU")),
     ("--temperature", dict(type=float, default=1, help="softmax temperature applied to the probabilities (1 = unchanged)")),
     ("--support_old_datasetmap", dict(action="store_true", default=False, help="the dataset map is the old 4-column csv")),
-    ("--seed", dict(type=int, default=42, help="seed of NumPy's legacy generator")),
+    ("--seed", dict(type=int, default=42, help="seed of NumPy's legacy generator (and of the device generators of --rng)")),
+    # not in the reference: where the uniforms come from.  numpy = np.random.rand replayed bit for bit (the reference's stream
+    # after np.random.seed(seed)); philox = rocRAND Philox4x32-10 on the GPU; mt19937 = MT19937(seed) generated on the GPU
+    ("--rng", dict(type=str, default="numpy", choices=list(su.RNG_CHOICES), help="source of the uniforms (default: numpy, the reference's stream)")),
 )
 
 

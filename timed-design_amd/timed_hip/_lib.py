@@ -13,7 +13,7 @@ TH_EINVAL, TH_EIO, TH_EHIP, TH_EUNSUP, TH_ENOMEM, TH_ECOMM, TH_EBUSY = -1, -2, -
 TH_F32, TH_F64, TH_U8, TH_BOOL, TH_F16 = 0, 1, 2, 3, 4
 TH_LOAD_DEFAULT, TH_LOAD_NO_FUSE, TH_LOAD_NO_MFMA, TH_LOAD_KEEP_ALL = 0, 1, 2, 4
 TH_PREDICT_DEFAULT, TH_PREDICT_LOGITS, TH_PREDICT_OUT_DEVICE, TH_PREDICT_IN_DEVICE = 0, 1, 2, 4
-TH_RNG_HOST, TH_RNG_PHILOX, TH_RNG_MT19937 = 0, 1, 2
+TH_RNG_HOST, TH_RNG_PHILOX, TH_RNG_MT19937, TH_RNG_MT_WORDS = 0, 1, 2, 3
 TH_TEMPER_NONE, TH_TEMPER_POW, TH_TEMPER_PREPOWERED = 0, 1, 2
 TH_COMM_ID_BYTES = 128
 
@@ -45,6 +45,7 @@ PROTOTYPES = {
     "th_model_profile": (_i, [_vp, _i]),
     "th_model_step_info": (_i, [_vp, _i, C.c_char_p, _sz, _pd, _pi64, _pd, _pd, _pd]),
     "th_model_knobs": (_i, [_vp, C.c_char_p, _sz]),
+    "th_model_step_direct_flops": (_i, [_vp, _i, _pd]),
     "th_model_guard_info": (_i, [_vp, C.POINTER(C.c_int), _pd, _pd, C.c_char_p, _sz]),
     "th_dev_alloc": (_i, [_i, _sz, C.POINTER(_vp)]),
     "th_dev_free": (_i, [_i, _vp]),
@@ -58,6 +59,8 @@ PROTOTYPES = {
     "th_sampler_free": (None, [_vp]),
     "th_sampler_load": (_i, [_vp, _vp, _i64, _i, _d, _i, _i, _vp]),
     "th_sampler_draw": (_i, [_vp, _i64, _pi64, _i64, _i, _u64, _u64, _vp, C.c_char_p, _vp, _vp, _vp, _vp]),
+    "th_sampler_uniform_buffer": (_i, [_vp, _sz, C.POINTER(C.c_void_p)]),
+    "th_sampler_run": (_i, [_vp, _vp, _i64, _i, _i, _i64, _pi64, _i64, _i, _u64, _u64, _vp, C.c_char_p, C.c_uint, C.POINTER(C.c_void_p), _pi64]),
     "th_sample": (_i, [_vp, _i64, _i, _i64, _d, _i, _u64, _vp, _vp]),
     "th_sample_ex": (_i, [_vp, _i64, _i, _i64, _d, _i, _u64, _u64, _vp, _vp, _vp, C.c_char_p, _vp, _vp, _i]),
     "th_comm_unique_id": (_i, [C.c_char_p]),
@@ -67,6 +70,7 @@ PROTOTYPES = {
     "th_comm_barrier": (_i, [_vp]),
     "th_voxelise": (_i, [_i, _vp, _vp, _vp, _i64, _vp, _i64, _i, C.c_float, _i, _i, _vp, _i]),
     "th_mt19937_rand": (_i, [_vp, _pi, _i64, _vp]),
+    "th_mt19937_words": (_i, [_vp, _pi, _i64, _vp]),
     "th_format_csv": (_i64, [_vp, _i, _i64, _i64, _vp, _i64]),
     "th_format_csv_device": (_i64, [_i, _vp, _i64, _i64, _vp, _i64]),
     "th_format_csv_device_release": (_i, []),

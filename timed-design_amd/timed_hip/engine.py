@@ -175,13 +175,15 @@ class HipFrameModel:
     def steps(self) -> List[dict]:
         out = []
         for i in range(self.cost()["n_steps"]):
-            label = C.create_string_buffer(256)
+            label = C.create_string_buffer(640)
             ms, fl, ef, by = C.c_double(), C.c_double(), C.c_double(), C.c_double()
             ln = C.c_int64()
-            _lib.check(self._lib.th_model_step_info(self._h, i, label, 256, C.byref(ms), C.byref(ln), C.byref(fl),
+            _lib.check(self._lib.th_model_step_info(self._h, i, label, 640, C.byref(ms), C.byref(ln), C.byref(fl),
                                                     C.byref(ef), C.byref(by)))
+            df = C.c_double()
+            _lib.check(self._lib.th_model_step_direct_flops(self._h, i, C.byref(df)))
             out.append(dict(label=label.value.decode(), ms=ms.value, launches=ln.value, flops=fl.value,
-                            exec_flops=ef.value, bytes=by.value))
+                            exec_flops=ef.value, bytes=by.value, direct_flops=df.value if df.value >= 0 else None))
         return out
 
     def guard(self) -> dict:

@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _lib
 
-RNG_HOST, RNG_PHILOX, RNG_MT19937 = _lib.TH_RNG_HOST, _lib.TH_RNG_PHILOX, _lib.TH_RNG_MT19937
+RNG_HOST, RNG_PHILOX, RNG_MT19937, RNG_MT_WORDS = _lib.TH_RNG_HOST, _lib.TH_RNG_PHILOX, _lib.TH_RNG_MT19937, _lib.TH_RNG_MT_WORDS
 
 
 def _as_probs(probs) -> np.ndarray:
@@ -108,6 +108,61 @@ class Sampler:
                 let.ctypes.data if let is not None else None, met.ctypes.data if met is not None else None))
         out.update(idx=idx, uniforms=r_out, letters=let, metrics=met, row_off=off, n_samples=int(n_samples))
         return out
+
+    def uniform_buffer(self, count: int, dtype) -> np.ndarray:
+        """`count` elements of page-locked memory owned by the sampler (th_sampler_uniform_buffer): uniforms / raw generator words
+        written here are uploaded by direct DMA.  Valid until the next call of this method."""
+        nbytes = int(count) * np.dtype(dtype).itemsize
+        ptr = C.c_void_p()
+        _lib.check(self._lib.th_sampler_uniform_buffer(self._h, max(nbytes, 16), C.byref(ptr)))
+        return np.frombuffer((C.c_char * nbytes).from_address(ptr.value), dtype=dtype, count=int(count))
+
+    def run(self, probs, row_off: Sequence[int], n_samples: int, uniforms: Optional[np.ndarray] = None, rng: str = "auto", seed: int = 0,
+            rng_offset: int = 0, letters: Optional[str] = None, want_idx: bool = True, want_letters: bool = True,
+            want_metrics: bool = False, cum_dtype=np.float64) -> dict:
+        """load + draw as ONE submission (th_sampler_run): the rows of every key (used as they are: temper first), their running
+        sums, all draws, letters and metrics between one upload and one download.  The arrays returned are VIEWS of a page-locked
+        block owned by the sampler: valid until its next call (callers hold ``lock`` while they consume them)."""
+        p = _as_probs(probs)
+        off = np.ascontiguousarray(np.asarray(row_off, dtype=np.int64))
+        n_keys = off.size - 1
+        total = int(n_samples) * p.shape[0]
+        mode = {"host": RNG_HOST, "philox": RNG_PHILOX, "mt19937": RNG_MT19937, "mt_words": RNG_MT_WORDS,
+                "auto": RNG_HOST if uniforms is not None else RNG_PHILOX}[rng]
+        u_ptr = None
+        if mode == RNG_HOST:
+            if uniforms is None:
+                raise ValueError("rng='host' needs uniforms")
+            u = np.ascontiguousarray(np.asarray(uniforms, dtype=np.float64)).ravel()
+            if u.size != total:
+                raise ValueError(f"uniforms must hold {total} values, got {u.size}")
+            u_ptr = u.ctypes.data
+        elif mode == RNG_MT_WORDS:      # raw MT19937 state words (th_mt19937_words), two per draw: tempered and converted by the kernel
+            u = np.ascontiguousarray(np.asarray(uniforms, dtype=np.uint32)).ravel()
+            if u.size != 2 * total:
+                raise ValueError(f"rng='mt_words' needs {2 * total} state words, got {u.size}")
+            u_ptr = u.ctypes.data
+        cat = None
+        if letters is not None:
+            if len(letters) != p.shape[1]:
+                raise ValueError(f"letters must have one character per category ({p.shape[1]}), got {len(letters)}")
+            cat = letters.encode("ascii")
+        elif want_letters or want_metrics:
+            raise ValueError("letters / metrics need the category letters")
+        want = (1 if want_idx else 0) | (2 if want_letters else 0) | (4 if want_metrics else 0)
+        block = C.c_void_p()
+        offs = (C.c_int64 * 3)()
+        _lib.check(self._lib.th_sampler_run(self._h, p.ctypes.data, p.shape[0], p.shape[1], _CUM[np.dtype(cum_dtype)], n_keys,
+                                            off.ctypes.data_as(C.POINTER(C.c_int64)), int(n_samples), mode, int(seed), int(rng_offset), u_ptr,
+                                            cat, want, C.byref(block), offs))
+        def view(o, dtype, count):
+            if o < 0:
+                return None
+            nbytes = count * np.dtype(dtype).itemsize
+            return np.frombuffer((C.c_char * nbytes).from_address(block.value + o), dtype=dtype, count=count)
+        return dict(idx=view(offs[0], np.int32, total), letters=view(offs[1], "S1", total),
+                    metrics=(lambda m: None if m is None else m.reshape(-1, 4))(view(offs[2], np.float64, n_keys * int(n_samples) * 4)),
+                    uniforms=None, row_off=off, n_samples=int(n_samples))
 
     @staticmethod
     def split(flat: np.ndarray, row_off: np.ndarray, n_samples: int):

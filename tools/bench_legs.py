@@ -211,6 +211,18 @@ def predict_py_e2e(cfg, weights, n_pack=20000, n_hdf5=2000, batch_size=500, work
                 run(h5, "predict_py_hdf5_gzip_f64_first_call", n_pdb * 100)
                 shutil.rmtree(Path(td) / "out_predict_py_hdf5_gzip_f64_first_call")
                 run(h5, "predict_py_hdf5_gzip_f64", n_pdb * 100)
+                # and as the first thing a fresh process does — what every `python predict.py` invocation is: HIP start-up and
+                # code-object load, model load + guard, decoder scratch, first parse of the group tables inside the timed region
+                try:
+                    rc = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_h5_cold.py"), h5, str(n_pdb * 100), str(batch_size)],
+                                        capture_output=True, text=True, timeout=300)
+                    cold = json.loads(rc.stdout.strip().splitlines()[-1])
+                    res["predict_py_hdf5_cold_process_fps"] = cold["cold_fps"]
+                    res["predict_py_hdf5_cold_process_s"] = cold["cold_s"]
+                    res["predict_py_hdf5_cold_process_second_call_fps"] = cold["warm_fps"]
+                except Exception as e:            # a leg never takes the bench line down
+                    res["predict_py_hdf5_cold_process_fps"] = None
+                    res["hdf5_cold_note"] = repr(e)[:200]
             else:
                 res["predict_py_hdf5_gzip_f64_fps"] = None
                 res["hdf5_note"] = "h5py writer failed: " + r.stderr[-200:]
@@ -264,11 +276,15 @@ def sampler_config5(device=0, n_res=300, n_samples=1000, temps=(0.1, 0.5, 1.0), 
             q = su.apply_temp_to_probs(p, t) if t != 1 else p
             api.out = su.sample_with_multiprocessing(8, ["k"], n_samples, {"k": q}, None)
 
+        def api_philox():       # sample.py --rng philox: uniforms drawn on the device (rocRAND Philox4x32-10), nothing generated by the host
+            q = su.apply_temp_to_probs(p, t) if t != 1 else p
+            api_philox.out = su.sample_with_multiprocessing(8, ["k"], n_samples, {"k": q}, None, rng="philox", seed=seed)
+
         def kernel():
             sm.load(p, t)
             kernel.out = sm.draw([0, n_res], n_samples, rng="philox", seed=seed)
 
-        t_api, t_kernel = _best(api, 5), _best(kernel, 10)
+        t_api, t_kernel, t_api_ph = _best(api, 5), _best(kernel, 10), _best(api_philox, 5)
         r = so.legacy_uniforms(seed, draws).reshape(n_samples, n_res)
         want = ["".join(letters[i]) for i in so.choice_indices(q_ref, r)]
         exact = [s[0] for s in api.out["k"]] == want
@@ -286,6 +302,7 @@ def sampler_config5(device=0, n_res=300, n_samples=1000, temps=(0.1, 0.5, 1.0), 
         t0 = time.perf_counter(); cpu(True); t_cpu_m = time.perf_counter() - t0
         out["temperatures"][str(t)] = {
             "api_ms": t_api * 1e3, "api_sequences_per_s": n_samples / t_api, "api_draws_per_s": draws / t_api,
+            "api_philox_ms": t_api_ph * 1e3, "api_philox_sequences_per_s": n_samples / t_api_ph,
             "kernel_ms": t_kernel * 1e3, "kernel_draws_per_s": draws / t_kernel,
             "cpu_numpy_ms": t_cpu * 1e3, "cpu_numpy_sequences_per_s": n_samples / t_cpu,
             "cpu_numpy_with_metrics_ms": t_cpu_m * 1e3, "indices_bit_exact_vs_oracle": bool(exact)}
@@ -297,8 +314,11 @@ def sampler_config5(device=0, n_res=300, n_samples=1000, temps=(0.1, 0.5, 1.0), 
     r = np.random.rand(draws)
     let = "".join(letters)
     t_rand = _best(lambda: su._legacy_rand(draws), 5)        # np.random.rand's values and state, replayed natively (th_mt19937_rand)
+    t_words = _best(lambda: su._legacy_words(draws, out=sm.uniform_buffer(2 * draws, np.uint32)), 5)   # the recurrence only, into page-locked memory
     t_np = _best(lambda: np.random.rand(draws), 5)
-    t_gpu = _best(lambda: (sm.load(q), sm.draw([0, n_res], n_samples, uniforms=r, letters=let, want_idx=False, want_metrics=True)), 10)
+    w = su._legacy_words(draws)
+    t_gpu = _best(lambda: sm.run(q, [0, n_res], n_samples, uniforms=w, rng="mt_words", letters=let, want_idx=False, want_metrics=True), 10)
+    t_gpu_ph = _best(lambda: sm.run(q, [0, n_res], n_samples, rng="philox", seed=seed, letters=let, want_idx=False, want_metrics=True), 10)
     d = sm.draw([0, n_res], n_samples, uniforms=r, letters=let, want_idx=False, want_metrics=True)
 
     def tuples():          # as design_utils/sampling_utils._sample_keys builds them
@@ -306,7 +326,8 @@ def sampler_config5(device=0, n_res=300, n_samples=1000, temps=(0.1, 0.5, 1.0), 
         seqs = [text[i * n_res:(i + 1) * n_res] for i in range(n_samples)]
         return su._result_tuples(seqs, d["metrics"])
     t_py = _best(tuples, 5)
-    out["api_breakdown_ms"] = {"legacy_rand_replay": t_rand * 1e3, "np_random_rand_itself": t_np * 1e3, "gpu_load_draw_metrics_copies": t_gpu * 1e3, "python_result_tuples": t_py * 1e3}
+    out["api_breakdown_ms"] = {"mt19937_words_on_host": t_words * 1e3, "legacy_rand_replay_full": t_rand * 1e3, "np_random_rand_itself": t_np * 1e3,
+                               "gpu_one_submission_host_words": t_gpu * 1e3, "gpu_one_submission_philox": t_gpu_ph * 1e3, "python_result_tuples": t_py * 1e3}
     sm.close()
     out["cpu_cores"] = 1
     from timed_hip import _lib
@@ -383,17 +404,39 @@ def pmc_traffic_inrun(topologies, chunk, timeout=240):
     return result
 
 
+PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32-input MFMA = the fp32 vector peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # same guide: dense bf16 MFMA (the 5 PF headline figure includes 2:1 sparsity)
+
+
+def step_pipe(step):
+    """(matrix pipe, its dense peak in TFLOP/s, FLOPs per frame that pipe executes for the step's OWN arithmetic).  A step whose
+    label says bf16x3 runs every fp32 multiply-add as six bf16 piece products (csrc/conv_wino.hip, k_wino_gemm_b3): it is priced
+    on the bf16 pipe with six times its fp32-equivalent FLOPs — never with the fp32 count against the fp32 peak (which it exceeds)."""
+    if "bf16x3" in step["label"]:
+        return "bf16", PEAK_BF16_MFMA_TFLOPS, 6.0 * step["flops"]
+    return "fp32", PEAK_FP32_MFMA_TFLOPS, step["flops"]
+
+
+def pipe_time_frac(steps, fps):
+    """fraction of the wall time the matrix pipes would need at their dense peaks for what the plan's kernels compute:
+    frames/s x sum over steps of (own FLOPs on the step's pipe / that pipe's peak)"""
+    return fps * sum(step_pipe(s)[2] / (step_pipe(s)[1] * 1e12) for s in steps if s["flops"])
+
+
 def step_roofline(step, frames, traffic_bytes=None, chunk=None):
     """roofline record of one plan step from its HIP-event time over `frames` frames: bound 'mfma' for convolutions
     whose arithmetic intensity is above the ridge (157.3 TFLOP/s / 8 TB/s = 19.7 FLOP/B), 'hbm' otherwise"""
     ms = step["ms"]
     if not ms:
         return None
-    tf = step["flops"] * frames / (ms * 1e-3) / 1e12
+    pipe, peak, pflops = step_pipe(step)
+    tf = pflops * frames / (ms * 1e-3) / 1e12
     gbs = step["bytes"] * frames / (ms * 1e-3) / 1e9
     intensity = step["flops"] / step["bytes"] if step["bytes"] else float("inf")
     if intensity >= 157.3e12 / 8.0e12 and step["flops"]:
-        rec = {"bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3}
+        rec = {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "pipe": pipe}
+        if pipe != "fp32":
+            rec["fp32_equiv_tflops"] = step["flops"] * frames / (ms * 1e-3) / 1e12
     else:
         rec = {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0}
     rec.update(kernel=step["label"], flop_per_byte=intensity if step["bytes"] else None,
@@ -404,24 +447,24 @@ def step_roofline(step, frames, traffic_bytes=None, chunk=None):
 
 
 # ---- other BASELINE topologies ---------------------------------------------------------------------------------------
-def topology_rate(name, device, d_frames_ptr, n, chunk, steps=2, traffic=None, cpu_baseline=None, winograd=None):
+def topology_rate(name, device, d_frames_ptr, n, chunk, steps=2, traffic=None, cpu_baseline=None, env=None):
     """device-resident frames/s of another BASELINE topology on the same frames (config 3: densecpd, config 4's model:
     timed_rotamer) with its own roofline records: the whole model against the fp32-MFMA peak, the dominant kernel
     (largest share of device time) and every kernel's bound / fraction / measured HBM traffic; all n output rows are
     checked.  ``traffic``: this topology's record from pmc_traffic_inrun; ``cpu_baseline``: callable(cfg, weights, name)."""
     from timed_hip import _lib, engine, synth
     cfg, weights = synth.TOPOLOGIES[name]()
-    keep = os.environ.get("TH_WINOGRAD")
-    if winograd is not None:                 # the library reads TH_WINOGRAD when a model is loaded
-        os.environ["TH_WINOGRAD"] = str(winograd)
+    # ``env``: TH_* knobs of a non-default plan ({"TH_WINO_SPLIT": "0"}): the library reads them once, when the model is loaded
+    keep = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
     try:
         model = engine.HipFrameModel.from_keras(cfg, weights, device=device, name=name)
     finally:
-        if winograd is not None:
-            if keep is None:
-                os.environ.pop("TH_WINOGRAD", None)
+        for k, v in keep.items():
+            if v is None:
+                os.environ.pop(k, None)
             else:
-                os.environ["TH_WINOGRAD"] = keep
+                os.environ[k] = v
     model.set_chunk(chunk)
     d_probs = engine.DeviceBuffer(n * model.n_classes * 4, device)
     lib = _lib.load()
@@ -449,8 +492,11 @@ def topology_rate(name, device, d_frames_ptr, n, chunk, steps=2, traffic=None, c
     res = {"topology": name, "frames": n, "chunk": chunk, "n_classes": model.n_classes, "frames_per_s": fps, "rows_verified": n,
            "algo_mflop_per_frame": cost["algo_flops"] / 1e6, "kernel_mflop_per_frame": kflops / 1e6, "model_tflops": fps * kflops / 1e12,
            "model_direct_equiv_tflops": fps * cost["algo_flops"] / 1e12,
-           "model_roofline": {"bound": "mfma", "achieved": fps * kflops / 1e12, "peak": 157.3, "unit": "TFLOP/s",
-                              "frac": fps * kflops / 1e12 / 157.3,
+           # the whole model against its matrix pipes: the share of the wall time they would need at their dense peaks (fp32-input
+           # MFMA 157.3 TFLOP/s; the bf16x3-split GEMMs on the bf16 pipe, 2500 TFLOP/s, with six products per multiply-add);
+           # `achieved` / `peak` restate it in fp32-pipe terms for plans without split steps
+           "model_roofline": {"bound": "mfma", "achieved": pipe_time_frac(model.steps(), fps) * 157.3, "peak": 157.3, "unit": "TFLOP/s",
+                              "frac": pipe_time_frac(model.steps(), fps), "fp32_equiv_tflops": fps * kflops / 1e12,
                               "traffic": (traffic or {}).get("model"), "traffic_frames": (traffic or {}).get("chunk"),
                               "algorithmic_bytes": algo_bytes * ((traffic or {}).get("chunk") or 0) or None},
            "hbm": {"algo_bytes_per_frame": algo_bytes, "achieved_GBps": fps * algo_bytes / 1e9, "frac": fps * algo_bytes / 1e9 / 8000.0},
@@ -462,9 +508,10 @@ def topology_rate(name, device, d_frames_ptr, n, chunk, steps=2, traffic=None, c
                             GBps_algo=(s["bytes"] * n / (s["ms"] * 1e-3) / 1e9) if s["ms"] else 0.0) for s in table]}
     for k in res["kernels"]:
         k.pop("kernel", None)
-    if winograd is not None:
+    res["knobs"] = model.knobs()
+    if env:
         # parity note of a non-default plan: its logits on the first frames against the DEFAULT plan's on the same frames
-        res["topology"] = f"{name} (TH_WINOGRAD={winograd})"
+        res["topology"] = f"{name} ({' '.join(f'{k}={v}' for k, v in env.items())})"
         k = min(n, 512)
         ref = engine.HipFrameModel.from_keras(cfg, weights, device=device, name=name)
         d_a, d_b = engine.DeviceBuffer(k * model.n_classes * 4, device), engine.DeviceBuffer(k * model.n_classes * 4, device)

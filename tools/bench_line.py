@@ -40,6 +40,8 @@ def _roofline(rl: dict) -> dict:
     out = {"bound": rl.get("bound"), "achieved": _r(rl.get("achieved"), 5), "peak": rl.get("peak"), "unit": rl.get("unit"),
            "frac": _r(rl.get("frac")), "traffic": rl.get("traffic"), "kernel": short_kernel(rl.get("kernel", "")),
            "avg_launch_ms": _r(rl.get("avg_launch_ms"), 5), "launches": rl.get("launches")}
+    if rl.get("pipe"):
+        out["pipe"] = rl["pipe"]
     for k in ("algorithmic_bytes", "traffic_frames", "algorithmic_flops_per_launch", "frames_per_launch"):
         if rl.get(k) is not None:
             out[k] = rl[k]
@@ -48,13 +50,16 @@ def _roofline(rl: dict) -> dict:
     return out
 
 
-def _cpu(cb: dict, sample_chars: int = 150) -> dict:
+def _cpu(cb: dict, sample_chars: int = 120) -> dict:
     return {"value": _r(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
             "sample": (cb.get("sample") or "")[:sample_chars]}
 
 
 def _other(o: dict) -> dict:
     mr, rl = o.get("model_roofline") or {}, o.get("roofline") or {}
+    if "(" in (o.get("topology") or ""):           # a non-default plan of a topology listed above: its rate and its distance only
+        return {"topology": o.get("topology"), "frames_per_s": _r(o.get("frames_per_s"), 5),
+                "max_dlogit_vs_default": _r(o.get("max_abs_dlogit_vs_default_plan"), 3)}
     out = {"topology": o.get("topology"), "frames": o.get("frames"), "frames_per_s": _r(o.get("frames_per_s"), 5),
            "model_frac": _r(mr.get("frac")), "dominant": short_kernel(rl.get("kernel", "")), "dominant_frac": _r(rl.get("frac"))}
     if mr.get("traffic") and mr.get("algorithmic_bytes"):
@@ -68,14 +73,15 @@ def _other(o: dict) -> dict:
 
 _E2E_KEYS = ("device_resident_fps", "th_predict_sync_pageable_fps", "th_predict_async_pinned_fps",
              "predict_py_framepack_f32_fps", "predict_py_framepack_u8_fps", "predict_py_rotamer_fps",
-             "predict_py_hdf5_gzip_f64_first_call_fps", "predict_py_hdf5_gzip_f64_fps", "config1_predict_py_from_pdb_s",
+             "predict_py_hdf5_gzip_f64_first_call_fps", "predict_py_hdf5_gzip_f64_fps", "predict_py_hdf5_cold_process_fps",
+             "config1_predict_py_from_pdb_s",
              "config1_cpu_oracle_forward_s")
 
 
 def _sampler(s: dict) -> dict:
     out = {"n_residues": s.get("n_residues"), "n_samples": s.get("n_samples")}
     for t, v in (s.get("temperatures") or {}).items():
-        out[f"T{t}"] = {"api_ms": _r(v.get("api_ms")), "kernel_ms": _r(v.get("kernel_ms")),
+        out[f"T{t}"] = {"api_ms": _r(v.get("api_ms")), "api_philox_ms": _r(v.get("api_philox_ms")), "kernel_ms": _r(v.get("kernel_ms")),
                         "seq_per_s": _r(v.get("api_sequences_per_s")), "cpu_numpy_ms": _r(v.get("cpu_numpy_ms")),
                         "bit_exact": v.get("indices_bit_exact_vs_oracle")}
     if s.get("api_breakdown_ms"):
@@ -94,8 +100,12 @@ def compact(full: dict, detail_path: str | None = None) -> dict:
             cfg[k] = _r(cfg[k], 6)
     if isinstance(cfg.get("exchange"), str):
         cfg["exchange"] = cfg["exchange"][:120]
+    if isinstance(cfg.get("arithmetic"), str):
+        cfg["arithmetic"] = cfg["arithmetic"][:160]
+    if isinstance(cfg.get("workload"), str):
+        cfg["workload"] = cfg["workload"][:200]
     line["config"] = cfg
-    for k in ("model_tflops", "model_frac_of_fp32_mfma_peak", "model_direct_equiv_tflops"):
+    for k in ("schema", "model_tflops", "model_kernel_tflops_fp32_equiv", "model_pipe_time_frac", "model_frac_of_fp32_mfma_peak", "model_direct_equiv_tflops"):
         if k in full:
             line[k] = _r(full[k])
     if "hbm" in full:
@@ -116,7 +126,11 @@ def compact(full: dict, detail_path: str | None = None) -> dict:
         line["extras_wall_s"] = _r(full["extras_wall_s"], 3)
     if detail_path:
         line["detail"] = detail_path
-    # last resort: shed optional blocks rather than ever exceed the budget
+    # over the budget: first the non-default-plan legs and the sampler's breakdown, then whole optional blocks — never a contract key
+    if len(json.dumps(line)) > MAX_LINE_BYTES and "other_configs" in line:
+        line["other_configs"] = [o for o in line["other_configs"] if "(" not in (o.get("topology") or "")]
+    if len(json.dumps(line)) > MAX_LINE_BYTES and "sampler" in line:
+        line["sampler"].pop("api_breakdown_ms", None)
     for drop in ("sampler", "e2e", "other_configs", "hbm"):
         if len(json.dumps(line)) <= MAX_LINE_BYTES:
             break

@@ -60,17 +60,19 @@ def main():
         total = sum(sum(v) / len(v) for v in sums if v)
         print(f"# {topo}: one chunk of {args.chunk} frames, average of {args.reps} passes; matched kernels {total / 1e3:.3f} ms per chunk "
               f"= {args.chunk / total * 1e6:,.0f} frames/s")
-        print(f"{'plan step':40s} {'avg_us':>9s} {'share':>6s} {'GFLOP/launch':>13s} {'TFLOP/s':>8s} {'of 157.3':>8s} {'MB/launch':>10s} {'GB/s':>8s} {'of 8000':>8s}  bound")
+        print(f"{'plan step':40s} {'avg_us':>9s} {'share':>6s} {'GFLOP/launch':>13s} {'TFLOP/s':>8s} {'of peak':>8s} {'MB/launch':>10s} {'GB/s':>8s} {'of 8000':>8s}  bound")
         for label, (fl, _ef, by), v in zip(labels, costs, sums):
             if not v:
                 continue
             us = sum(v) / len(v)
-            tf = fl * args.chunk / (us * 1e-6) / 1e12
+            split = "bf16x3" in label            # six bf16 piece products per multiply-add: priced on the bf16 pipe (2500 TFLOP/s dense)
+            peak = 2500.0 if split else PEAK_TF
+            tf = (6.0 if split else 1.0) * fl * args.chunk / (us * 1e-6) / 1e12
             gbs = by * args.chunk / (us * 1e-6) / 1e9
             bound = "mfma" if fl and by and fl / by >= PEAK_TF * 1e12 / (PEAK_GBS * 1e9) else "hbm"
             short = label.split(":", 1)[0] + " " + (re.search(r"\[([^\]]+)\]\s*$", label).group(1))
-            print(f"{short[:40]:40s} {us:9.1f} {100 * us / total:5.1f}% {fl * args.chunk / 1e9:13.2f} {tf:8.1f} {tf / PEAK_TF:8.3f} "
-                  f"{by * args.chunk / 1e6:10.1f} {gbs:8.0f} {gbs / PEAK_GBS:8.3f}  {bound}")
+            print(f"{short[:40]:40s} {us:9.1f} {100 * us / total:5.1f}% {(6.0 if split else 1.0) * fl * args.chunk / 1e9:13.2f} {tf:8.1f} {tf / peak:8.3f} "
+                  f"{by * args.chunk / 1e6:10.1f} {gbs:8.0f} {gbs / PEAK_GBS:8.3f}  {bound}{' (bf16 pipe, peak 2500: 6 products per fp32 multiply-add)' if split else ''}")
         print()
 
 
