@@ -299,9 +299,12 @@ int th_h5_decode_device(const void* file, int64_t file_len, int64_t base, int64_
                         void* d_out);
 /* th_model_free keeps a model's device blocks (weights, arenas, rings) in a per-process cache for the next th_model_load
  * (hipFree synchronises the device: ~13 ms per TIMED handle, paid by every predict.py call that loads and frees a model as
- * reference predict.py:114-121 does); at most 24 GB are kept.  th_dev_trim returns the cached blocks of `device` (all devices
- * when negative) to HIP. */
+ * reference predict.py:114-121 does); at most min(24 GB, an eighth of the device's memory) are kept per device, the blocks parked
+ * longest ago leave first, and every allocator inside the library returns the cache to HIP and retries before it reports
+ * TH_ENOMEM.  th_dev_trim returns the cached blocks of `device` (all devices when negative) to HIP; th_dev_cache_info reports
+ * what is parked (bytes, the cap, number of blocks). */
 int th_dev_trim(int device);
+int th_dev_cache_info(int device, uint64_t* cached_bytes, uint64_t* cap_bytes, int* blocks);
 /* th_h5_decode_device keeps per-device scratch memory between calls (compressed span, token arena: ~5 bytes per uncompressed
  * byte of the largest batch so far).  When an allocation fails it frees that scratch and returns TH_ENOMEM — decode fewer
  * datasets per call or read through th_h5_read_chunked_as; th_h5_release_scratch frees it on request (end of a run). */

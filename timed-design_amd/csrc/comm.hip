@@ -100,7 +100,7 @@ int th_comm_init(const char id[TH_COMM_ID_BYTES], int n_ranks, int rank, int dev
     int r = R->CommInitRank(&c->comm, n_ranks, u, rank);
     if (r != 0) { th_set_error("ncclCommInitRank failed: %s", R->GetErrorString(r)); delete c; return TH_ECOMM; }
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc(&c->d_token, sizeof(float));
+    if (e == hipSuccess) e = th_malloc_retry(&c->d_token, sizeof(float));
     if (e == hipSuccess) e = hipMemset(c->d_token, 0, sizeof(float));   // the barrier all-reduces it: keep it finite
     if (e != hipSuccess) { th_set_error("th_comm_init: %s", hipGetErrorString(e)); th_comm_free(c); return TH_EHIP; }
     *out = c;

@@ -61,6 +61,12 @@ const ThKnobs& th_knobs_planning();             // the snapshot of the th_model_
 void th_knobs_set_planning(const ThKnobs* k);   // runtime.hip, around the planner
 inline const ThKnobs& th_knobs_of(const ThKnobs* k) { static const ThKnobs dflt; return k ? *k : dflt; }
 
+// hipMalloc for every allocator inside the library: when the device is out of memory the blocks parked in the model block
+// cache (runtime.hip: freed arenas kept for the next load) are returned to HIP and the allocation is tried once more — a dead
+// block in the cache must never be the reason a decode, a text formatter or a sampler runs out of memory.
+hipError_t th_malloc_retry_impl(void** p, size_t bytes);
+template <class T> inline hipError_t th_malloc_retry(T** p, size_t bytes) { return th_malloc_retry_impl(reinterpret_cast<void**>(p), bytes); }
+
 // CPUs this process may actually use: min(hardware threads, scheduler affinity, cgroup CPU quota).  Containers often
 // expose every host core but enforce a quota (cpu.max); more runnable threads than the quota are throttled in 100 ms
 // periods — measured on the GPU box (256 cores visible, quota 16): 20 k frames/s inflated with 16 threads, a bimodal

@@ -906,11 +906,11 @@ struct DevBuf {
         p = nullptr; cap = 0;
         // 25 % of slack so that batches of slowly growing size do not re-allocate; the exact size when the slack does not fit
         for (const size_t want : {bytes + bytes / 4 + 4096, bytes}) {
-            const hipError_t e = hipMalloc(&p, want);
+            const hipError_t e = th_malloc_retry(&p, want);
             if (e == hipSuccess) { cap = want; return TH_OK; }
             p = nullptr;
             (void)hipGetLastError();
-            if (e != hipErrorOutOfMemory) TH_FAIL(TH_EHIP, "hipMalloc(%zu): %s", want, hipGetErrorString(e));
+            if (e != hipErrorOutOfMemory) TH_FAIL(TH_EHIP, "th_malloc_retry(%zu): %s", want, hipGetErrorString(e));
         }
         TH_FAIL(TH_ENOMEM, "inflate: no device memory for a %zu-byte scratch buffer (decode fewer datasets per call)", bytes);
     }
@@ -951,13 +951,13 @@ extern "C" int th_inflate_many(int device, const void* comp, int64_t comp_len, i
     int rc = TH_OK;
     auto fail = [&](hipError_t e, const char* what) { th_set_error("th_inflate_many: %s: %s", what, hipGetErrorString(e)); rc = TH_EHIP; };
     hipError_t e;
-    if ((e = hipMalloc(&d_comp, (size_t)comp_len + 16)) != hipSuccess) fail(e, "hipMalloc");
-    if (!rc && (e = hipMalloc(&d_out, (size_t)out_len + 16)) != hipSuccess) fail(e, "hipMalloc");
-    if (!rc && (e = hipMalloc(&d_desc, (size_t)n * sizeof(InfDesc))) != hipSuccess) fail(e, "hipMalloc");
-    if (!rc && (e = hipMalloc(&d_st, (size_t)n * sizeof(int))) != hipSuccess) fail(e, "hipMalloc");
-    if (!rc && (e = hipMalloc(&d_tok, (size_t)(tok_total + 16) * sizeof(unsigned))) != hipSuccess) fail(e, "hipMalloc");
-    if (!rc && (e = hipMalloc(&d_nt, (size_t)n * sizeof(long long))) != hipSuccess) fail(e, "hipMalloc");
-    if (!rc && (e = hipMalloc(&d_ad, (size_t)n * sizeof(unsigned))) != hipSuccess) fail(e, "hipMalloc");
+    if ((e = th_malloc_retry(&d_comp, (size_t)comp_len + 16)) != hipSuccess) fail(e, "hipMalloc");
+    if (!rc && (e = th_malloc_retry(&d_out, (size_t)out_len + 16)) != hipSuccess) fail(e, "hipMalloc");
+    if (!rc && (e = th_malloc_retry(&d_desc, (size_t)n * sizeof(InfDesc))) != hipSuccess) fail(e, "hipMalloc");
+    if (!rc && (e = th_malloc_retry(&d_st, (size_t)n * sizeof(int))) != hipSuccess) fail(e, "hipMalloc");
+    if (!rc && (e = th_malloc_retry(&d_tok, (size_t)(tok_total + 16) * sizeof(unsigned))) != hipSuccess) fail(e, "hipMalloc");
+    if (!rc && (e = th_malloc_retry(&d_nt, (size_t)n * sizeof(long long))) != hipSuccess) fail(e, "hipMalloc");
+    if (!rc && (e = th_malloc_retry(&d_ad, (size_t)n * sizeof(unsigned))) != hipSuccess) fail(e, "hipMalloc");
     if (!rc && (e = hipMemcpy(d_comp, comp, (size_t)comp_len, hipMemcpyHostToDevice)) != hipSuccess) fail(e, "copy in");
     if (!rc && (e = hipMemcpy(d_desc, desc.data(), (size_t)n * sizeof(InfDesc), hipMemcpyHostToDevice)) != hipSuccess) fail(e, "copy in");
     if (!rc && (e = hipMemset(d_st, 0xff, (size_t)n * sizeof(int))) != hipSuccess) fail(e, "memset");

@@ -99,13 +99,31 @@ void th_knobs_read(ThKnobs* k) {
 namespace {
 struct DevCache {
     std::mutex mu;
-    std::multimap<std::pair<int, size_t>, void*> free_blocks;   // (device, bytes) -> block
+    struct Blk { void* p; uint64_t stamp; };
+    std::multimap<std::pair<int, size_t>, Blk> free_blocks;     // (device, bytes) -> block, with the time it was parked
     std::map<void*, std::pair<int, size_t>> live;               // blocks handed out
-    size_t cached_bytes = 0;
+    std::map<int, size_t> cached_bytes;                         // per device
+    std::map<int, size_t> cap_bytes;                            // per device: min(kCacheBytes, an eighth of the device's memory)
+    uint64_t clock = 0;
     static constexpr size_t kCacheBytes = 24ull << 30;
     static constexpr size_t kCacheBlocks = 1024;
 };
 DevCache g_cache;
+
+// the cap of `device` (lock held): the fixed 24 GB of round 4 is more than a small card has — an eighth of the device's memory
+size_t cache_cap_locked(int device) {
+    auto it = g_cache.cap_bytes.find(device);
+    if (it != g_cache.cap_bytes.end()) return it->second;
+    size_t cap = DevCache::kCacheBytes, free_b = 0, total_b = 0;
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && (cur == device || hipSetDevice(device) == hipSuccess)) {
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) cap = std::min(cap, total_b / 8);
+        if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
+    }
+    (void)hipGetLastError();
+    g_cache.cap_bytes[device] = cap;
+    return cap;
+}
 
 int cached_malloc(void** out, size_t bytes, int device) {
     if (!bytes) bytes = 4;
@@ -113,26 +131,14 @@ int cached_malloc(void** out, size_t bytes, int device) {
         std::lock_guard<std::mutex> lock(g_cache.mu);
         auto it = g_cache.free_blocks.find({device, bytes});
         if (it != g_cache.free_blocks.end()) {
-            *out = it->second;
+            *out = it->second.p;
             g_cache.free_blocks.erase(it);
-            g_cache.cached_bytes -= bytes;
+            g_cache.cached_bytes[device] -= bytes;
             g_cache.live[*out] = {device, bytes};
             return TH_OK;
         }
     }
-    hipError_t e = hipMalloc(out, bytes);
-    if (e == hipErrorOutOfMemory) {                 // give the cache back and try once more
-        (void)hipGetLastError();
-        std::vector<void*> drop;
-        {
-            std::lock_guard<std::mutex> lock(g_cache.mu);
-            for (auto& kv : g_cache.free_blocks) drop.push_back(kv.second);
-            g_cache.free_blocks.clear();
-            g_cache.cached_bytes = 0;
-        }
-        for (void* p : drop) (void)hipFree(p);
-        e = hipMalloc(out, bytes);
-    }
+    hipError_t e = th_malloc_retry(out, bytes);       // (gives the parked blocks back and tries again when the device is full)
     if (e != hipSuccess) {
         (void)hipGetLastError();
         TH_FAIL(e == hipErrorOutOfMemory ? TH_ENOMEM : TH_EHIP, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
@@ -144,22 +150,60 @@ int cached_malloc(void** out, size_t bytes, int device) {
 
 void cached_free(void* p) {
     if (!p) return;
-    std::pair<int, size_t> key;
+    std::vector<void*> evict;
     {
         std::lock_guard<std::mutex> lock(g_cache.mu);
         auto it = g_cache.live.find(p);
         if (it == g_cache.live.end()) { (void)hipFree(p); return; }
-        key = it->second;
+        const std::pair<int, size_t> key = it->second;
         g_cache.live.erase(it);
-        if (g_cache.cached_bytes + key.second <= DevCache::kCacheBytes && g_cache.free_blocks.size() < DevCache::kCacheBlocks) {
-            g_cache.free_blocks.insert({key, p});
-            g_cache.cached_bytes += key.second;
-            return;
+        const size_t cap = cache_cap_locked(key.first);
+        if (key.second > cap) evict.push_back(p);               // larger than the whole cache: straight back to HIP
+        else {
+            // least recently parked blocks of this device make room (round 4 refused the NEW block instead, so a process that
+            // loads models of varying size pinned its first 24 GB of stale sizes for ever)
+            g_cache.free_blocks.insert({key, {p, ++g_cache.clock}});
+            g_cache.cached_bytes[key.first] += key.second;
+            while (g_cache.cached_bytes[key.first] > cap || g_cache.free_blocks.size() > DevCache::kCacheBlocks) {
+                auto oldest = g_cache.free_blocks.end();
+                for (auto b = g_cache.free_blocks.begin(); b != g_cache.free_blocks.end(); ++b)
+                    if ((b->first.first == key.first || g_cache.free_blocks.size() > DevCache::kCacheBlocks) &&
+                        (oldest == g_cache.free_blocks.end() || b->second.stamp < oldest->second.stamp))
+                        oldest = b;
+                if (oldest == g_cache.free_blocks.end()) break;
+                evict.push_back(oldest->second.p);
+                g_cache.cached_bytes[oldest->first.first] -= oldest->first.second;
+                g_cache.free_blocks.erase(oldest);
+            }
         }
     }
-    (void)hipFree(p);
+    for (void* q : evict) (void)hipFree(q);
 }
 }  // namespace
+
+hipError_t th_malloc_retry_impl(void** p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipErrorOutOfMemory) return e;
+    (void)hipGetLastError();
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) return e;
+    std::vector<void*> drop;
+    {
+        std::lock_guard<std::mutex> lock(g_cache.mu);
+        for (auto it = g_cache.free_blocks.begin(); it != g_cache.free_blocks.end();) {
+            if (it->first.first == device) {
+                drop.push_back(it->second.p);
+                g_cache.cached_bytes[device] -= it->first.second;
+                it = g_cache.free_blocks.erase(it);
+            } else ++it;
+        }
+    }
+    if (drop.empty()) return e;
+    for (void* q : drop) (void)hipFree(q);
+    e = hipMalloc(p, bytes);
+    if (e != hipSuccess) (void)hipGetLastError();
+    return e;
+}
 
 extern "C" int th_dev_trim(int device) {
     std::vector<void*> drop;
@@ -167,14 +211,27 @@ extern "C" int th_dev_trim(int device) {
         std::lock_guard<std::mutex> lock(g_cache.mu);
         for (auto it = g_cache.free_blocks.begin(); it != g_cache.free_blocks.end();) {
             if (device < 0 || it->first.first == device) {
-                drop.push_back(it->second);
-                g_cache.cached_bytes -= it->first.second;
+                drop.push_back(it->second.p);
+                g_cache.cached_bytes[it->first.first] -= it->first.second;
                 it = g_cache.free_blocks.erase(it);
             } else ++it;
         }
     }
     if (drop.empty()) return TH_OK;                 // nothing cached: no HIP call at all
     for (void* p : drop) (void)hipFree(p);
+    return TH_OK;
+}
+
+// bytes parked in the block cache of `device` (all devices: -1) and their cap — tests and tools
+extern "C" int th_dev_cache_info(int device, uint64_t* cached_bytes, uint64_t* cap_bytes, int* blocks) {
+    std::lock_guard<std::mutex> lock(g_cache.mu);
+    uint64_t c = 0;
+    int n = 0;
+    for (auto& kv : g_cache.free_blocks)
+        if (device < 0 || kv.first.first == device) { c += kv.first.second; ++n; }
+    if (cached_bytes) *cached_bytes = c;
+    if (cap_bytes) *cap_bytes = device >= 0 ? cache_cap_locked(device) : DevCache::kCacheBytes;
+    if (blocks) *blocks = n;
     return TH_OK;
 }
 
@@ -1773,7 +1830,7 @@ int th_model_fetch(th_model* m, const char* layer_name, int64_t n, float* out, i
         const int64_t per = (int64_t)nd.D * nd.H * nd.W * nd.C;
         if (out_floats < n * per) TH_FAIL(TH_EINVAL, "output buffer too small (%lld < %lld)", (long long)out_floats, (long long)(n * per));
         float* d = nullptr;
-        HIP_TRY(hipMalloc(&d, (size_t)(n * per) * sizeof(float) + 16));
+        HIP_TRY(th_malloc_retry((void**)&d, (size_t)(n * per) * sizeof(float) + 16));
         TView o;
         o.p = d; o.D = nd.D; o.H = nd.H; o.W = nd.W; o.C = o.cs = nd.C; o.fs = per;
         int rc = launch_copy(m->stream, n, m->view((int)i), o);
@@ -1848,7 +1905,7 @@ int th_model_knobs(const th_model* m, char* buf, size_t buf_len) {
 int th_dev_alloc(int device, size_t bytes, void** d_out) {
     if (!d_out) TH_FAIL(TH_EINVAL, "null argument");
     HIP_TRY(hipSetDevice(device));
-    HIP_TRY(hipMalloc(d_out, bytes ? bytes : 1));
+    HIP_TRY(th_malloc_retry(d_out, bytes ? bytes : 1));
     return TH_OK;
 }
 int th_dev_free(int device, void* d) {

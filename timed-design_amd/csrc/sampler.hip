@@ -370,7 +370,7 @@ struct Scratch {
         if (cap >= bytes && p) return TH_OK;
         if (p) { if (host) (void)hipHostFree(p); else (void)hipFree(p); p = nullptr; cap = 0; }
         const size_t want = std::max<size_t>(bytes + bytes / 4, 1 << 16);
-        hipError_t e = host ? hipHostMalloc(&p, want, hipHostMallocDefault) : hipMalloc(&p, want);
+        hipError_t e = host ? hipHostMalloc(&p, want, hipHostMallocDefault) : th_malloc_retry(&p, want);
         if (e != hipSuccess) { p = nullptr; th_set_error("sampler: allocating %zu bytes failed: %s", want, hipGetErrorString(e)); return TH_ENOMEM; }
         cap = want;
         return TH_OK;

@@ -315,15 +315,15 @@ extern "C" int64_t th_format_csv_device(int device, const float* rows, int64_t n
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         hipError_t e = hipStreamCreateWithPriority(&S.stream, hipStreamNonBlocking, greatest);
-        if (e == hipSuccess) e = hipMalloc((void**)&S.d_flag, sizeof(int));
+        if (e == hipSuccess) e = th_malloc_retry((void**)&S.d_flag, sizeof(int));
         if (e != hipSuccess) { S.release(); th_set_error("th_format_csv_device: %s", hipGetErrorString(e)); return TH_EHIP; }
     }
     if (S.cap_values < (size_t)total) {
         (void)hipFree(S.d_in); (void)hipFree(S.d_out);
         S.d_in = nullptr; S.d_out = nullptr; S.cap_values = 0;
         const size_t want = (size_t)total + (size_t)total / 4;
-        hipError_t e = hipMalloc((void**)&S.d_in, want * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc((void**)&S.d_out, want * kFmtBytes + 16);
+        hipError_t e = th_malloc_retry((void**)&S.d_in, want * sizeof(float));
+        if (e == hipSuccess) e = th_malloc_retry((void**)&S.d_out, want * kFmtBytes + 16);
         if (e != hipSuccess) {
             (void)hipFree(S.d_in); S.d_in = nullptr;
             (void)hipGetLastError();

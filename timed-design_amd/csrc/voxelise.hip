@@ -138,10 +138,10 @@ extern "C" int th_voxelise(int device, const float* atoms_xyz, const int32_t* at
     hipError_t e;
     do {
         const size_t na = (size_t)std::max<int64_t>(n_atoms, 1);
-        if ((e = hipMalloc(&d_xyz, na * 12)) != hipSuccess || (e = hipMalloc(&d_chn, na * 4)) != hipSuccess ||
-            (e = hipMalloc(&d_sig, na * 4)) != hipSuccess || (e = hipMalloc(&d_frt, (size_t)n_res * 48)) != hipSuccess ||
-            (e = hipMalloc(&d_flag, 4)) != hipSuccess) { fail(e, "hipMalloc"); break; }
-        if (!out_on_device && (e = hipMalloc(&d_out, out_bytes)) != hipSuccess) { fail(e, "hipMalloc(frames)"); break; }
+        if ((e = th_malloc_retry(&d_xyz, na * 12)) != hipSuccess || (e = th_malloc_retry(&d_chn, na * 4)) != hipSuccess ||
+            (e = th_malloc_retry(&d_sig, na * 4)) != hipSuccess || (e = th_malloc_retry(&d_frt, (size_t)n_res * 48)) != hipSuccess ||
+            (e = th_malloc_retry(&d_flag, 4)) != hipSuccess) { fail(e, "hipMalloc"); break; }
+        if (!out_on_device && (e = th_malloc_retry(&d_out, out_bytes)) != hipSuccess) { fail(e, "th_malloc_retry(frames)"); break; }
         if (n_atoms) {
             if ((e = hipMemcpy(d_xyz, atoms_xyz, (size_t)n_atoms * 12, hipMemcpyHostToDevice)) != hipSuccess ||
                 (e = hipMemcpy(d_chn, atom_channel, (size_t)n_atoms * 4, hipMemcpyHostToDevice)) != hipSuccess) { fail(e, "upload"); break; }

@@ -200,10 +200,16 @@ def _run_groups(models, dataset_path, flat_dataset_map, groups, consume, gpu_dec
     # copies from it already run at the PCIe rate here, and page-locking 1 GB costs more than a short run takes
     # (th_host_alloc exists for callers that keep their buffers).  Frame packs hand out memory-mapped rows instead.
     ring = []
-    ring_size = 3 * len(models) + 2
-    max_rows = max(hi - lo for lo, hi in groups)
     from timed_hip import framepack
-    use_ring = len(groups) > ring_size and not framepack.is_pack(dataset_path) and not framepack.is_structure(dataset_path)
+    plain_h5 = not framepack.is_pack(dataset_path) and not framepack.is_structure(dataset_path)
+    # loader threads: two on GPU-inflated datasets (see below), one elsewhere.  The ring is sized for ALL of them: when the device
+    # decode falls back to the host reader mid-run (an unsupported file, TH_ENOMEM), both loaders keep filling host buffers, and
+    # a ring sized for one would hand group k + 2 the slot of a group whose ticket may still be outstanding
+    n_loaders = max(1, int(os.environ.get("TIMED_LOADERS", "2" if (gpu_decode and plain_h5) else "1")))
+    ring_size = 3 * len(models) + 1 + n_loaders
+    max_rows = max(hi - lo for lo, hi in groups)
+    use_ring = len(groups) > ring_size and plain_h5
+    full_seen = [0]                    # full-size groups loaded so far: they take the ring's slots in turn (ramp-up groups are smaller)
 
     load_seconds = [0.0]
 
@@ -215,7 +221,7 @@ def _run_groups(models, dataset_path, flat_dataset_map, groups, consume, gpu_dec
         finally:
             load_seconds[0] += time.perf_counter() - t0
 
-    decode_on_gpu = [bool(gpu_decode) and not framepack.is_pack(dataset_path) and not framepack.is_structure(dataset_path)]
+    decode_on_gpu = [bool(gpu_decode) and plain_h5]
 
     host_lock = threading.Lock()       # the host reader's buffer ring is filled by one loader at a time
 
@@ -258,10 +264,16 @@ def _run_groups(models, dataset_path, flat_dataset_map, groups, consume, gpu_dec
                 return got
             decode_on_gpu[0] = False
         with host_lock:
-            slot = k % ring_size
+            # full-size groups take the ring's slots in turn, starting with the FIRST full-size group (the smaller ramp-up groups
+            # in front of it, and the ragged last one, get buffers of their own)
+            slot = None
+            if use_ring and hi - lo == max_rows:
+                slot = full_seen[0] % ring_size
+                full_seen[0] += 1
             # float32 frames: the rounding Keras applies to load_batch's float64 anyway, done while the chunks are placed
-            X, y = du.load_batch(dataset_path, flat_dataset_map[lo:hi], dtype=np.float32, out=ring[slot] if slot < len(ring) else None)
-            if use_ring and len(ring) == slot and isinstance(X, np.ndarray) and X.base is None and len(X) == max_rows:
+            X, y = du.load_batch(dataset_path, flat_dataset_map[lo:hi], dtype=np.float32,
+                                 out=ring[slot] if slot is not None and slot < len(ring) else None)
+            if slot is not None and len(ring) == slot and isinstance(X, np.ndarray) and X.base is None and len(X) == max_rows:
                 ring.append(X)
             return X, y
 
@@ -292,9 +304,7 @@ def _run_groups(models, dataset_path, flat_dataset_map, groups, consume, gpu_dec
         # two — 17.8 ms per 4096 frames, which is the inflate kernels (8 ms) plus the CNN (10.3 ms) one after the other on the
         # GPU — and 0.19 s with three.  (When the CNN took twice as long the second loader bought nothing.)  One loader elsewhere:
         # the host reader fills its ring under a lock anyway, and frame packs hand out mapped rows.
-        default_loaders = 2 if decode_on_gpu[0] else 1
-        _pump(models, groups, load, finish, pending, writing, depth,
-              loaders=max(1, int(os.environ.get("TIMED_LOADERS", str(default_loaders)))))
+        _pump(models, groups, load, finish, pending, writing, depth, loaders=n_loaders)
         completed = True
     finally:
         sys.setswitchinterval(switch)

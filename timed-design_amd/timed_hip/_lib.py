@@ -83,6 +83,7 @@ PROTOTYPES = {
     "th_h5_decode_device": (_i, [_vp, _i64, _i64, _i64, _pi64, _i, _pi64, _pi64, _i, _i, _pi, _i, _i, _vp]),
     "th_h5_release_scratch": (_i, [_i]),
     "th_dev_trim": (_i, [_i]),
+    "th_dev_cache_info": (_i, [_i, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _pi]),
     "th_inflate_many": (_i, [_i, _vp, _i64, _i64, _pi64, _pi64, _pi64, _pi64, _vp, _i64, _i, _pi]),
     "th_h5_group_links": (_i, [_vp, _i64, _i64, _i64, _i64, _i64, _vp, _i64, _pi64, _i64, _pi64, _pi64]),
     "th_h5_resolve": (_i, [_vp, _i64, _i64, _i64, _pi64, C.c_char_p, _vp, _i, C.c_char_p, _vp, _i, _pi64, _pi64, _pi, _i]),

@@ -73,6 +73,23 @@ class HostRendezvous:
         else:
             self._join(addr, ports, token, deadline)
 
+    def _listen_address(self) -> str:
+        mode = os.environ.get("TIMED_RDZV_BIND", "")
+        if mode == "wildcard":
+            return ""
+        if mode == "strict":
+            return self._bind_addr
+        try:
+            resolved = socket.gethostbyname(self._bind_addr)
+        except OSError:
+            return ""
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "0") or 0)
+        multi_node = local_world > 0 and self.world > local_world
+        is_literal = resolved == self._bind_addr                      # MASTER_ADDR was given as an IPv4 literal
+        if resolved.startswith("127.") and multi_node and not is_literal:
+            return ""                                                 # a name that is loopback HERE only: peers on other nodes need the wildcard
+        return self._bind_addr
+
     # ---- connection set-up -----------------------------------------------------------------------------------------
     def _serve(self, ports: Sequence[int], token: bytes, deadline: float) -> None:
         srv = None
@@ -81,9 +98,12 @@ class HostRendezvous:
             s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             try:
                 # listen on MASTER_ADDR only (loopback for a one-node job), not on every interface; an address that is not
-                # local to this host (a name that resolves elsewhere, a NAT'd address) falls back to the wildcard
+                # local to this host (a name that resolves elsewhere, a NAT'd address) falls back to the wildcard — and so does
+                # a multi-node job whose MASTER_ADDR is a host NAME that rank 0's own /etc/hosts maps to loopback (Debian's
+                # 127.0.1.1 line): the bind would succeed on loopback and the other nodes, resolving the real address, would be
+                # refused until the timeout.  TIMED_RDZV_BIND=wildcard|strict overrides the choice.
                 try:
-                    s.bind((self._bind_addr, p))
+                    s.bind((self._listen_address(), p))
                 except (OSError, socket.gaierror) as e:
                     if getattr(e, "errno", None) == 98:          # EADDRINUSE: this port is taken, try the next one
                         raise

@@ -32,20 +32,22 @@ class TextScratch:
     def __init__(self):
         self._buf = None
         self._pinned = False
+        self._pin_failed = False      # th_host_register refused THIS buffer: not tried again until it is reallocated
 
     def get(self, cap: int, lib, pin: bool) -> np.ndarray:
         if self._buf is None or self._buf.size < cap:
             self.close()
             self._buf = np.empty(max(cap, 1 << 20), dtype=np.uint8)                # not zero-filled
-        if pin and not self._pinned:
+        if pin and not self._pinned and not self._pin_failed:
             self._buf.fill(0)                                                      # resident before it is locked
             self._pinned = lib.th_host_register(C.c_void_p(self._buf.ctypes.data), self._buf.nbytes) == 0
+            self._pin_failed = not self._pinned                                   # (a failing hipHostRegister + a 13 MB fill per group otherwise)
         return self._buf
 
     def close(self) -> None:
         if self._buf is not None and self._pinned:
             _lib.load().th_host_unregister(C.c_void_p(self._buf.ctypes.data))
-        self._buf, self._pinned = None, False
+        self._buf, self._pinned, self._pin_failed = None, False, False
 
     def __del__(self):
         try:
