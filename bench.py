@@ -264,6 +264,7 @@ def main():
     if rank == 0:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_legs
+        import bench_line
         cost = model.cost()
         kernel_flops = sum(s["flops"] for s in model.steps())
         total_frames = n * world * args.steps
@@ -273,8 +274,7 @@ def main():
             "metric": "residue_frames_per_sec", "value": fps, "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{model.name}-synth forward, {D}x{H}x{W}x{Cc} fp32 frames resident in HBM, "
-                                   f"{n} frames per GPU per step, {model.n_classes} classes, random-init weights",
+            "config": {"workload": bench_line.workload_string(model.name, (D, H, W, Cc), n, model.n_classes),
                        "frames_per_gpu": n, "chunk": args.chunk, "parallelism": f"frame-shard x{world}",
                        "exchange": exchange, "rccl_ranks": world if comm is not None else 0, "gather_verified": gather_verified,
                        "rows_verified": n,

@@ -71,3 +71,25 @@ def test_short_kernel_names_with_a_remark_in_front_of_the_bracket():
     lab = ("conv3d_1: conv_wf<F(2,3)^2 in-plane fused in LDS, z direct; pool1> 16c x 4, K32, lds159K (16x16x4 MFMA) "
            "(input chunk-blocked) [k_conv_wf<10,10,10,1,0,0>]")
     assert bench_line.short_kernel(lab) == "conv3d_1 k_conv_wf<10,10,10,1,0,0>"
+
+
+def test_workload_string_does_not_depend_on_the_number_of_ranks():
+    """the N = 1 line of the driver's scaling run and the headline run name the same workload: the string is a function of the
+    per-GPU job (weak scaling), and it is the one the canned round-4 record carries"""
+    w = bench_line.workload_string("timed", (21, 21, 21, 6), 100000, 20)
+    assert w == "timed-synth forward, 21x21x21x6 fp32 frames resident in HBM, 100000 frames per GPU per step, 20 classes, random-init weights"
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "bench_line.workload_string(model.name, (D, H, W, Cc), n, model.n_classes)" in src      # nothing rank-dependent goes in
+    r4 = json.load(open(os.path.join(ROOT, "profiles/r04_k_bench_line.json")))
+    assert r4["config"]["workload"].startswith("timed-synth forward, 21x21x21x6 fp32 frames resident in HBM, 100000 frames per GPU per step, 20 classes")
+
+
+def test_bf16x3_steps_are_priced_on_the_bf16_pipe():
+    import bench_legs
+    fp32 = {"label": "conv3d_1: conv_wf<...> [k_conv_wf<10,10,10,1,0,0>]", "flops": 45.88e6}
+    split = {"label": "conv3d_4: conv_wino<...; bf16x3 split operands, 6 products, fp32 accumulate> [k_wino_gemm_b3]", "flops": 69.01e6}
+    assert bench_legs.step_pipe(fp32) == ("fp32", 157.3, 45.88e6)
+    assert bench_legs.step_pipe(split) == ("bf16", 2500.0, 6 * 69.01e6)
+    # 400 k frames/s: the two steps need 0.1167 + 0.0662 of the wall time of their pipes at peak
+    f = bench_legs.pipe_time_frac([fp32, split, {"label": "k_wino_in", "flops": 0.0}], 400e3)
+    assert abs(f - (400e3 * 45.88e6 / 157.3e12 + 400e3 * 6 * 69.01e6 / 2500e12)) < 1e-12

@@ -339,3 +339,120 @@ def test_rccl_transport_single_rank(gpu):
     c.barrier()
     assert np.array_equal(dst.download((37, 20), np.float32), rows)
     c.close()
+
+
+SHARED_GPU_WORKER = textwrap.dedent("""
+    import os, sys, warnings
+    from pathlib import Path
+    sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "timed-design_amd"))
+    import predict
+    from timed_hip import distributed as td
+    warnings.simplefilter("ignore")
+    out = Path({out!r})
+    res = predict.load_dataset_and_predict([Path({model!r})], {data!r}, batch_size={bs}, start_batch={start}, dataset_map_path=out / "datasetmap.txt",
+                                           path_to_output=out, frames_per_call={fpc}, devices=[0])
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    lo, hi = td.shard_bounds(26 - {start} * {bs}, world)[rank]
+    print("RANK_DONE", rank, hi - lo, "root" if res[1] is not None else "peer")
+""")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,bs,fpc,start", [(2, 7, 1024, 0), (3, 6, 4, 0), (3, 12, 5, 2)])
+def test_processes_sharing_one_gpu_write_the_same_bytes_as_one_process(gpu, tmp_path, world, bs, fpc, start):
+    """BASELINE config 4's control flow on REAL kernels with more than one process: `world` processes on the one GPU of the box run
+    predict.py's shard + gather path — every rank predicts its contiguous shard on the device, formats its own text, rank 0
+    assembles — over the explicit host transport (TIMED_GATHER=host: RCCL refuses two ranks on one device; the RCCL transfer
+    itself is covered by the 1-rank tests above and by the driver's 8-GPU run).  Shards of 13 + 13, 8 + 9 + 9 and — a resumed run
+    with 2 rows left for 3 ranks — 0 + 1 + 1 rows (the ROOT's shard is empty): every file equals the single-process run's."""
+    import warnings
+    from pathlib import Path
+    import predict
+    G = os.path.join(ROOT, "tests", "golden")
+    model, data = os.path.join(G, "keras_tiny.h5"), os.path.join(G, "frames_tiny.hdf5")
+    one, many = tmp_path / "one", tmp_path / "many"
+    one.mkdir(); many.mkdir()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        if start:      # a resumed run appends to what the first batches left behind: seed both directories alike
+            for d in (one, many):
+                predict.load_dataset_and_predict([Path(model)], data, batch_size=bs, dataset_map_path=d / "datasetmap.txt", path_to_output=d)
+                for fn in ("keras_tiny.csv", "encoded_labels.csv"):
+                    lines = (d / fn).read_text().splitlines(True)
+                    (d / fn).write_text("".join(lines[: start * bs]))
+        predict.load_dataset_and_predict([Path(model)], data, batch_size=bs, start_batch=start, dataset_map_path=one / "datasetmap.txt",
+                                         path_to_output=one, frames_per_call=fpc)
+    script = tmp_path / "worker.py"
+    script.write_text(SHARED_GPU_WORKER.format(root=ROOT, out=str(many), model=model, data=data, bs=bs, fpc=fpc, start=start))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), TIMED_GATHER="host")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, o, e))
+    for r, (rc, o, e) in enumerate(outs):
+        assert rc == 0, f"rank {r}: {o[-1500:]} {e[-1500:]}"
+    counts = td.shard_counts(26 - start * bs, world)
+    for r, (_rc, o, _e) in enumerate(outs):
+        assert f"RANK_DONE {r} {counts[r]} {'root' if r == 0 else 'peer'}" in o, o[-500:]
+    for fn in sorted(p.name for p in one.iterdir()):
+        assert (one / fn).read_bytes() == (many / fn).read_bytes(), fn
+
+
+HOST_GATHER_WORKER = textwrap.dedent("""
+    import os, sys
+    import numpy as np
+    sys.path.insert(0, os.path.join({root!r}, "timed-design_amd"))
+    from timed_hip import distributed as td
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    g = td.HostGather(rank, world)
+    counts = {counts!r}
+    base = sum(counts[:rank])
+    local = (np.arange(base, base + counts[rank], dtype=np.float32)[:, None] * 10 + np.arange(7, dtype=np.float32)[None, :]).astype(np.float32)
+    out = g.gather_rows(local.reshape(counts[rank], 7), counts, root={root_rank})
+    assert g.allgather_ints([rank, counts[rank]]) == [[r, counts[r]] for r in range(world)]
+    if rank == {root_rank}:
+        n = sum(counts)
+        want = np.arange(n, dtype=np.float32)[:, None] * 10 + np.arange(7, dtype=np.float32)[None, :]
+        assert out.shape == (n, 7) and np.array_equal(out, want)
+        print("ROOT_OK")
+    else:
+        assert out is None
+    try:
+        g.gather_rows(local[:0], counts, 0) if counts[rank] else g.gather_rows(np.zeros((1, 7), np.float32), counts, 0)
+        raise SystemExit("a block that disagrees with counts must be refused")
+    except ValueError:
+        pass
+    g.barrier()
+    g.close()
+""")
+
+
+@pytest.mark.parametrize("counts,root_rank", [([3, 0, 5], 0), ([0, 4], 1), ([1, 1, 1, 0], 0)])
+def test_host_gather_over_the_tcp_rendezvous(tmp_path, counts, root_rank):
+    """timed_hip.distributed.HostGather (the explicit transport for ranks that share a GPU, TIMED_GATHER=host): uneven and empty
+    blocks, a root other than rank 0, a block that disagrees with `counts` refused on the spot — no PyTorch, no GPU"""
+    script = tmp_path / "worker.py"
+    script.write_text(HOST_GATHER_WORKER.format(root=ROOT, counts=counts, root_rank=root_rank))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    world = len(counts)
+    procs = [subprocess.Popen([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              env=dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)))
+             for r in range(world)]
+    outs = [p.communicate(timeout=180) + (p.returncode,) for p in procs]
+    for r, (o, e, rc) in enumerate(outs):
+        assert rc == 0, f"rank {r}: {o[-800:]} {e[-800:]}"
+    assert "ROOT_OK" in outs[root_rank][0]

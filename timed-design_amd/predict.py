@@ -520,7 +520,11 @@ def _predict_sharded(model, gather, rank, world, dataset_path, flat_dataset_map,
     groups = [(a, min(a + max(1, int(frames_per_call)), len(shard))) for a in range(0, len(shard), max(1, int(frames_per_call)))]
     own_transport = gather is None
     if own_transport:
-        gather = td.RcclGather.from_environment(rank, world, model.device)     # raises when RCCL cannot be brought up
+        if os.environ.get("TIMED_GATHER", "rccl") == "host":
+            # explicit opt-in for ranks that share a GPU (RCCL refuses two ranks on one device): rows travel over the TCP rendezvous
+            gather = td.HostGather(rank, world)
+        else:
+            gather = td.RcclGather.from_environment(rank, world, model.device)     # raises when RCCL cannot be brought up
     try:
         if isinstance(gather, td.RcclGather):
             width = model.n_classes
@@ -547,7 +551,7 @@ def _predict_sharded(model, gather, rank, world, dataset_path, flat_dataset_map,
             d_all = engine.DeviceBuffer(max(1, n * width * 4), model.device) if rank == 0 else None
             gather.gather_rows_device(d_local.ptr, counts, width, 0, d_all.ptr if d_all else 0)
             probs = d_all.download((n, width), np.float32) if rank == 0 else None
-        else:                     # host transport (tests/_gloo_transport.GlooGather, the CPU tests): rows are on the host already
+        else:                     # host transport (distributed.HostGather; tests/_gloo_transport.GlooGather): rows are on the host already
             local = np.zeros((len(shard), model.n_classes), dtype=np.float32)
             cursor = [0]
 

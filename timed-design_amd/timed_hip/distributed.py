@@ -129,6 +129,41 @@ class RcclGather:
             pass
 
 
+class HostGather:
+    """The same row-gather interface over the product's own TCP rendezvous (timed_hip/rendezvous.py), rows in HOST memory: for
+    ranks that SHARE a GPU — a development box, the 2-process-on-1-GPU tests — where RCCL cannot span the ranks (it refuses two
+    ranks on one device).  Never chosen silently: predict.py takes it only under TIMED_GATHER=host; a one-process-per-GPU job
+    uses RcclGather and fails loudly when RCCL cannot be brought up."""
+
+    def __init__(self, rank: int, world: int, rendezvous=None):
+        from .rendezvous import HostRendezvous
+        self.rank, self.world = rank, world
+        self._own = rendezvous is None
+        self.rendezvous = rendezvous or HostRendezvous(rank, world)
+
+    def gather_rows(self, local: np.ndarray, counts: Sequence[int], root: int = 0) -> Optional[np.ndarray]:
+        local = np.ascontiguousarray(local, dtype=np.float32)
+        if len(counts) != self.world or local.shape[0] != counts[self.rank]:
+            raise ValueError(f"rank {self.rank}: local block has {local.shape[0]} rows, counts say {list(counts)}")
+        width = local.shape[1]
+        parts = self.rendezvous.allgather(local.tobytes())
+        if self.rank != root:
+            return None
+        blocks = [np.frombuffer(b, dtype=np.float32).reshape(c, width) for b, c in zip(parts, counts)]
+        return np.concatenate(blocks, axis=0) if blocks else np.empty((0, width), np.float32)
+
+    def allgather_ints(self, values: Sequence[int]) -> List[List[int]]:
+        return self.rendezvous.allgather_ints(values)
+
+    def barrier(self):
+        self.rendezvous.barrier()
+
+    def close(self):
+        if self._own and self.rendezvous is not None:
+            self.rendezvous.close()
+        self.rendezvous = None
+
+
 def predict_sharded(model, frames_for_range, n_total: int, gather, root: int = 0) -> Optional[np.ndarray]:
     """Predict this rank's contiguous shard and gather the probability rows to ``root``.
 

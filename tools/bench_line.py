@@ -16,6 +16,15 @@ REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
             "vs_baseline", "dtype", "data", "config")
 
 
+def workload_string(topology: str, dims, frames_per_gpu: int, n_classes: int) -> str:
+    """`config.workload` of the bench line.  A function of the per-GPU job only — never of the number of ranks — so that the N = 1
+    line of a scaling run (SCALE_rNN.json) names the same workload as the headline run (BENCH_rNN.json): scaling is weak, every
+    rank runs this job on its own GPU (tests/test_bench_line.py holds the two equal)."""
+    d, h, w, c = (int(v) for v in dims)
+    return (f"{topology}-synth forward, {d}x{h}x{w}x{c} fp32 frames resident in HBM, {int(frames_per_gpu)} frames per GPU per step, "
+            f"{int(n_classes)} classes, random-init weights")
+
+
 def _r(x, nd=4):
     """Round floats to `nd` significant digits (ints and None pass through)."""
     if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
