@@ -39,7 +39,8 @@ def _one_layer(cin, cout, seed, pre=False, bias=True):
 
 
 @pytest.mark.parametrize("cin,cout,n,pre", [(32, 64, 1, False), (64, 128, 3, False), (128, 128, 64, False), (128, 256, 65, False),
-                                            (256, 338, 5, False), (32, 96, 130, True), (64, 64, 7, True)])
+                                            (256, 338, 5, False), (32, 96, 130, True), (64, 64, 7, True),
+                                            (256, 20, 37, False), (128, 32, 70, True), (160, 7, 3, False)])      # narrow: k_wino_gemm_n32
 def test_single_layer_matches_the_float64_oracle(gpu, monkeypatch, cin, cout, n, pre):
     """one Conv -> ELU -> BN block (with and without a BN -> ReLU prologue), frame counts around the 64-frame GEMM row block,
     Cout that is not a multiple of the 128-column block (96, 338): the layer's tensor against the oracle in float64"""
@@ -102,8 +103,17 @@ def test_winograd_is_not_taken_where_it_does_not_apply(gpu, monkeypatch):
     model = engine.HipFrameModel.from_keras(cfg, w, device=gpu)
     labels = [s["label"] for s in model.steps()]
     conv = [l for l in labels if l.startswith("conv3d") and not any(k in l for k in ("wino_in", "wino_out", "wino_mid"))]
+    # the 20-class head (256 -> 20) is a Winograd layer too since round 5: the narrow split GEMM (k_wino_gemm_n32)
+    assert [("k_wino_gemm" in l) for l in conv] == [False, False, True, True, True, True]
+    assert "k_wino_gemm_n32" in conv[-1] and "bf16x3" in conv[-1]
+    # conv3d_2 .. conv3d_5 are consecutive Winograd layers: one input transform, three fused mid transforms, one (pooling) output
+    assert [sum(k in l for l in labels) for k in ("k_wino_in", "k_wino_mid", "k_wino_out")] == [1, 3, 1]
+    model.close()
+    monkeypatch.setenv("TH_WINO_SPLIT", "0")           # fp32-input MFMA GEMMs: the narrow head stays on the direct kernel
+    model = engine.HipFrameModel.from_keras(cfg, w, device=gpu)
+    labels = [s["label"] for s in model.steps()]
+    conv = [l for l in labels if l.startswith("conv3d") and not any(k in l for k in ("wino_in", "wino_out", "wino_mid"))]
     assert [("k_wino_gemm" in l) for l in conv] == [False, False, True, True, True, False]
-    # conv3d_2 -> conv3d_3 -> conv3d_4 are consecutive Winograd layers: one input transform, two fused mid transforms, one output
     assert [sum(k in l for l in labels) for k in ("k_wino_in", "k_wino_mid", "k_wino_out")] == [1, 2, 1]
     model.close()
 

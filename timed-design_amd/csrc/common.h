@@ -183,6 +183,7 @@ struct ConvWinoPlan {
     double exec_flops = 0;                       // MFMA FLOPs issued per frame (Cout padded to the column block)
     int split = 0;                               // 1: the GEMM runs on bf16 MFMA with both operands split exactly into three bf16 pieces
                                                  // (x = h + m + l) and six of the nine piece products summed in fp32 (k_wino_gemm_b3)
+    int narrow = 0;                              // split GEMM of a layer with Cout <= 32: one 32-column tile per wave, no LDS (k_wino_gemm_n32)
     const ThKnobs* knobs = nullptr;
     std::string label;
 };

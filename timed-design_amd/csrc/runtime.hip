@@ -878,7 +878,7 @@ int plan(th_model* m) {
                         // split GEMM: six bf16 piece products per fp32 multiply-add — what the bf16 matrix pipe issues
                         st.exec_flops = wp.split ? 6.0 * wp.exec_flops : wp.exec_flops;
                         st.bytes = 4.0 * ((double)vf + (double)mf);
-                        st.label = n.name + ": " + wp.label + (wp.split ? " [k_wino_gemm_b3]" : " [k_wino_gemm]");
+                        st.label = n.name + ": " + wp.label + (wp.narrow ? " [k_wino_gemm_n32]" : wp.split ? " [k_wino_gemm_b3]" : " [k_wino_gemm]");
                         st.run = [=](hipStream_t s, int64_t cnt) { return launch_wino_gemm(s, cnt, wp, Vp(), Mp(), dw); };
                         add_step(st);
                         // two Winograd layers in a row and nobody else reads the tensor between them: this layer's output transform
@@ -893,7 +893,7 @@ int plan(th_model* m) {
                                 const ConvGeom g2 = geom_of(nx, N[dst]);
                                 TView i2; i2.D = N[dst].D; i2.H = N[dst].H; i2.W = N[dst].W; i2.C = N[dst].C;
                                 TView o2; o2.D = nx.D; o2.H = nx.H; o2.W = nx.W; o2.C = nx.C;
-                                if (conv_wino_plan(i2, o2, g2, N[dst].C, nx.C, wp.P, &np) && np.Cin == Cout) next = c2;
+                                if (conv_wino_plan(i2, o2, g2, N[dst].C, nx.C, wp.P, &np, M->wino_split) && np.Cin == Cout) next = c2;
                             }
                         }
                         if (next >= 0) {
