@@ -84,10 +84,55 @@ def _activation(x, name, alpha=None):
     raise ValueError(f"activation {name}")
 
 
+_CONV_C = None        # ctypes handle of oracle/_build/liboracle_conv.so once use_c_conv() found it
+
+
+def use_c_conv(threads: int = 0) -> bool:
+    """Route float32, dilation-1 convolutions of forward() through the blocked direct convolution of oracle/conv3d_omp.c (OpenMP
+    over `threads` host cores; 0 = OpenMP's default) — the `cpu_baseline` configuration of bench.py.  Returns
+    False when the library has not been built (__graft_entry__.build() / make -C oracle): the NumPy im2col + sgemm form stays.
+    tests/test_oracle_cnn.py holds the two forms together."""
+    global _CONV_C
+    import ctypes as C
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "liboracle_conv.so")
+    if not os.path.exists(path):
+        return False
+    lib = C.CDLL(path)
+    lib.oracle_conv3d_f32.restype = C.c_int
+    lib.oracle_conv3d_f32.argtypes = [C.c_void_p] * 4 + [C.c_long] + [C.c_int] * 18
+    _CONV_C = (lib, int(threads))
+    return True
+
+
+def use_numpy_conv() -> None:
+    global _CONV_C
+    _CONV_C = None
+
+
+def _conv3d_c(x, kernel, bias, s, padding):
+    lib, threads = _CONV_C
+    n, d, h, w, cin = x.shape
+    kd, kh, kw, _cin, cout = kernel.shape
+    pads = [_same_pads(x.shape[1 + i], kernel.shape[i], s[i], 1) if padding == "same" else (0, 0) for i in range(3)]
+    outs = [(x.shape[1 + i] + sum(pads[i]) - kernel.shape[i]) // s[i] + 1 for i in range(3)]
+    xc = np.ascontiguousarray(x, dtype=np.float32)
+    kc = np.ascontiguousarray(kernel, dtype=np.float32)
+    bc = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32)
+    y = np.empty((n, *outs, cout), dtype=np.float32)
+    rc = lib.oracle_conv3d_f32(xc.ctypes.data, kc.ctypes.data, bc.ctypes.data if bc is not None else None, y.ctypes.data, n, d, h, w, cin,
+                               cout, kd, kh, kw, s[0], s[1], s[2], pads[0][0], pads[1][0], pads[2][0], outs[0], outs[1], outs[2], threads)
+    if rc != 0:
+        raise MemoryError("oracle_conv3d_f32 could not allocate its scratch")
+    return y
+
+
 def conv3d(x, kernel, bias, strides, dilation, padding, acc_dtype):
     """x [N,D,H,W,Cin]; kernel [kd,kh,kw,Cin,Cout]."""
     kd, kh, kw, cin, cout = kernel.shape
     s, d = _t3(strides), _t3(dilation)
+    if _CONV_C is not None and acc_dtype == np.float32 and d == (1, 1, 1) and x.ndim == 5 and min(x.shape) > 0:
+        return _conv3d_c(x, kernel, bias, s, padding)
     if padding == "same":
         pads = [_same_pads(x.shape[1 + i], kernel.shape[i], s[i], d[i]) for i in range(3)]
         x = np.pad(x, [(0, 0), *pads, (0, 0)])

@@ -1,9 +1,13 @@
 """The CNN oracle against the torch-generated golden vectors (tests/golden/make_cnn_golden.py).
 TensorFlow is unavailable (parity unpinned vs Keras itself); torch CPU is the independent arbiter."""
+import os
+
 import numpy as np
 import pytest
 
 from oracle import cnn_oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from timed_hip import synth
 
 
@@ -83,3 +87,39 @@ def test_oracle_input_dtypes_equivalent():
     a = cnn_oracle.forward(cfg, weights, fb.astype(bool))
     b = cnn_oracle.forward(cfg, weights, fb.astype(np.float64))
     assert np.array_equal(a, b)
+
+
+def test_c_direct_convolution_equals_the_numpy_convolution():
+    """oracle/conv3d_omp.c (the cpu_baseline configuration of bench.py: blocked direct convolution, OpenMP) against the NumPy
+    im2col form it replaces there and against float64: 'same' / 'valid', strides, anisotropic and even kernels, 1x1x1, Cout that is
+    not a multiple of the 32-channel register tile, widths that are not a multiple of the 6-voxel tile; then a whole forward pass"""
+    import subprocess
+    if not cnn_oracle.use_c_conv(2):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
+        assert cnn_oracle.use_c_conv(2)
+    try:
+        rng = np.random.default_rng(0)
+        cases = [((5, 6, 7), 3, 5, (3, 3, 3), (1, 1, 1), "same"), ((9, 8, 7), 4, 33, (3, 2, 5), (2, 1, 2), "same"),
+                 ((7, 7, 7), 6, 16, (3, 3, 3), (1, 1, 1), "valid"), ((6, 5, 4), 2, 70, (1, 1, 1), (1, 1, 1), "same"),
+                 ((8, 8, 8), 5, 20, (5, 5, 5), (2, 2, 2), "valid"), ((4, 4, 13), 1, 1, (4, 4, 4), (1, 1, 1), "same")]
+        for shape, cin, cout, k, s, pad in cases:
+            x = rng.standard_normal((3, *shape, cin)).astype(np.float32)
+            w = rng.standard_normal((*k, cin, cout)).astype(np.float32)
+            b = rng.standard_normal(cout).astype(np.float32)
+            got = cnn_oracle.conv3d(x, w, b, s, (1, 1, 1), pad, np.float32)
+            cnn_oracle.use_numpy_conv()
+            ref32 = cnn_oracle.conv3d(x, w, b, s, (1, 1, 1), pad, np.float32)
+            ref64 = cnn_oracle.conv3d(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64), s, (1, 1, 1), pad, np.float64)
+            assert cnn_oracle.use_c_conv(2)
+            assert got.shape == ref32.shape and got.dtype == np.float32
+            scale = max(1.0, float(np.abs(ref64).max()))
+            assert float(np.abs(got - ref64).max()) <= 4e-6 * scale, (shape, k, s, pad)
+            # no bias, and a dilated kernel (not the C path's business): both fall through correctly
+            assert np.allclose(cnn_oracle.conv3d(x, w, None, s, (1, 1, 1), pad, np.float32), ref32 - b, atol=1e-4 * scale)
+        cfg, weights = synth.timed_synth(20)
+        frames = synth.synthetic_frames(3, seed=3)
+        fast = cnn_oracle.forward(cfg, weights, frames)
+        cnn_oracle.use_numpy_conv()
+        assert np.abs(fast - cnn_oracle.forward(cfg, weights, frames)).max() < 2e-6
+    finally:
+        cnn_oracle.use_numpy_conv()
