@@ -302,6 +302,10 @@ def test_heterogeneous_cout_blocks(gpu, shape, cin, cout, pool, post, n, kernels
     ((9, 8, 6), 8, 32, None, "leaky", 4),            # no pool: both outputs of a pair stored, 4 k-steps
     ((7, 6, 10), 3, 9, "max", "none", 7),            # 2 k-steps, odd depth (last plane dropped by the pool), Cout < 32
     ((6, 6, 4), 1, 16, None, "elu_bn", 3),           # one input channel
+    ((21, 21, 21), 6, 64, "max", "elu_bn", 2),       # a 64-filter first layer: two passes of 32 columns over the caller's frames
+    ((10, 8, 6), 5, 40, None, "elu_bn", 3),          # 32 + 8 columns, per-channel BatchNorm vectors of the second pass start at channel 32
+    ((8, 8, 8), 6, 97, "avg", "leaky", 2),           # four passes, the last one a single column
+    ((7, 6, 6), 4, 33, "max", "tanh", 3),            # non-monotone chain, 32 + 1
 ])
 def test_first_layer_winograd_along_x(gpu, monkeypatch, shape, cin, cout, pool, post, n):
     """k_conv_first_w (F(2,3) along x: rows are x pairs, four transform points per (dz, dy) tap formed in registers) against the
@@ -326,6 +330,8 @@ def test_first_layer_winograd_along_x(gpu, monkeypatch, shape, cin, cout, pool, 
     frames = _frames(n, shape, cin, seed=n + 3)
     labels = _check(cfg, weights, frames)
     assert any("k_conv_first_w" in l for l in labels), labels
+    if cout > 32:
+        assert any(f"x{(cout + 31) // 32} passes" in l for l in labels), labels
     _check(cfg, weights, frames, chunk=2)
     got = engine.HipFrameModel.from_keras(cfg, weights).predict(frames)
     monkeypatch.setenv("TH_FIRST_WINO", "0")

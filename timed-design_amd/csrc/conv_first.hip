@@ -578,10 +578,13 @@ bool conv_first_plan(int Din, int Hin, int Win, int Cin, const TView& oc, const 
                      ConvMfmaPlan* p) {
     if (g.kd != 3 || g.kh != 3 || g.kw != 3) return false;
     if (g.sd != 1 || g.sh != 1 || g.sw != 1 || g.dd != 1 || g.dh != 1 || g.dw != 1) return false;
-    if (Cin < 1 || Cin > 8 || Cout > 32) return false;
+    // the kernel holds the weights of 32 output channels in registers; a wider first layer (33 .. 128 filters) runs it once per
+    // block of 32 columns (nnb passes over the caller's frames: a 64-filter layer costs two launches of 2.3 ms per 4096 frames
+    // where the generic brick kernel, which the layer would otherwise fall to, takes 11 — tools/plan_report.py, timed_w40)
+    if (Cin < 1 || Cin > 8 || Cout > 128) return false;
     if (pool && (oc.D < 2 || oc.H < 2 || oc.W < 2)) return false;
     p->cfg = 100;  // marks the first-layer kernel
-    p->CI = 8; p->CS = 8; p->BN = 32; p->nnb = 1; p->nchunks = 1; p->pool = pool; p->bres = 1; p->FB = 1;
+    p->CI = 8; p->CS = 8; p->BN = 32; p->nnb = (Cout + 31) / 32; p->nchunks = 1; p->pool = pool; p->bres = 1; p->FB = 1;
     p->Dc = pool ? (oc.D / 2) * 2 : oc.D;
     p->Hc = pool ? (oc.H / 2) * 2 : oc.H;
     p->Wc = pool ? (oc.W / 2) * 2 : oc.W;
@@ -626,7 +629,7 @@ bool conv_first_plan(int Din, int Hin, int Win, int Cin, const TView& oc, const 
     p->lds_bytes = lds_for(ZB);
     p->tab_off = img_for(ZB);
     p->wpk_floats = (size_t)(wino ? 36 : kTaps) * 2 * 32 * 4;
-    p->exec_flops = 2.0 * (double)p->nzb * p->rows_pf * 32.0 * (2.0 * nst) * (wino ? 36 : kTaps);
+    p->exec_flops = 2.0 * (double)p->nzb * p->rows_pf * 32.0 * (2.0 * nst) * (wino ? 36 : kTaps) * p->nnb;
     p->own_flops = wino ? 2.0 * (double)p->Dc * p->Hc * (p->Wc / 2) * 36.0 * Cin * Cout : 0.0;
     if (oc.fs > 0x7fffffffLL) return false;
     char buf[224];

@@ -727,7 +727,7 @@ int plan(th_model* m) {
             const ConvMfmaPlan& pp = mplans[prod];
             ConvWfPlan dummy;
             if (wf_plan_for(prod, &dummy)) continue;                    // (the producer itself runs on conv_wfused: channels-last stores only)
-            if (!((pp.cfg >= 300 && pp.pool == 0) || pp.cfg == 100)) continue;
+            if (!((pp.cfg >= 300 && pp.pool == 0) || (pp.cfg == 100 && pp.nnb == 1))) continue;
             bool shared = false;                                        // nobody else may alias the buffer (Flatten / Identity views)
             for (int k = 0; k < nn; ++k) if (k != src && N[k].buf == sn.buf && N[k].materialised) shared = true;
             if (shared) continue;
@@ -958,21 +958,42 @@ int plan(th_model* m) {
                         };
                     } else if (mplans.count(i) && mplans[i].cfg == 100) {
                         const ConvMfmaPlan mp = mplans[i];
-                        std::vector<float> packed(mp.wpk_floats);
                         if (mp.first_wino) {
-                            conv_first_w_pack_weights(Cin, Cout, hw, packed.data());
                             st.direct_flops = st.flops;
                             st.flops = mp.own_flops;
-                        } else
-                        conv_first_pack_weights(Cin, Cout, hw, packed.data());
-                        float* dw;
-                        if ((rc = upload(M, packed.data(), packed.size(), &dw))) return rc;
+                        }
                         st.exec_flops = mp.exec_flops;
                         st.label = n.name + ": " + (N[dst].blk ? label_note(conv_first_label(mp, Cin, po), " (output chunk-blocked)") : conv_first_label(mp, Cin, po));
+                        if (mp.nnb > 1) st.label = label_note(st.label, (" x" + std::to_string(mp.nnb) + " passes of 32 columns").c_str());
                         const int iD = sn.D, iH = sn.H, iW = sn.W;
+                        // one launch per block of 32 output channels: its own weight columns, bias and per-channel epilogue vectors
+                        struct Pass { int c0, cn; float* dw; const float* bias; PostOps po; };
+                        std::vector<Pass> passes;
+                        const size_t ktaps = (size_t)g.kd * g.kh * g.kw * Cin;
+                        for (int c0 = 0; c0 < Cout; c0 += 32) {
+                            Pass ps;
+                            ps.c0 = c0; ps.cn = std::min(32, Cout - c0);
+                            std::vector<float> wcol(ktaps * ps.cn), packed(mp.wpk_floats);
+                            for (size_t r = 0; r < ktaps; ++r) std::memcpy(&wcol[r * ps.cn], hw + r * Cout + c0, (size_t)ps.cn * sizeof(float));
+                            if (mp.first_wino) conv_first_w_pack_weights(Cin, ps.cn, wcol.data(), packed.data());
+                            else conv_first_pack_weights(Cin, ps.cn, wcol.data(), packed.data());
+                            if ((rc = upload(M, packed.data(), packed.size(), &ps.dw))) return rc;
+                            ps.bias = dbias ? dbias + c0 : nullptr;
+                            ps.po = po;
+                            for (int k = 0; k < ps.po.n; ++k) {
+                                if (ps.po.scale[k]) ps.po.scale[k] += c0;
+                                if (ps.po.shift[k]) ps.po.shift[k] += c0;
+                            }
+                            passes.push_back(ps);
+                        }
                         st.run = [=](hipStream_t s, int64_t cnt) {
-                            return launch_conv_first(s, cnt, mp, M->cur_in, M->cur_dtype, iD, iH, iW, Cin, M->view(dst), g, Cout,
-                                                     dw, dbias, po);
+                            for (const Pass& ps : passes) {
+                                TView ov = M->view(dst);
+                                if (passes.size() > 1) { ov.coff += ps.c0; ov.C = ps.cn; }
+                                const int r = launch_conv_first(s, cnt, mp, M->cur_in, M->cur_dtype, iD, iH, iW, Cin, ov, g, ps.cn, ps.dw, ps.bias, ps.po);
+                                if (r) return r;
+                            }
+                            return (int)TH_OK;
                         };
                     } else if (mplans.count(i) && mplans[i].cfg >= 300) {
                         const ConvMfmaPlan mp = mplans[i];
