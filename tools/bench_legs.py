@@ -73,6 +73,29 @@ def host_resident(model, d_frames_ptr, n_total, device_fps, n=16384, batch=1024)
     res["ratio_sync_pageable"] = res["th_predict_sync_pageable_fps"] / device_fps
     res["ratio_async_pageable"] = res["th_predict_async_pageable_fps"] / device_fps
     model.set_chunk(old_chunk)
+    # the same model on DEVICE-RESIDENT uint8 frames (boolean aposteriori datasets, voxels_as_gaussian=False: reference
+    # utils.py:518-521): the first-layer kernel reads the caller's bytes directly (a quarter of the float32 frames' HBM traffic);
+    # 4096 distinct frames tiled to 32 768 on the device, the chunk the headline run uses
+    try:
+        from timed_hip import synth
+        base = synth.synthetic_frames(4096, side=D, channels=Cc, seed=77, gaussian=False)
+        n8 = 8 * len(base)
+        d8 = engine.DeviceBuffer(n8 * base[0].size, model.device)
+        for k in range(8):
+            _lib.check(lib.th_dev_upload(model.device, C.c_void_p(d8.ptr + k * base.nbytes), base.ctypes.data, base.nbytes))
+        d_o8 = engine.DeviceBuffer(n8 * model.n_classes * 4, model.device)
+        model.predict_device(d8.ptr, n8, d_o8.ptr, dtype=_lib.TH_U8)
+
+        def run8():
+            model.predict_device(d8.ptr, n8, d_o8.ptr, dtype=_lib.TH_U8)
+        res["device_resident_u8_frames"] = n8
+        res["device_resident_u8_fps"] = n8 / _best(run8, 3)
+        y8 = d_o8.download((n8, model.n_classes), np.float32)
+        assert np.isfinite(y8).all() and np.abs(y8.sum(1) - 1).max() < 1e-4 and np.array_equal(y8[:4096], y8[4096:8192])
+        d8.free(); d_o8.free()
+    except Exception as e:            # a leg never takes the bench line down
+        res["device_resident_u8_fps"] = None
+        res["device_resident_u8_note"] = repr(e)[:200]
     del pinned
     owner.free()
     return res
