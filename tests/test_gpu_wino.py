@@ -40,7 +40,9 @@ def _one_layer(cin, cout, seed, pre=False, bias=True):
 
 @pytest.mark.parametrize("cin,cout,n,pre", [(32, 64, 1, False), (64, 128, 3, False), (128, 128, 64, False), (128, 256, 65, False),
                                             (256, 338, 5, False), (32, 96, 130, True), (64, 64, 7, True),
-                                            (256, 20, 37, False), (128, 32, 70, True), (160, 7, 3, False)])      # narrow: k_wino_gemm_n32
+                                            (256, 20, 37, False), (128, 32, 70, True), (160, 7, 3, False),       # narrow: k_wino_gemm_n32
+                                            (40, 72, 5, False), (72, 136, 66, True), (136, 264, 3, False),       # Cin padded to 64 / 96 / 160
+                                            (36, 64, 4, False), (200, 24, 9, False)])                            # 36 -> 64; narrow with 200 -> 224
 def test_single_layer_matches_the_float64_oracle(gpu, monkeypatch, cin, cout, n, pre):
     """one Conv -> ELU -> BN block (with and without a BN -> ReLU prologue), frame counts around the 64-frame GEMM row block,
     Cout that is not a multiple of the 128-column block (96, 338): the layer's tensor against the oracle in float64"""
@@ -261,3 +263,36 @@ def test_output_transform_pools_for_a_global_average_tail(gpu, monkeypatch, cin,
     ref = cnn_oracle.forward(cfg, w, frames[:8], np.float64)
     np.testing.assert_allclose(fused.predict(frames[:8]), ref, atol=TIGHT, rtol=0)
     fused.close(); plain.close()
+
+
+def test_consecutive_layers_with_padded_channel_counts(gpu):
+    """widths that are no multiple of the GEMM's 32-channel chunk through the fused mid transform: 40 -> 72 -> 136 -> 20 at 5^3
+    (V rows 64, 96, 160 and 160 channels wide; k_wino_mid writes zeros into the padding channels of the next layer's V, whose
+    scratch arena was last used by a layer of another width) against the float64 oracle; twice, so that the second run finds the
+    scratch of the first"""
+    b = synth.KerasGraphBuilder((5, 5, 5, 40), seed=77)
+    x = b.input_name
+    for c in (72, 136, 136, 20):
+        x = b.conv3d(x, c, 3, padding="same")
+        x = b.elu(x)
+        x = b.batchnorm(x)
+    x = b.gap(x)
+    x = b.softmax(x)
+    cfg, w = b.finish(x)
+    rng = np.random.default_rng(5)
+    frames = (rng.standard_normal((70, 5, 5, 5, 40)) * (rng.random((70, 5, 5, 5, 40)) < 0.5)).astype(np.float32)
+    model = engine.HipFrameModel.from_keras(cfg, w, device=gpu)
+    labels = [s["label"] for s in model.steps()]
+    assert sum("k_wino_gemm" in l for l in labels) == 4 and sum("k_wino_mid" in l for l in labels) == 3, labels
+    assert any("K64 (40 real)" in l for l in labels) and any("K160 (136 real)" in l for l in labels), labels
+    ref = cnn_oracle.forward(cfg, w, frames[:6], np.float64, return_all=True)
+    last = list(ref)[-1]
+    logit_layer = [k for k in ref if "global_average" in k][-1]
+    for _ in range(2):
+        probs = model.predict(frames)
+        np.testing.assert_allclose(probs[:6], ref[last], atol=TIGHT, rtol=0)
+        logits = model.predict(frames, logits=True)
+        np.testing.assert_allclose(logits[:6], ref[logit_layer], atol=TIGHT * max(1.0, float(np.abs(ref[logit_layer]).max())), rtol=0)
+    model.set_chunk(64)                                       # the ragged second launch of 6 frames
+    np.testing.assert_allclose(model.predict(frames), probs, atol=1e-6, rtol=0)
+    model.close()

@@ -177,6 +177,7 @@ int launch_conv_mfma(hipStream_t s, int64_t n, const ConvMfmaPlan& p, TView in, 
 struct ConvWinoPlan {
     int P = 9;                                   // evaluation points per in-plane axis: 9 = F(3,3)+F(2,3) (default), 7 = F(5,3)
     int Cin = 0, Cout = 0, Coutp = 0, ncb = 0;   // Coutp: Cout rounded up to the 128-column GEMM block
+    int Cinp = 0;                                // Cin rounded up to the GEMM's 32-channel chunk: the channel count of V (padding channels are zero)
     size_t wpk_floats = 0;                       // transformed weights in fragment-stream order
     int64_t v_fpf = 0, m_fpf = 0;                // scratch floats per frame: transformed input V, GEMM output M
     double gemm_flops = 0;                       // the algorithm's multiply-adds x 2 per frame: P^2 positions x 13 z-tap pairs x Cin x Cout

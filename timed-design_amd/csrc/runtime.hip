@@ -1095,7 +1095,7 @@ int plan(th_model* m) {
                         else if (sn.D == 5 && sn.H == 5 && sn.W == 5) {
                             if (!M->winograd) why = "TH_WINOGRAD=0";
                             else if (f.pool >= 0) why = "a pooling layer is fused behind it";
-                            else if (sn.C < 32 || sn.C % 32) why = "Cin is not a multiple of 32";
+                            else if (sn.C < 32) why = "Cin < 32";
                             else if (n.C < 64) why = "Cout < 64 (a 128-column GEMM block would run mostly empty)";
                             else why = "softmax fused into the layer";
                         } else if (sn.H % 2 == 0 && sn.W % 2 == 0 && sn.D * (sn.H / 2) * (sn.W / 2) <= 250) {
