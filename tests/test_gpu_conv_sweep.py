@@ -329,7 +329,7 @@ def test_first_layer_winograd_along_x(gpu, monkeypatch, shape, cin, cout, pool, 
     cfg, weights = _net(shape, cin, build, seed=cin * 7 + cout)
     frames = _frames(n, shape, cin, seed=n + 3)
     labels = _check(cfg, weights, frames)
-    assert any("k_conv_first_w" in l for l in labels), labels
+    assert any("k_conv_first_w" in l or "k_conv_first_b3" in l for l in labels), labels
     if cout > 32:
         assert any(f"x{(cout + 31) // 32} passes" in l for l in labels), labels
     _check(cfg, weights, frames, chunk=2)
@@ -339,3 +339,55 @@ def test_first_layer_winograd_along_x(gpu, monkeypatch, shape, cin, cout, pool, 
     ref = m.predict(frames)
     assert any("k_conv_first<" in s["label"] for s in m.steps()), [s["label"] for s in m.steps()]
     np.testing.assert_allclose(got, ref, rtol=0, atol=4e-6 * max(1.0, float(np.abs(ref).max())))
+
+
+@pytest.mark.parametrize("cin,cout,post,n,resident,dtype", [
+    (6, 32, "elu_bn", 3, 0, np.float32),        # TIMED block 1
+    (6, 32, "elu_bn", 11, 2, np.float32),       # two workgroups: 6 and 5 frames each stream through the plane ring back to back
+    (6, 32, "bn_relu", 7, 3, np.uint8),         # DenseCPD's opening chain, uint8 frames (the generic element loads), trips 3 / 2 / 2
+    (5, 24, "relu", 4, 1, np.float32),          # 5-channel codec, Cout < 32, ONE workgroup walks all four frames
+    (6, 64, "elu_bn", 5, 2, np.float32),        # two passes of 32 columns
+    (6, 20, "relu", 1, 0, np.float64),          # a single frame, float64 frames
+])
+def test_first_layer_on_the_bf16_pipe_with_split_operands(gpu, monkeypatch, cin, cout, post, n, resident, dtype):
+    """k_conv_first_b3 (conv_first_b3.hip: the aposteriori first layer as F(2,3) along x on bf16 MFMA, operands split exactly
+    into three bf16 pieces, a persistent workgroup streaming frames through a ring of planes) against the oracle, against the
+    fp32-input kernel it replaces (TH_FIRST_SPLIT=0), with several frames per workgroup and ragged chunks."""
+    def build(b, x):
+        x = b.conv3d(x, cout, 3, padding="same")
+        if post == "elu_bn":
+            x = b.batchnorm(b.elu(x))
+        elif post == "bn_relu":
+            x = b.relu(b.batchnorm(x))
+        elif post == "relu":
+            x = b.relu(x)
+        return b.maxpool(x, 2)
+
+    shape = (21, 21, 21)
+    cfg, weights = _net(shape, cin, build, seed=cin * 11 + cout)
+    if dtype == np.uint8:
+        frames = np.random.default_rng(n).integers(0, 256, (n, *shape, cin)).astype(np.uint8) * (np.random.default_rng(n + 1).random((n, *shape, cin)) < 0.3)
+        frames = frames.astype(np.uint8)
+    else:
+        frames = _frames(n, shape, cin, seed=n + 5).astype(dtype)
+    if resident:
+        monkeypatch.setenv("TH_WF_RESIDENT", str(resident))
+    want = cnn_oracle.forward(cfg, weights, frames.astype(np.float32), np.float32)
+    scale = max(1.0, float(np.abs(want).max()))
+    m = engine.HipFrameModel.from_keras(cfg, weights)
+    labels = [s["label"] for s in m.steps()]
+    assert any("k_conv_first_b3" in l and "bf16x3" in l for l in labels), labels
+    if cout > 32:
+        assert any("x2 passes" in l for l in labels), labels
+    got = m.predict(frames)
+    m.set_chunk(3)
+    got3 = m.predict(frames)
+    m.close()
+    assert float(np.abs(got - want).max()) <= 2e-5 * scale
+    np.testing.assert_array_equal(got, got3)                    # a frame's result does not depend on its place in the ring
+    monkeypatch.setenv("TH_FIRST_SPLIT", "0")
+    m = engine.HipFrameModel.from_keras(cfg, weights)
+    assert any("k_conv_first_w" in s["label"] for s in m.steps()), [s["label"] for s in m.steps()]
+    ref = m.predict(frames)
+    m.close()
+    np.testing.assert_allclose(got, ref, rtol=0, atol=4e-6 * scale)

@@ -21,7 +21,7 @@ def _labels(model):
 
 
 def _fast(labels):
-    return [l for l in labels if "conv_wino" in l or "conv_wf<" in l or "k_conv_first_w" in l]
+    return [l for l in labels if "conv_wino" in l or "conv_wf<" in l or "k_conv_first_w" in l or "k_conv_first_b3" in l]
 
 
 def test_guard_passes_on_the_benchmark_topologies(gpu):

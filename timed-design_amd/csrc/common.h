@@ -43,6 +43,7 @@ struct ThKnobs {
     int lanes = 1, lane_lag = 1;   // TH_LANES, TH_LANE_LAG
     int guard = 1;             // TH_GUARD: load-time check of the fast plans against the direct fp32 plan (0: off)
     int first_wino = 1;        // TH_FIRST_WINO=0: k_conv_first instead of k_conv_first_w
+    int first_split = 1;       // TH_FIRST_SPLIT: the aposteriori first layer on bf16 MFMA with exactly split operands (conv_first_b3.hip)
     int first_zb = 0;          // TH_FIRST_ZB: brick depth of the first-layer kernel (tuning)
     int first_dbg = 0;         // TH_FIRST_DBG: timing knock-outs (results wrong)
     int no_pool_first = 0;     // TH_NO_POOL_FIRST: act / BN before the max-pool even when the chain is monotone
@@ -226,6 +227,14 @@ void conv_first_pack_weights(int Cin, int Cout, const float* w_keras, float* dst
 void conv_first_w_pack_weights(int Cin, int Cout, const float* w_keras, float* dst);    // plans with first_wino set
 int launch_conv_first(hipStream_t s, int64_t n, const ConvMfmaPlan& p, const void* frames, int dtype, int Din, int Hin,
                       int Win, int Cin, TView out, ConvGeom g, int Cout, const float* wpk, const float* bias, PostOps post);
+// the same layer on the bf16 pipe with split operands (conv_first_b3.hip): 21^3 x (5..6) frames, 'same', max-pool before a monotone chain
+bool conv_first_b3_ok(const ConvMfmaPlan& p, int Din, int Hin, int Win, int Cin, int Cout, const ConvGeom& g, const PostOps& post);
+size_t conv_first_b3_wpk_floats();
+double conv_first_b3_exec_flops();
+std::string conv_first_b3_label(int nnb);
+void conv_first_b3_pack_weights(int Cin, int Cout, const float* w_keras, float* dst);
+int launch_conv_first_b3(hipStream_t s, int64_t n, const ConvMfmaPlan& p, const void* frames, int dtype, int Cin, TView out, int Cout,
+                         const float* wpk, const float* bias, PostOps post);
 
 // ---- pointwise (1x1x1) streaming convolution (conv_pointwise.hip); plan.cfg in [300, 309) ----
 bool conv_pw_plan(const TView& in, const TView& out_conv, const ConvGeom& g, int Cin, int Cout, int pool, ConvMfmaPlan* plan);

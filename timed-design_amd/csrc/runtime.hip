@@ -60,6 +60,7 @@ void th_knobs_read(ThKnobs* k) {
     num("TH_LANE_LAG", &k->lane_lag, 0, 1 << 20);
     num("TH_GUARD", &k->guard, 0, 2);
     num("TH_FIRST_WINO", &k->first_wino, 0, 1);
+    num("TH_FIRST_SPLIT", &k->first_split, 0, 1);
     num("TH_FIRST_ZB", &k->first_zb, 0, 1 << 20);
     num("TH_FIRST_DBG", &k->first_dbg, 0, 1 << 20);
     flag("TH_NO_POOL_FIRST", &k->no_pool_first);
@@ -963,9 +964,13 @@ int plan(th_model* m) {
                             st.flops = mp.own_flops;
                         }
                         st.exec_flops = mp.exec_flops;
-                        st.label = n.name + ": " + (N[dst].blk ? label_note(conv_first_label(mp, Cin, po), " (output chunk-blocked)") : conv_first_label(mp, Cin, po));
-                        if (mp.nnb > 1) st.label = label_note(st.label, (" x" + std::to_string(mp.nnb) + " passes of 32 columns").c_str());
                         const int iD = sn.D, iH = sn.H, iW = sn.W;
+                        // the aposteriori case (21^3 frames, pool before a monotone chain) runs on the bf16 pipe with split operands
+                        const bool b3 = conv_first_b3_ok(mp, iD, iH, iW, Cin, std::min(Cout, 32), g, po);
+                        const std::string flabel = b3 ? conv_first_b3_label(mp.nnb) : conv_first_label(mp, Cin, po);
+                        if (b3) st.exec_flops = conv_first_b3_exec_flops() * mp.nnb;
+                        st.label = n.name + ": " + (N[dst].blk ? label_note(flabel, " (output chunk-blocked)") : flabel);
+                        if (mp.nnb > 1) st.label = label_note(st.label, (" x" + std::to_string(mp.nnb) + " passes of 32 columns").c_str());
                         // one launch per block of 32 output channels: its own weight columns, bias and per-channel epilogue vectors
                         struct Pass { int c0, cn; float* dw; const float* bias; PostOps po; };
                         std::vector<Pass> passes;
@@ -973,9 +978,10 @@ int plan(th_model* m) {
                         for (int c0 = 0; c0 < Cout; c0 += 32) {
                             Pass ps;
                             ps.c0 = c0; ps.cn = std::min(32, Cout - c0);
-                            std::vector<float> wcol(ktaps * ps.cn), packed(mp.wpk_floats);
+                            std::vector<float> wcol(ktaps * ps.cn), packed(b3 ? conv_first_b3_wpk_floats() : mp.wpk_floats);
                             for (size_t r = 0; r < ktaps; ++r) std::memcpy(&wcol[r * ps.cn], hw + r * Cout + c0, (size_t)ps.cn * sizeof(float));
-                            if (mp.first_wino) conv_first_w_pack_weights(Cin, ps.cn, wcol.data(), packed.data());
+                            if (b3) conv_first_b3_pack_weights(Cin, ps.cn, wcol.data(), packed.data());
+                            else if (mp.first_wino) conv_first_w_pack_weights(Cin, ps.cn, wcol.data(), packed.data());
                             else conv_first_pack_weights(Cin, ps.cn, wcol.data(), packed.data());
                             if ((rc = upload(M, packed.data(), packed.size(), &ps.dw))) return rc;
                             ps.bias = dbias ? dbias + c0 : nullptr;
@@ -990,7 +996,8 @@ int plan(th_model* m) {
                             for (const Pass& ps : passes) {
                                 TView ov = M->view(dst);
                                 if (passes.size() > 1) { ov.coff += ps.c0; ov.C = ps.cn; }
-                                const int r = launch_conv_first(s, cnt, mp, M->cur_in, M->cur_dtype, iD, iH, iW, Cin, ov, g, ps.cn, ps.dw, ps.bias, ps.po);
+                                const int r = b3 ? launch_conv_first_b3(s, cnt, mp, M->cur_in, M->cur_dtype, Cin, ov, ps.cn, ps.dw, ps.bias, ps.po)
+                                                 : launch_conv_first(s, cnt, mp, M->cur_in, M->cur_dtype, iD, iH, iW, Cin, ov, g, ps.cn, ps.dw, ps.bias, ps.po);
                                 if (r) return r;
                             }
                             return (int)TH_OK;
@@ -1084,7 +1091,8 @@ int plan(th_model* m) {
                     const Node& sn = N[src];
                     const ConvGeom g = geom_of(n, sn);
                     const bool k333 = g.kd == 3 && g.kh == 3 && g.kw == 3 && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.dd == 1 && g.dh == 1 && g.dw == 1;
-                    const bool fast = st.label.find("conv_wf<") != std::string::npos || st.label.find("conv_first_w<") != std::string::npos;
+                    const bool fast = st.label.find("conv_wf<") != std::string::npos || st.label.find("conv_first_w<") != std::string::npos ||
+                                      st.label.find("conv_first_b3<") != std::string::npos;
                     if (k333 && !fast) {
                         std::string why;
                         const bool same = g.pz == 1 && g.py == 1 && g.px == 1;
@@ -1434,19 +1442,27 @@ constexpr double kGuardTol = 1e-5;
 bool has_fast_steps(const th_model* m) {
     for (const Step& s : m->steps)
         if (s.label.find("conv_wino") != std::string::npos || s.label.find("conv_wf<") != std::string::npos ||
-            s.label.find("k_conv_first_w") != std::string::npos)
+            s.label.find("k_conv_first_w") != std::string::npos || s.label.find("k_conv_first_b3") != std::string::npos)
             return true;
     return false;
 }
 
-// sparse frames in [0, 1] (about one voxel-channel in twelve non-zero, like Gaussian-splat frames), any shape, deterministic
+// deterministic frames of any shape: the first half sparse in [0, 1] (about one voxel-channel in five non-zero, like
+// Gaussian-splat frames), the rest with BOTH signs — one dense in [-1, 1], the others sparse in [-4, 4].  (The all-positive
+// set alone let a broken operand of the split first layer through — a constant the hardware expanded with the wrong half —
+// which only showed on negative inputs: tests/test_gpu_conv_sweep.py caught it, the guard did not.)
 void guard_frames(std::vector<float>* out, size_t count) {
     out->assign(count, 0.f);
     uint64_t st = 0x9e3779b97f4a7c15ull;
+    const size_t per = std::max<size_t>(1, count / kGuardFrames);
     for (size_t i = 0; i < count; ++i) {
         st = st * 6364136223846793005ull + 1442695040888963407ull;
         const uint32_t r = (uint32_t)(st >> 33);
-        if ((r & 15u) < 3u) (*out)[i] = (float)((r >> 8) & 0xffffu) / 65535.f;     // ~19 % non-zero; smooth neighbours are not needed
+        const float u = (float)((r >> 8) & 0xffffu) / 65535.f;
+        const size_t frame = i / per;
+        if (frame < (size_t)kGuardFrames / 2) { if ((r & 15u) < 3u) (*out)[i] = u; }
+        else if (frame == (size_t)kGuardFrames / 2) (*out)[i] = 2.f * u - 1.f;
+        else if ((r & 15u) < 3u) (*out)[i] = 8.f * u - 4.f;
     }
 }
 
@@ -1509,7 +1525,7 @@ int guard_check(std::unique_ptr<th_model>* mp, std::function<th_model*(const ThK
     if (m->nodes[m->output_node].C > 4096 || (m->logits_node >= 0 && m->nodes[m->logits_node].C > 4096)) return done(TH_OK);
     HIP_TRY(hipMemcpy(d_frames, hf.data(), hf.size() * sizeof(float), hipMemcpyHostToDevice));
     ThKnobs direct = m->knobs;
-    direct.guard = 0; direct.wino_split = 0; direct.winograd = 0; direct.wfused = 0; direct.first_wino = 0;
+    direct.guard = 0; direct.wino_split = 0; direct.first_split = 0; direct.winograd = 0; direct.wfused = 0; direct.first_wino = 0;
     int lrc = TH_OK;
     const auto t0 = std::chrono::steady_clock::now();
     std::unique_ptr<th_model, void (*)(th_model*)> ref(reload(direct, &lrc), th_model_free);
@@ -1549,10 +1565,10 @@ int guard_check(std::unique_ptr<th_model>* mp, std::function<th_model*(const ThK
     hist = note;
     ThKnobs k = m->knobs;
     k.guard = 0;
-    const char* names[4] = {"TH_WINO_SPLIT=0", "TH_WINOGRAD=0", "TH_WFUSED=0", "TH_FIRST_WINO=0"};
+    const char* names[5] = {"TH_WINO_SPLIT=0", "TH_FIRST_SPLIT=0", "TH_WINOGRAD=0", "TH_WFUSED=0", "TH_FIRST_WINO=0"};
     std::string dropped;
-    for (int stage = 0; stage < 4; ++stage) {
-        int* field = stage == 0 ? &k.wino_split : stage == 1 ? &k.winograd : stage == 2 ? &k.wfused : &k.first_wino;
+    for (int stage = 0; stage < 5; ++stage) {
+        int* field = stage == 0 ? &k.wino_split : stage == 1 ? &k.first_split : stage == 2 ? &k.winograd : stage == 3 ? &k.wfused : &k.first_wino;
         if (*field == 0) continue;
         *field = 0;
         dropped += (dropped.empty() ? "" : " ");
@@ -1563,7 +1579,7 @@ int guard_check(std::unique_ptr<th_model>* mp, std::function<th_model*(const ThK
         if ((rc = diff_of(alt.get(), &da))) { th_model_free(alt.release()); return done(rc); }
         snprintf(note, sizeof note, "; %s %.3g", names[stage], da);
         hist += note;
-        if (da <= bound || stage == 3) {
+        if (da <= bound || stage == 4) {
             alt->knobs.guard = m->knobs.guard;
             alt->guard_state = 2; alt->guard_dlogit = da; alt->guard_scale = scale;
             alt->guard_ref_load_ms = m->guard_ref_load_ms; alt->guard_run_ms = m->guard_run_ms;
