@@ -19,7 +19,7 @@
 //     as one ds_read_b128 per fragment (12 per k-step);
 //   * that leaves room for ONE workgroup per CU, so the bricks of k_conv_first_w (whose ragged last round and staging the
 //     second workgroup used to cover) are replaced by a persistent workgroup of 8 waves that streams whole frames through a RING
-//     of 8 input planes (22 x 22 voxels x 6 floats, zero halo included): a frame is 125 tiles = 16 rounds of 8 (the last one
+//     of 8 input planes (22 x 22 voxels x 6 floats, zero halo included; bank-spread layout below): a frame is 125 tiles = 16 rounds of 8 (the last one
 //     of 5), round r needs planes 2 pz - 1 .. 2 pz + 2 of at most two pooled planes pz (<= 6 planes), the next two planes
 //     are requested from HBM when the round starts and written to their ring slots when it ends — one barrier per round, no
 //     halo plane is staged twice, frame boundaries included (the next frame's first planes arrive during the last two rounds).
@@ -42,9 +42,20 @@ namespace {
 constexpr int kFD = 21;                       // frame extent (aposteriori frames)
 constexpr int kPW = 22;                       // staged plane: 22 x 22 voxels (x_in, y_in = -1 .. 20)
 constexpr int kPlaneVox = kPW * kPW;          // 484
-constexpr int kRec = 6;                       // floats per voxel record: [c0 c2 | c1 c3 | c4 | c5]
-constexpr int kPlaneFloats = kPlaneVox * kRec;
+// A staged plane is TWO images, laid out so that the 32 lanes of a half wave (8 consecutive pooled voxels x their 4 (dz, dy)
+// mates, one lane half = one channel parity) spread over all 32 LDS banks:
+//   pairs   [row 22][x 23][c0 c2 | c1 c3]   4 words per voxel: a lane half reads (s0, s1) as one ds_read_b64; rows of 23 voxels
+//           (92 words = 28 mod 32) and 2 words behind the plane (2026 = 10 mod 32): the lanes' word addresses are
+//           8 px + 28 my + 10 mz (+ 2 h): every even residue twice per half wave = the two cycles a b64 half wave needs anyway
+//   singles [row 22][x 23][c4 | c5]         2 words per voxel (s2): 4 px + 14 my + 21 mz — all 32 residues different
+// (With one 24-byte record per voxel — [c0 c2 | c1 c3 | c4 | c5] — the same reads hit 16 banks: SQ_LDS_BANK_CONFLICT was 61 %
+// of the LDS-active cycles and the LDS was busy 49 % of the kernel.)
+constexpr int kRowVox = 23;
+constexpr int kPairWords = kPW * kRowVox * 4 + 2;     // 2026
+constexpr int kSingleWords = kPW * kRowVox * 2 + 1;   // 1013
+constexpr int kPlaneFloats = kPairWords + kSingleWords;
 constexpr int kRing = 8;
+constexpr int kSingleBase = kRing * kPairWords;       // the singles images start behind the 8 pair images
 constexpr int kPlanesPerFrame = 22;           // c = 0: the zero plane z_in = -1; c = 1 .. 21: z_in = c - 1
 constexpr int kTiles = 125;                   // 1000 pooled voxels x 4 (dz, dy) mates / 32 rows
 constexpr int kRounds = 16;
@@ -126,7 +137,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_first_b3(const ConvFirstB3Args 
         const int vox = v - spl[u] * kPlaneVox;
         const int y = vox / kPW, x = vox - y * kPW;
         const int yi = y - 1, xi = x - 1;
-        sloc[u] = v < 2 * kPlaneVox ? vox * kRec : -1;
+        sloc[u] = v < 2 * kPlaneVox ? y * kRowVox + x : -1;          // voxel index inside the padded plane
         sgo[u] = (v < 2 * kPlaneVox && yi >= 0 && yi < kFD && xi >= 0 && xi < kFD) ? (yi * kFD + xi) * a.Cin : -1;
     }
     const int plane_elems = kFD * kFD * a.Cin;
@@ -140,7 +151,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_first_b3(const ConvFirstB3Args 
             const int gp = S + pl;
             const int k = gp / kPlanesPerFrame, c = gp - k * kPlanesPerFrame;
             preal[pl] = gp < S2 && c >= 1 && !(DBG & 4);
-            pslot[pl] = gp < S2 ? (gp & (kRing - 1)) * kPlaneFloats : -1;
+            pslot[pl] = gp < S2 ? (gp & (kRing - 1)) : -1;
             pbase[pl] = (blockIdx.x + (int64_t)k * G) * frame_elems + (int64_t)(c - 1) * plane_elems;
         }
 #pragma unroll
@@ -148,7 +159,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_first_b3(const ConvFirstB3Args 
 #pragma unroll
             for (int c = 0; c < 6; ++c) e[u][c] = 0.f;
             const int slot = spl[u] ? pslot[1] : pslot[0];
-            sdst[u] = (slot >= 0 && sloc[u] >= 0) ? slot + sloc[u] : -1;
+            sdst[u] = (slot >= 0 && sloc[u] >= 0) ? slot * (1 << 16) + sloc[u] : -1;      // (ring slot, voxel)
             if ((spl[u] ? preal[1] : preal[0]) && sgo[u] >= 0) {
                 const int64_t base = (spl[u] ? pbase[1] : pbase[0]) + sgo[u];
                 if (fast6) {
@@ -167,10 +178,13 @@ __global__ void __launch_bounds__(512, 1) k_conv_first_b3(const ConvFirstB3Args 
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             if (sdst[u] < 0) continue;
-            float* rec = A + sdst[u];
+            const int slot = sdst[u] >> 16, vox = sdst[u] & 0xffff;
+            float* rec = A + slot * kPairWords + vox * 4;
             *reinterpret_cast<float2*>(rec) = make_float2(e[u][0], e[u][2]);
             *reinterpret_cast<float2*>(rec + 2) = make_float2(e[u][1], e[u][3]);
-            *reinterpret_cast<float2*>(rec + 4) = make_float2(e[u][4], e[u][5]);
+            float* sg = A + kSingleBase + slot * kSingleWords + vox * 2;
+            sg[0] = e[u][4];
+            sg[1] = e[u][5];
         }
     };
 
@@ -247,17 +261,19 @@ __global__ void __launch_bounds__(512, 1) k_conv_first_b3(const ConvFirstB3Args 
                 const int pq = 8 * t + (j >> 2), mate = j & 3;
                 const int pz = pq / 100, rem = pq - 100 * pz, py = rem / 10, px = rem - 10 * py;
                 const int z = 2 * pz + (mate >> 1), y = 2 * py + (mate & 1);
-                int pa[3];                                             // float index of d0 at (dz, dy = 0), this half's pair slot
+                int pa[3], sa[3];                                      // word index of d0 at (dz, dy = 0): this half's pair / single
 #pragma unroll
-                for (int dz = 0; dz < 3; ++dz)
-                    pa[dz] = ((kPlanesPerFrame * k + z + dz) & (kRing - 1)) * kPlaneFloats + (y * kPW + 2 * px) * kRec + 2 * h;
-                const int sdelta = 4 - h;                              // from the pair slot (2 h) to the single (4 + h)
+                for (int dz = 0; dz < 3; ++dz) {
+                    const int slot = (kPlanesPerFrame * k + z + dz) & (kRing - 1);
+                    pa[dz] = slot * kPairWords + (y * kRowVox + 2 * px) * 4 + 2 * h;
+                    sa[dz] = kSingleBase + slot * kSingleWords + (y * kRowVox + 2 * px) * 2 + h;
+                }
                 auto rdP = [&](int t9, v2f (&d)[4]) {
                     const int dz = t9 / 3, dy = t9 % 3;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         if (DBG & 256) { d[i] = (v2f){__builtin_bit_cast(float, pa[dz] + t9), (float)i}; continue; }
-                        d[i] = *reinterpret_cast<const v2f*>(A + pa[dz] + (dy * kPW + i) * kRec);
+                        d[i] = *reinterpret_cast<const v2f*>(A + pa[dz] + (dy * kRowVox + i) * 4);
                     }
                 };
                 auto rdS = [&](int t9, float (&d)[4]) {
@@ -265,7 +281,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_first_b3(const ConvFirstB3Args 
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         if (DBG & 256) { d[i] = __builtin_bit_cast(float, pa[dz] + t9 + i); continue; }
-                        d[i] = A[pa[dz] + sdelta + (dy * kPW + i) * kRec];
+                        d[i] = A[sa[dz] + (dy * kRowVox + i) * 2];
                     }
                 };
                 auto join = [&](const float (&sa)[4], const float (&sb)[4], v2f (&d)[4]) {
