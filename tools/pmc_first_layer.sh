@@ -1,3 +1,5 @@
+# SQ / LDS counters of the first-layer kernel (three rocprofv3 --pmc passes over tools/plan_report.py --measure timed), raw per-kernel averages:
+#   gpurun -- 'bash tools/pmc_first_layer.sh'   -> gpurun_out/pmc_first/*.log and the table on stdout
 set -u
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/pmc_first; mkdir -p $OUT; export TMPDIR=/tmp
 CMD="python $ROOT/tools/plan_report.py --measure timed"
