@@ -285,9 +285,9 @@ def main():
                        "rows_verified": n,
                        "algo_mflop_per_frame": cost["algo_flops"] / 1e6, "kernel_mflop_per_frame": kernel_flops / 1e6,
                        "exec_mflop_per_frame": cost["exec_flops"] / 1e6, "winograd_layers": sum("k_wino_gemm" in s["label"] for s in model.steps()),
-                       "split_gemm_layers": sum("bf16x3" in s["label"] for s in model.steps()),
-                       "arithmetic": "fp32-input MFMA; Winograd GEMMs: operands split exactly into 3 bf16 pieces, 6 products on bf16 MFMA, "
-                                     "fp32 accumulate (tests hold the same 5e-6 bound)",
+                       "split_gemm_layers": sum("bf16x3" in s["label"] for s in model.steps()),      # (steps, the first layer included)
+                       "arithmetic": "fp32-input MFMA; first layer and 5^3 Winograd GEMMs: operands split exactly into 3 bf16 pieces, "
+                                     "6 products on bf16 MFMA, fp32 accumulate (tests hold the same 5e-6 bound)",
                        "knobs": model.knobs(), "guard": {k: (round(v, 9) if isinstance(v, float) else v) for k, v in model.guard().items() if k != "note"},
                        "device": f"{model.device_arch} {model.device_cus} CUs"},
             # FLOPs the kernels really compute per frame (the SURVEY §8d direct-form count, except that layers on the Cook-Toom /
@@ -358,9 +358,10 @@ def main():
             base = None if args.no_cpu_baseline else (lambda c, w, t: cpu_baseline(c, w, t, budget_s=8.0, min_s=5.0))
             line["other_configs"] = [bench_legs.topology_rate(t, device, d_frames.ptr, min(n, args.other_frames), args.chunk,
                                                               traffic=pmc.get(t), cpu_baseline=base) for t in others]
-            # the same plans with the Winograd GEMMs on the fp32-input matrix pipe (TH_WINO_SPLIT=0: exact fp32 products instead of
-            # the bf16x3 split): same frames, the rate and the logits against the default plan's
-            line["other_configs"] += [bench_legs.topology_rate(t, device, d_frames.ptr, min(n, args.other_frames), args.chunk, env={"TH_WINO_SPLIT": "0"})
+            # the same plans with every layer on the fp32-input matrix pipe (TH_WINO_SPLIT=0 TH_FIRST_SPLIT=0: exact fp32 products instead
+            # of the bf16x3 split): same frames, the rate and the logits against the default plan's
+            line["other_configs"] += [bench_legs.topology_rate(t, device, d_frames.ptr, min(n, args.other_frames), args.chunk,
+                                                               env={"TH_WINO_SPLIT": "0", "TH_FIRST_SPLIT": "0"})
                                       for t in (args.topology, "timed_rotamer") if t in ("timed", "timed_rotamer")]
             line["extras_wall_s"] = time.perf_counter() - t_legs
         # the full record (per-kernel tables of every topology, all e2e/sampler legs) goes to a side file and stderr;

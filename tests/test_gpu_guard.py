@@ -66,7 +66,7 @@ def test_forced_trip_falls_back_to_the_direct_plan_and_keeps_parity(gpu, cnn_gol
     model = engine.HipFrameModel.from_keras(cfg, weights, device=gpu)
     g = model.guard()
     assert g["state"] == 2, g
-    for key in ("TH_WINO_SPLIT=0", "TH_WINOGRAD=0", "TH_WFUSED=0", "TH_FIRST_WINO=0"):
+    for key in ("TH_WINO_SPLIT=0", "TH_FIRST_SPLIT=0", "TH_WINOGRAD=0", "TH_WFUSED=0", "TH_FIRST_WINO=0"):
         assert key in g["note"], g
     assert "guard:" in model.knobs()
     assert not _fast(_labels(model)), _labels(model)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Raw per-kernel averages of every counter in rocprofv3 rocpd .db files: python tools/pmc_raw.py [--match text] a.db b.db ..."""
-import collections, sqlite3, sys
+import collections, re, sqlite3, sys
 args = sys.argv[1:]
 match = ""
 if args and args[0] == "--match":
@@ -15,9 +15,10 @@ for db in args:
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for ev, name, st, en, wgs in disp:
         if match and match not in name: continue
-        key = (name.split("(")[0][-60:], wgs)
+        mm = re.search(r"k_[a-z0-9_]+(<[^>]*>)?", name)
+        key = (mm.group(0) if mm else name[:40], wgs)
         for k, v in vals[ev].items(): agg[key][k].append(v)
         agg[key]["dur_us"].append((en - st) / 1e3)
-    for key, d in sorted(agg.items(), key=lambda kv: -sum(kv[1]["dur_us"]))[:6]:
+    for key, d in sorted(agg.items(), key=lambda kv: -sum(kv[1]["dur_us"]))[:8]:
         m = {k: sum(v) / len(v) for k, v in d.items()}
         print(key, " ".join("%s=%.4g" % kv for kv in sorted(m.items())))
