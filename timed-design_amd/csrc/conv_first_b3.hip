@@ -325,6 +325,9 @@ __global__ void __launch_bounds__(512, 1) k_conv_first_b3(const ConvFirstB3Args 
                 bf16x8 PB[2][3];
                 v2f D[2][4][4];
                 auto prep = [&](int p, const v2f (&d)[4][4], int buf) {
+                    // (two-float subtractions: hipcc emits v_pk_add_f32 for a third of them and two scalar adds for the rest; forcing the
+                    // packed form everywhere — inline asm — is SLOWER, 1.91 against 1.79 ms: a packed fp32 add is evidently not cheaper
+                    // than two scalar ones here.)
                     // (x - piece through v_dot2c_f32_bf16 — x + piece.lo * (-1) + piece.hi * 0, one instruction per value instead of
                     // shift / mask / subtract — is exact too and 25 % fewer VALU instructions, but measured SLOWER next to the MFMAs
                     // (2.10 against 1.96 ms): the DOT unit is not independent of the matrix pipe.  Two traps on the way, kept here:
