@@ -391,3 +391,32 @@ def test_first_layer_on_the_bf16_pipe_with_split_operands(gpu, monkeypatch, cin,
     ref = m.predict(frames)
     m.close()
     np.testing.assert_allclose(got, ref, rtol=0, atol=4e-6 * scale)
+
+
+def test_split_first_layer_over_twenty_decades_of_input_magnitude(gpu, monkeypatch):
+    """x = h + m + l with bf16 pieces is exact over the whole fp32 exponent range (bf16 has fp32's exponent): frames whose voxels
+    span 1e-14 .. 1e6 (per-frame scale, both signs, a third of the voxels exactly zero) through k_conv_first_b3 agree with the
+    fp32-input kernel to 4e-6 of each FRAME's own output scale — an absolute bound on the whole batch would hide the small frames."""
+    def build(b, x):
+        return b.maxpool(b.batchnorm(b.elu(b.conv3d(x, 32, 3, padding="same"))), 2)
+
+    shape = (21, 21, 21)
+    cfg, weights = _net(shape, 6, build, seed=5, bias_std=0.0)      # no bias: the output scales with the input
+    rng = np.random.default_rng(11)
+    scales = np.array([1e-14, 1e-9, 1e-4, 1.0, 3e2, 1e6], dtype=np.float64)
+    frames = rng.standard_normal((len(scales), *shape, 6)) * (rng.random((len(scales), *shape, 6)) < 0.66)
+    frames = (frames * scales[:, None, None, None, None]).astype(np.float32)
+    m = engine.HipFrameModel.from_keras(cfg, weights)
+    assert any("k_conv_first_b3" in s["label"] for s in m.steps())
+    got = m.predict(frames)
+    m.close()
+    monkeypatch.setenv("TH_FIRST_SPLIT", "0")
+    m = engine.HipFrameModel.from_keras(cfg, weights)
+    ref = m.predict(frames)
+    m.close()
+    want = cnn_oracle.forward(cfg, weights, frames, np.float32)
+    for i in range(len(scales)):
+        # ELU -> BatchNorm of a zero-bias convolution: subtract the frame-independent offset f(0) before scaling
+        s = max(float(np.abs(want[i] - want[i].mean()).max()), 1e-30)
+        assert float(np.abs(got[i] - ref[i]).max()) <= 4e-6 * max(s, float(np.abs(want[i]).max()) * 1e-3), (i, scales[i])
+        assert float(np.abs(got[i] - want[i]).max()) <= 2e-5 * max(s, float(np.abs(want[i]).max()) * 1e-3), (i, scales[i])
