@@ -7,22 +7,25 @@
 // V2 = d2 - d1, V3 = d1 - d3 per (dz, dy) tap and channel, out(2 tx) = M0 + M1 + M2, out(2 tx + 1) = M1 - M2 - M3 — but the
 // products run as v_mfma_f32_32x32x16_bf16 on operands split exactly into three bf16 pieces (x = h + m + l, round to nearest
 // even at every step; six of the nine piece products, fp32 accumulation: the scheme of conv_wino.hip's k_wino_gemm_b3, error of
-// one fp32 rounding).  Per point the 54 products of a row (9 taps x 6 channels) fill 4 k-steps of 16 (a lane half holds the 27
-// values of its three channels 2 s + h in 32 slots), 96 MFMAs of 32 cycles per tile of 32 pairs where the fp32 form issues 108
-// of 64: 2.25x fewer matrix-pipe cycles.
+// one fp32 rounding).  A lane half holds the three channels 2 s + h: taps 0..7 fill 3 k-steps of 16 without a padding slot (72
+// MFMAs of 32 cycles per tile of 32 pairs), tap 8 runs as 3 v_mfma_f32_32x32x2_f32 per point (table below): 3072 matrix-pipe
+// cycles per tile where the fp32 form needs 6912 (108 MFMAs of 64).
 //
 // What changes around it:
 //   * the data points are split IN REGISTERS right after the transform (9 VALU instructions per pair of values: three
-//     v_cvt_pk_bf16_f32, four shifts / masks, two packed subtractions) — ~160 per k-step and lane against 24 MFMAs (768
-//     cycles); a wave alternates between a VALU phase and an MFMA phase and the two waves of a SIMD interleave them;
-//   * the split weights (4 points x 4 k-steps x 3 pieces x 1 KB = 48 KB) do not fit the register file: they live in LDS, read
-//     as one ds_read_b128 per fragment (12 per k-step);
+//     v_cvt_pk_bf16_f32, four shifts / masks, two subtractions) — 36 + 4 per (k-step, point) unit and lane against its 6 MFMAs.
+//     THE VALU IS WHAT BOUNDS THIS KERNEL (~855 instructions per tile and lane at ~4.1 cycles with two waves per SIMD, every
+//     MFMA issued costs ~10 cycles of the same port: tools/microbench/mfma_valu_coissue.hip); every unit is
+//     a window in which the wave multiplies one unit and prepares the next;
+//   * the split weights (4 points x 3 k-steps x 3 pieces x 1 KB = 36 KB) do not fit the register file: they live in LDS, read
+//     as one ds_read_b128 per fragment (3 per unit);
 //   * that leaves room for ONE workgroup per CU, so the bricks of k_conv_first_w (whose ragged last round and staging the
 //     second workgroup used to cover) are replaced by a persistent workgroup of 8 waves that streams whole frames through a RING
-//     of 8 input planes (22 x 22 voxels x 6 floats, zero halo included; bank-spread layout below): a frame is 125 tiles = 16 rounds of 8 (the last one
-//     of 5), round r needs planes 2 pz - 1 .. 2 pz + 2 of at most two pooled planes pz (<= 6 planes), the next two planes
-//     are requested from HBM when the round starts and written to their ring slots when it ends — one barrier per round, no
-//     halo plane is staged twice, frame boundaries included (the next frame's first planes arrive during the last two rounds).
+//     of 8 input planes (22 x 22 voxels x 6 floats, zero halo included; bank-spread layout below): a frame is 125 tiles = 16
+//     rounds of 8 (the last one of 5), round r needs planes 2 pz - 1 .. 2 pz + 2 of at most two pooled planes pz (<= 6 planes),
+//     the next two planes are requested from HBM when the round starts and written to their ring slots when it ends — one
+//     barrier per round, no halo plane is staged twice, frame boundaries included (the next frame's first planes arrive during
+//     the last two rounds).
 #include "common.h"
 #include "device_math.h"
 
@@ -65,7 +68,7 @@ constexpr size_t kB3Lds = (size_t)kRing * kPlaneFloats * 4 + (size_t)kB3WFrag * 
 
 struct ConvFirstB3Args {
     const void* in; int dtype; int Cin; int vec8;
-    const uint4* wpk;                 // [point 4][k-step 4][piece 3][lane 64] x 8 bf16
+    const uint4* wpk;                 // [point 4][k-step 3][piece 3][lane 64] x 8 bf16, then tap 8 as fp32 [point 4][step 3][lane 64]
     int Cout;
     const float* bias;
     PostOps post;
