@@ -22,8 +22,8 @@ vals = cnn_oracle.forward(cfg, w, frames, np.float64, return_all=True)
 layers = cfg["config"]["layers"]; out = cfg["config"]["output_layers"][0][0]
 last = next(l for l in layers if l["name"] == out)
 want = vals[last["inbound_nodes"][0][0][0]]
-outs = {"default": run({}), "first fp32": run({"TH_FIRST_SPLIT": "0"}), "all fp32 (Winograd)": run({"TH_FIRST_SPLIT": "0", "TH_WINO_SPLIT": "0"}),
+outs = {"opt-in 7-point scheme (TH_WINOGRAD=2)": run({"TH_WINOGRAD": "2"}), "default": run({}), "first fp32": run({"TH_FIRST_SPLIT": "0"}), "all fp32 (Winograd)": run({"TH_FIRST_SPLIT": "0", "TH_WINO_SPLIT": "0"}),
         "direct": run({"TH_FIRST_SPLIT": "0", "TH_WINO_SPLIT": "0", "TH_WINOGRAD": "0", "TH_WFUSED": "0", "TH_FIRST_WINO": "0"})}
 ref = want if want is not None else outs["direct"].astype(np.float64)
 for k, v in outs.items():
-    print("%-22s max |dlogit| vs %s %.3g  (scale %.3g)" % (k, "float64 oracle" if want is not None else "direct plan", float(np.abs(v - ref).max()), float(np.abs(ref).max())))
+    print("%-42s max |dlogit| vs %s %.3g  (scale %.3g)" % (k, "float64 oracle" if want is not None else "direct plan", float(np.abs(v - ref).max()), float(np.abs(ref).max())))
