@@ -131,6 +131,9 @@ def main():
     ap.add_argument("--frames", type=int, default=100_000, help="frames per GPU per step (BASELINE config: 100k)")
     ap.add_argument("--topology", default="timed", choices=["timed", "timed_rotamer", "densecpd", "prodconn"])
     ap.add_argument("--chunk", type=int, default=4096, help="frames per launch (activation arenas are sized for this many frames)")
+    ap.add_argument("--allow-host-exchange", action="store_true",
+                    help="development only: ranks that SHARE a GPU exchange their rows over TCP instead of RCCL (the line says so); "
+                         "without it a --gpus N run that is not N RCCL ranks with a verified gather exits with an error")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP events (roofline omitted)")
     ap.add_argument("--no-extras", action="store_true", help="skip the e2e / sampler / other-topology legs (N=1 only)")
@@ -198,11 +201,10 @@ def main():
                 d_gather = engine.DeviceBuffer(world * n * model.n_classes * 4, device)
         except RuntimeError as e:
             why = str(e)
-            if ndev >= world:
-                # every rank has its own GPU: RCCL must work here, and a silent host exchange would be measured as if
-                # it were the xGMI gather — refuse
-                sys.exit(f"[bench] rank {rank}: RCCL communicator could not be created although {ndev} devices are "
-                         f"visible for {world} ranks: {why}")
+            if ndev >= world or not args.allow_host_exchange:
+                # a --gpus N line must be N RCCL ranks, one per GPU, with the gather verified: a host exchange measured as if it
+                # were the xGMI gather is refused (ranks sharing a GPU: --allow-host-exchange, development only)
+                sys.exit(f"[bench] rank {rank}: RCCL communicator over {world} ranks could not be created ({ndev} device(s) visible): {why}")
             # ranks share a GPU (fewer devices than ranks): RCCL cannot span them; measure with the exchange done on the
             # host (device->host copy + TCP gather) and say so in the JSON line
             exchange = f"HOST FALLBACK (TCP gather of downloaded rows): {world} ranks on {ndev} device(s): " + why
@@ -265,6 +267,17 @@ def main():
                 sys.exit("[bench] RCCL gather delivered rows that differ from the ranks' own shards")
             # distinct seeds per rank: two blocks holding the same rows would mean a misrouted transfer
             assert not np.array_equal(parts[0], parts[1]), "ranks produced identical shards"
+        # every rank's own count of the RCCL transfers it issued: per step the root posts world - 1 ncclRecv, a peer one ncclSend
+        st = comm.stats()
+        per_rank = rdzv.allgather_ints([st["sends"], st["recvs"]])
+        if rank == 0:
+            calls = args.steps + args.warmup
+            want = [[0, (world - 1) * calls]] + [[calls, 0]] * (world - 1)
+            if per_rank != want:
+                sys.exit(f"[bench] RCCL transfer counts {per_rank} differ from the {want} that {calls} gathers over {world} ranks issue")
+    if world > 1 and rank == 0 and not args.allow_host_exchange and not (comm is not None and gather_verified):
+        sys.exit(f"[bench] --gpus {world}: not {world} RCCL ranks with a verified gather (rccl_ranks={world if comm else 0}, "
+                 f"gather_verified={gather_verified})")
 
     if rank == 0:
         sys.path.insert(0, os.path.join(ROOT, "tools"))

@@ -361,6 +361,10 @@ void th_comm_free(th_comm* c);
 int th_comm_gather_rows(th_comm* c, const float* d_local, const int64_t* counts, int width, int root,
                         float* d_out);
 int th_comm_barrier(th_comm* c);
+/* what this communicator's gathers have issued so far on THIS rank: out = {ncclSend calls, ncclRecv calls, bytes sent, bytes
+ * received, device copies of the root's own block}.  A 1-rank gather issues no RCCL transfer (the root's block is a copy) unless
+ * TH_COMM_SELF_RCCL=1 was set when th_comm_init ran: then that block goes through a grouped ncclSend/ncclRecv pair to self. */
+int th_comm_stats(th_comm* c, int64_t out[5]);
 
 #ifdef __cplusplus
 }

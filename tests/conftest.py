@@ -10,6 +10,11 @@ for p in (ROOT, PKG):
         sys.path.insert(0, p)
 
 
+# the load-time guard keeps its verdicts in a per-user directory (csrc/runtime.hip guard_disk_path); the suite must measure, not
+# remember: no verdict files unless a test points TH_GUARD_CACHE at a directory of its own
+os.environ.setdefault("TH_GUARD_CACHE", "0")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

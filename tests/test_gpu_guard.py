@@ -170,3 +170,50 @@ def test_a_pass_is_remembered_for_the_same_pack_knobs_and_device(gpu):
         c.close()
     finally:
         del os.environ["TH_WINO_SPLIT"]
+
+
+DISK_WORKER = """
+import os, sys
+sys.path.insert(0, os.path.join({root!r}, "timed-design_amd"))
+from timed_hip import engine, synth
+cfg, w = synth.timed_synth(20, seed=998)
+m = engine.HipFrameModel.from_keras(cfg, w, device=0)
+g = m.guard()
+print("GUARD", g["state"], repr(g["max_dlogit"]), repr(g["logit_scale"]), "|", g["note"])
+"""
+
+
+def test_a_pass_is_remembered_across_processes_in_a_verdict_file(gpu, tmp_path):
+    """predict.py loads one model per process: the second PROCESS that loads the same pack under the same knobs, on the same
+    device, with the same build of the library reads the verdict from $TH_GUARD_CACHE instead of building a second plan;
+    other knobs miss; TH_GUARD_CACHE=0 writes nothing; a damaged file is a miss, not an error"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "w.py"
+    script.write_text(DISK_WORKER.format(root=root))
+    cache = tmp_path / "verdicts"
+
+    def run(**env):
+        e = dict(os.environ, TH_GUARD_CACHE=str(cache))
+        e.update(env)
+        r = subprocess.run([sys.executable, str(script)], env=e, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (r.stdout[-800:], r.stderr[-800:])
+        line = [l for l in r.stdout.splitlines() if l.startswith("GUARD")][0]
+        head, note = line.split("|", 1)
+        return head.split()[1:], note
+
+    a, na = run()
+    files = sorted(cache.iterdir())
+    assert a[0] == "1" and "earlier" not in na and len(files) == 1 and files[0].name.startswith("guard-")
+    b, nb = run()
+    assert b == a and "earlier process" in nb and sorted(cache.iterdir()) == files
+    c, nc = run(TH_WINO_SPLIT="0")                                  # other knobs: measured on their own, a second file
+    assert "earlier" not in nc and len(list(cache.iterdir())) == 2
+    files[0].write_text("garbage\n")
+    d, nd = run()
+    assert d == a and "earlier" not in nd                           # damaged: measured again (and rewritten)
+    e, ne = run()
+    assert "earlier process" in ne
+    off = tmp_path / "off"
+    f, nf = run(TH_GUARD_CACHE="0", XDG_CACHE_HOME=str(off))
+    assert "earlier" not in nf and not off.exists()

@@ -12,6 +12,7 @@
 #include "common.h"
 
 #include <dlfcn.h>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -74,6 +75,11 @@ struct th_comm {
     int n_ranks = 0, rank = 0, device = 0;
     hipStream_t stream = nullptr;
     float* d_token = nullptr;
+    // TH_COMM_SELF_RCCL=1 (read once by th_comm_init): the root's own block travels through a grouped ncclSend/ncclRecv
+    // pair to itself instead of a device copy, so that a 1-rank communicator on a 1-GPU box drives the very transfer calls
+    // an N-rank gather issues (tests/test_distributed.py); the product default stays the copy.
+    bool self_rccl = false;
+    int64_t n_send = 0, n_recv = 0, bytes_send = 0, bytes_recv = 0, n_copy = 0;   // th_comm_stats
 };
 
 extern "C" {
@@ -95,6 +101,10 @@ int th_comm_init(const char id[TH_COMM_ID_BYTES], int n_ranks, int rank, int dev
     HIP_TRY(hipSetDevice(device));
     th_comm* c = new th_comm;
     c->n_ranks = n_ranks; c->rank = rank; c->device = device;
+    {
+        const char* e = getenv("TH_COMM_SELF_RCCL");
+        c->self_rccl = e && atoi(e) != 0;
+    }
     NcclUniqueId u;
     std::memcpy(u.internal, id, TH_COMM_ID_BYTES);
     int r = R->CommInitRank(&c->comm, n_ranks, u, rank);
@@ -126,10 +136,14 @@ int th_comm_gather_rows(th_comm* c, const float* d_local, const int64_t* counts,
     if (counts[c->rank] > 0 && !d_local) TH_FAIL(TH_EINVAL, "rank %d has %lld rows but no local buffer", c->rank, (long long)counts[c->rank]);
     int64_t my_row = 0;
     for (int r = 0; r < c->rank; ++r) my_row += counts[r];
-    // the root's own block is a plain device copy: issued before (outside) the RCCL group
-    if (c->rank == root && counts[root] > 0)
+    // the root's own block is a plain device copy: issued before (outside) the RCCL group — so a 1-rank gather issues NO
+    // RCCL transfer at all unless TH_COMM_SELF_RCCL routes that block through a send/recv pair to self inside the group
+    const bool self_pair = c->self_rccl && c->rank == root && counts[root] > 0;
+    if (c->rank == root && counts[root] > 0 && !self_pair) {
         HIP_TRY(hipMemcpyAsync(d_out + (size_t)my_row * width, d_local, (size_t)counts[root] * width * sizeof(float),
                                hipMemcpyDeviceToDevice, c->stream));
+        ++c->n_copy;
+    }
     // Inside the group nothing may return early: an error is remembered, the group is always closed, and the first
     // failure is reported afterwards (an open group would poison every later collective on this thread).
     int first_err = 0;
@@ -139,20 +153,29 @@ int th_comm_gather_rows(th_comm* c, const float* d_local, const int64_t* counts,
     if (c->rank == root) {
         int64_t row = 0;
         for (int r = 0; r < c->n_ranks; ++r) {
-            if (r != root && counts[r] > 0 && !first_err) {
+            if ((r != root || self_pair) && counts[r] > 0 && !first_err) {
                 rc = R->Recv(d_out + (size_t)row * width, (size_t)counts[r] * width, kNcclFloat32, r, c->comm, c->stream);
                 if (rc != 0) { first_err = rc; what = "ncclRecv"; }
+                else { ++c->n_recv; c->bytes_recv += counts[r] * (int64_t)width * 4; }
             }
             row += counts[r];
         }
-    } else if (counts[c->rank] > 0) {
+    }
+    if ((c->rank != root || self_pair) && counts[c->rank] > 0 && !first_err) {
         rc = R->Send(d_local, (size_t)counts[c->rank] * width, kNcclFloat32, root, c->comm, c->stream);
         if (rc != 0) { first_err = rc; what = "ncclSend"; }
+        else { ++c->n_send; c->bytes_send += counts[c->rank] * (int64_t)width * 4; }
     }
     rc = R->GroupEnd();
     if (first_err) { th_set_error("%s failed: %s", what, R->GetErrorString(first_err)); return TH_ECOMM; }
     if (rc != 0) { th_set_error("ncclGroupEnd failed: %s", R->GetErrorString(rc)); return TH_ECOMM; }
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return TH_OK;
+}
+
+int th_comm_stats(th_comm* c, int64_t out[5]) {
+    if (!c || !out) TH_FAIL(TH_EINVAL, "th_comm_stats: bad argument");
+    out[0] = c->n_send; out[1] = c->n_recv; out[2] = c->bytes_send; out[3] = c->bytes_recv; out[4] = c->n_copy;
     return TH_OK;
 }
 

@@ -68,6 +68,7 @@ PROTOTYPES = {
     "th_comm_free": (None, [_vp]),
     "th_comm_gather_rows": (_i, [_vp, _vp, _pi64, _i, _i, _vp]),
     "th_comm_barrier": (_i, [_vp]),
+    "th_comm_stats": (_i, [_vp, _pi64]),
     "th_voxelise": (_i, [_i, _vp, _vp, _vp, _i64, _vp, _i64, _i, C.c_float, _i, _i, _vp, _i]),
     "th_mt19937_rand": (_i, [_vp, _pi, _i64, _vp]),
     "th_mt19937_words": (_i, [_vp, _pi, _i64, _vp]),

@@ -114,6 +114,12 @@ class RcclGather:
     def barrier(self):
         _lib.check(self._lib.th_comm_barrier(self._h))
 
+    def stats(self) -> dict:
+        """What this rank's gathers issued so far: ncclSend / ncclRecv calls and bytes, device copies of the root's own block."""
+        out = (C.c_int64 * 5)()
+        _lib.check(self._lib.th_comm_stats(self._h, out))
+        return dict(sends=out[0], recvs=out[1], bytes_sent=out[2], bytes_received=out[3], root_copies=out[4])
+
     def close(self):
         if self._h:
             self._lib.th_comm_free(self._h)
