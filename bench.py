@@ -301,6 +301,7 @@ def main():
                        "split_gemm_layers": sum("bf16x3" in s["label"] for s in model.steps()),      # (steps, the first layer included)
                        "arithmetic": "fp32-input MFMA; first layer and 5^3 Winograd GEMMs: operands split exactly into 3 bf16 pieces, "
                                      "6 products on bf16 MFMA, fp32 accumulate (tests hold the same 5e-6 bound)",
+                       "emulated_fp32": True,      # fp32 results from bf16-pipe products on exactly split operands (5 of the plan's steps)
                        "knobs": model.knobs(), "guard": {k: (round(v, 9) if isinstance(v, float) else v) for k, v in model.guard().items() if k != "note"},
                        "device": f"{model.device_arch} {model.device_cus} CUs"},
             # FLOPs the kernels really compute per frame (the SURVEY §8d direct-form count, except that layers on the Cook-Toom /

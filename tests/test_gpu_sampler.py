@@ -353,10 +353,23 @@ def test_device_generators_from_the_reference_entry_points(gpu, mode):
     before = np.random.get_state()[1].copy()
     out = su.sample_with_multiprocessing(8, list(p2p), 6, p2p, None, rng=mode, seed=4242)
     assert np.array_equal(np.random.get_state()[1], before)
+    su.reset_device_rng()
+    out = su.sample_with_multiprocessing(8, list(p2p), 6, p2p, None, rng=mode, seed=4242)
+    # a second call with the same seed CONTINUES the (rng, seed) stream — like two calls on the global NumPy generator — and
+    # reset_device_rng() (sample.py's --seed) starts it over
+    second = su.sample_with_multiprocessing(8, ["b"], 2, p2p, None, rng=mode, seed=4242)
+    su.reset_device_rng()
     again = su.sample_with_multiprocessing(8, list(p2p), 6, p2p, None, rng=mode, seed=4242)
     other = su.sample_with_multiprocessing(8, list(p2p), 6, p2p, None, rng=mode, seed=4243)
     assert out == again and out != other
     total = 6 * sum(sizes.values())
+    more = total + 2 * sizes["b"]
+    if mode == "mt19937":
+        tail = so.legacy_uniforms(4242, more)[total:]
+    else:
+        tail = sampler.sample_indices(np.full((more, 2), 0.5), 1, rng="philox", seed=4242, return_uniforms=True)[1].ravel()[total:]
+    want2 = ["".join(np.array(list("ACDEFGHIKLMNPQRSTVWY"))[i]) for i in so.choice_indices(p2p["b"], tail.reshape(2, sizes["b"]))]
+    assert [t[0] for t in second["b"]] == want2
     if mode == "mt19937":
         stream = so.legacy_uniforms(4242, total)
     else:

@@ -40,6 +40,7 @@ struct ThKnobs {
     int winograd = 1;          // TH_WINOGRAD: 0 direct kernels, 1 F(3,3)+F(2,3) in-plane (default), 2 F(5,3) (opt-in)
     int wino_split = 1;        // TH_WINO_SPLIT: Winograd GEMMs on bf16 MFMA with exactly split operands (0: fp32-input MFMA)
     int wfused = 1;            // TH_WFUSED: 10^3 layers on conv_wfused.hip
+    int wf_split = 1;          // TH_WF_SPLIT: eligible conv_wfused layers on bf16 MFMA with exactly split operands (conv_wfsplit.hip)
     int lanes = 1, lane_lag = 1;   // TH_LANES, TH_LANE_LAG
     int guard = 1;             // TH_GUARD: load-time check of the fast plans against the direct fp32 plan (0: off)
     int first_wino = 1;        // TH_FIRST_WINO=0: k_conv_first instead of k_conv_first_w
@@ -218,6 +219,20 @@ std::string conv_wf_label(const ConvWfPlan& p, const PreOp& pre);    // the plan
 void conv_wf_pack_weights(const ConvWfPlan& p, const float* w_keras, float* dst);
 int launch_conv_wf(hipStream_t s, int64_t n, const ConvWfPlan& p, TView in, TView out, const float* wpk, const float* bias, PreOp pre,
                    PostOps post);
+
+// the same layer with its products on bf16 MFMA, both operands split exactly into three bf16 pieces (conv_wfsplit.hip): no input
+// prologue, Cin a multiple of 16, more than 32 output channels
+struct ConvWfsPlan {
+    int geo = -1, pool = 0;
+    int Cin = 0, Cout = 0, nkh = 0, ncp = 0;       // nkh: phases of 16 input channels, ncp: passes of 64 output channels
+    size_t wpk_floats = 0, lds_bytes = 0;
+    double own_flops = 0, exec_flops = 0;
+    const ThKnobs* knobs = nullptr;
+    std::string label;
+};
+bool conv_wfs_plan(const ConvWfPlan& base, const TView& in, const PreOp& pre, ConvWfsPlan* plan);
+void conv_wfs_pack_weights(const ConvWfsPlan& p, const float* w_keras, float* dst);
+int launch_conv_wfs(hipStream_t s, int64_t n, const ConvWfsPlan& p, TView in, TView out, const float* wpk, const float* bias, PostOps post);
 
 // ---- first-layer convolution (conv_first.hip): Cin <= 8, Cout <= 32, 3x3x3, reads the caller's frames ----
 std::string conv_first_label(const ConvMfmaPlan& p, int Cin, const PostOps& post);

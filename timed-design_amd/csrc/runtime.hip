@@ -61,6 +61,7 @@ void th_knobs_read(ThKnobs* k) {
     num("TH_WINOGRAD", &k->winograd, 0, 2);
     num("TH_WINO_SPLIT", &k->wino_split, 0, 1);
     num("TH_WFUSED", &k->wfused, 0, 1);
+    num("TH_WF_SPLIT", &k->wf_split, 0, 1);
     if (const char* e = getenv("TH_LANES")) { k->lanes = atoi(e) == 2 ? 2 : 1; if (k->lanes != 1) note("TH_LANES", e); }
     num("TH_LANE_LAG", &k->lane_lag, 0, 1 << 20);
     num("TH_GUARD", &k->guard, 0, 2);
@@ -949,7 +950,21 @@ int plan(th_model* m) {
                         continue;
                     }
                     ConvWfPlan fp;
-                    if (wf_plan_for(i, &fp)) {
+                    ConvWfsPlan sp;
+                    if (wf_plan_for(i, &fp) && conv_wfs_plan(fp, M->view(src), pre, &sp)) {
+                        // the same algorithm on the bf16 pipe: both operands split exactly into three bf16 pieces (conv_wfsplit.hip)
+                        std::vector<float> packed(sp.wpk_floats);
+                        conv_wfs_pack_weights(sp, hw, packed.data());
+                        float* dw;
+                        if ((rc = upload(M, packed.data(), packed.size(), &dw))) return rc;
+                        st.direct_flops = st.flops;
+                        st.flops = sp.own_flops;
+                        st.exec_flops = sp.exec_flops;
+                        st.label = n.name + ": " + (sn.blk ? label_note(sp.label, " (input chunk-blocked)") : sp.label);
+                        st.run = [=](hipStream_t s, int64_t cnt) {
+                            return launch_conv_wfs(s, cnt, sp, M->view(src), M->view(dst), dw, dbias, po);
+                        };
+                    } else if (wf_plan_for(i, &fp)) {
                         // F(2,3)^2 in-plane with the whole transform domain in LDS: one step, one kernel
                         std::vector<float> packed(fp.wpk_floats);
                         conv_wf_pack_weights(fp, hw, packed.data());
@@ -1603,7 +1618,7 @@ int guard_check(std::unique_ptr<th_model>* mp, std::function<th_model*(const ThK
         if (e != hipSuccess) { th_set_error("guard: frame upload failed: %s", hipGetErrorString(e)); return done(TH_EHIP); }
     }
     ThKnobs direct = m->knobs;
-    direct.guard = 0; direct.wino_split = 0; direct.first_split = 0; direct.winograd = 0; direct.wfused = 0; direct.first_wino = 0;
+    direct.guard = 0; direct.wino_split = 0; direct.first_split = 0; direct.wf_split = 0; direct.winograd = 0; direct.wfused = 0; direct.first_wino = 0;
     int lrc = TH_OK;
     const auto t0 = std::chrono::steady_clock::now();
     std::unique_ptr<th_model, void (*)(th_model*)> ref(reload(direct, &lrc), th_model_free);
@@ -1644,10 +1659,11 @@ int guard_check(std::unique_ptr<th_model>* mp, std::function<th_model*(const ThK
     hist = note;
     ThKnobs k = m->knobs;
     k.guard = 0;
-    const char* names[5] = {"TH_WINO_SPLIT=0", "TH_FIRST_SPLIT=0", "TH_WINOGRAD=0", "TH_WFUSED=0", "TH_FIRST_WINO=0"};
+    constexpr int kStages = 6;
+    const char* names[kStages] = {"TH_WINO_SPLIT=0", "TH_WF_SPLIT=0", "TH_FIRST_SPLIT=0", "TH_WINOGRAD=0", "TH_WFUSED=0", "TH_FIRST_WINO=0"};
     std::string dropped;
-    for (int stage = 0; stage < 5; ++stage) {
-        int* field = stage == 0 ? &k.wino_split : stage == 1 ? &k.first_split : stage == 2 ? &k.winograd : stage == 3 ? &k.wfused : &k.first_wino;
+    for (int stage = 0; stage < kStages; ++stage) {
+        int* field = stage == 0 ? &k.wino_split : stage == 1 ? &k.wf_split : stage == 2 ? &k.first_split : stage == 3 ? &k.winograd : stage == 4 ? &k.wfused : &k.first_wino;
         if (*field == 0) continue;
         *field = 0;
         dropped += (dropped.empty() ? "" : " ");
@@ -1658,7 +1674,7 @@ int guard_check(std::unique_ptr<th_model>* mp, std::function<th_model*(const ThK
         if ((rc = diff_of(alt.get(), &da))) { th_model_free(alt.release()); return done(rc); }
         snprintf(note, sizeof note, "; %s %.3g", names[stage], da);
         hist += note;
-        if (da <= bound || stage == 4) {
+        if (da <= bound || stage == kStages - 1) {
             alt->knobs.guard = m->knobs.guard;
             alt->guard_state = 2; alt->guard_dlogit = da; alt->guard_scale = scale;
             alt->guard_ref_load_ms = m->guard_ref_load_ms; alt->guard_run_ms = m->guard_run_ms;

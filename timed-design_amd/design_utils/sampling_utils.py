@@ -150,6 +150,16 @@ def _legacy_words(n: int, out=None):
 
 RNG_CHOICES = ("numpy", "philox", "mt19937")
 
+# Draws already taken from the device generators in this process, per (rng, seed): like the global NumPy stream, which advances
+# between calls, two sample_with_multiprocessing calls with the same --rng / --seed continue ONE stream instead of returning the
+# same draws twice.  reset_device_rng() starts the streams over (a fresh process starts at 0: a run is reproducible).
+_DEVICE_RNG_DRAWS: dict = {}
+
+
+def reset_device_rng(rng: t.Optional[str] = None, seed: t.Optional[int] = None) -> None:
+    for k in [k for k in _DEVICE_RNG_DRAWS if (rng is None or k[0] == rng) and (seed is None or k[1] == int(seed))]:
+        del _DEVICE_RNG_DRAWS[k]
+
 
 def _sample_keys(keys, sample_n: int, pdb_to_probability: dict, rotamer_categories, device: int = 0, rng: str = "numpy",
                  seed: int = 0) -> dict:
@@ -182,7 +192,10 @@ def _sample_keys(keys, sample_n: int, pdb_to_probability: dict, rotamer_categori
     on_device = one_letter and METRICS_SOURCE != "ampal"
     out = {}
     with sm.lock:       # the process-wide sampler is shared between threads; the arrays of run() are views of ITS result block
-        r, mode = None, rng
+        r, mode, offset = None, rng, 0
+        if rng != "numpy":
+            offset = _DEVICE_RNG_DRAWS.get((rng, int(seed)), 0)
+            _DEVICE_RNG_DRAWS[(rng, int(seed))] = offset + int(sample_n) * int(row_off[-1])
         if rng == "numpy":
             # the recurrence of the global generator is walked on the host straight into the sampler's page-locked buffer; the kernel
             # tempers the words and forms the doubles (short draws and other generators: np.random.rand's own doubles)
@@ -191,7 +204,7 @@ def _sample_keys(keys, sample_n: int, pdb_to_probability: dict, rotamer_categori
             mode = "mt_words"
             if r is None:
                 r, mode = _legacy_rand(n_draws), "host"
-        d = sm.run(np.concatenate(mats).astype(np.float64), row_off, sample_n, uniforms=r, rng=mode, seed=seed,
+        d = sm.run(np.concatenate(mats).astype(np.float64), row_off, sample_n, uniforms=r, rng=mode, seed=seed, rng_offset=offset,
                    letters="".join(cats[:n_cls]) if one_letter else None, want_idx=not one_letter, want_letters=one_letter,
                    want_metrics=on_device, cum_dtype=cum)
         out = _collect(keys, d, row_off, sample_n, cats, one_letter, on_device)
@@ -253,5 +266,6 @@ def sample_with_multiprocessing(workers, pdb_codes, sample_n, pdb_to_probability
     inherits the SAME generator state, so different PDBs can receive identical uniform streams — Appendix C-1).  Here
     all keys are drawn together on the GPU from one continuous stream in key order; ``workers`` is accepted and
     ignored.  Opt-in ``rng`` / ``seed`` (not in the reference): "numpy" replays np.random.rand bit for bit (default);
-    "philox" / "mt19937" draw the uniforms on the device from ``seed`` (see _sample_keys)."""
+    "philox" / "mt19937" draw the uniforms on the device from ``seed`` (see _sample_keys); successive calls in one process
+    continue the (rng, seed) stream where the previous call stopped, as the global NumPy stream does (reset_device_rng)."""
     return _sample_keys(pdb_codes, sample_n, pdb_to_probability, flat_categories, rng=rng, seed=seed)

@@ -40,6 +40,7 @@ def _read_matrix(path) -> np.ndarray:
 
 def main_sample(args):
     np.random.seed(args.seed)
+    su.reset_device_rng()                        # --seed restarts the device generators' streams too (they run on across library calls)
     matrix_path, map_path = Path(args.path_to_pred_matrix), Path(args.path_to_datasetmap)
     for what, path in (("prediction matrix", matrix_path), ("dataset map", map_path)):
         assert path.exists(), f"No {what} at {path}"
