@@ -216,4 +216,4 @@ def test_a_pass_is_remembered_across_processes_in_a_verdict_file(gpu, tmp_path):
     assert "earlier process" in ne
     off = tmp_path / "off"
     f, nf = run(TH_GUARD_CACHE="0", XDG_CACHE_HOME=str(off))
-    assert "earlier" not in nf and not off.exists()
+    assert "earlier" not in nf and not (off / "timed_hip").exists()      # (the ROCm runtime may create XDG_CACHE_HOME itself)
