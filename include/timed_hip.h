@@ -101,6 +101,20 @@ int th_predict(th_model* m, const void* frames, int dtype, int64_t n, float* pro
  * th_predict_async + th_predict_wait. */
 int th_predict_async(th_model* m, const void* frames, int dtype, int64_t n, float* probs_out, unsigned flags, int* ticket);
 int th_predict_wait(th_model* m, int ticket);
+/* Lossless sparse transport of float32 frames (row f-1: what design_utils/utils.py:487-530 hands to Model.predict, predict.py:142).
+ * Gaussian aposteriori frames are ~8 % non-zero; over PCIe a frame then costs ~25 KB instead of 222 KB, and is rebuilt bit for bit
+ * on the device in front of the first layer.  `blob` (host memory, little-endian, 16-byte aligned) is
+ *     0   char     magic[8] = "THSPF001"
+ *     8   uint32   n_frames, elems_per_frame E, bitmap words per frame W (>= ceil(E / 32), a multiple of 4), element bytes (4)
+ *     24  uint64   n_values
+ *     32  uint64   rank[n_frames + 1]      stored elements in front of frame i (rank[n] - rank[0] = n_values)
+ *     ..  (to the next multiple of 16)
+ *         uint32   bitmap[n_frames][W]     bit k of word w set <=> element 32 w + k is stored (every element whose bit pattern is
+ *                                          not +0.0: -0.0, NaN payloads and denormals are stored)
+ *         float    values[n_values]        the stored elements, frame by frame, in element order
+ * Same ticket / wait / ownership rules as th_predict_async (TH_PREDICT_LOGITS and TH_PREDICT_OUT_DEVICE apply). */
+#define TH_SPARSE_MAGIC "THSPF001"
+int th_predict_sparse_async(th_model* m, const void* blob, size_t blob_bytes, float* probs_out, unsigned flags, int* ticket);
 /* page-locked host memory for frame batches (what load_batch fills): allocate, or pin an existing range in place */
 int th_host_alloc(size_t bytes, void** out);
 int th_host_free(void* p);

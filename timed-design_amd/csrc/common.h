@@ -234,6 +234,9 @@ bool conv_wfs_plan(const ConvWfPlan& base, const TView& in, const PreOp& pre, Co
 void conv_wfs_pack_weights(const ConvWfsPlan& p, const float* w_keras, float* dst);
 int launch_conv_wfs(hipStream_t s, int64_t n, const ConvWfsPlan& p, TView in, TView out, const float* wpk, const float* bias, PostOps post);
 
+// ---- sparse float32 frames expanded on the device (sparse_frames.hip) ----
+int launch_sparse_expand(hipStream_t s, int64_t n, const uint32_t* bits, const uint64_t* vidx, const float* values, float* out, int E, int W);
+
 // ---- first-layer convolution (conv_first.hip): Cin <= 8, Cout <= 32, 3x3x3, reads the caller's frames ----
 std::string conv_first_label(const ConvMfmaPlan& p, int Cin, const PostOps& post);
 bool conv_first_plan(int Din, int Hin, int Win, int Cin, const TView& out_conv, const ConvGeom& g, int Cout, int pool,

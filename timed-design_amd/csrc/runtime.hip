@@ -352,6 +352,8 @@ struct th_model {
     hipStream_t copy_stream = nullptr, d2h_stream = nullptr;
     void* d_in_ring[kRing] = {nullptr, nullptr, nullptr};
     size_t in_ring_bytes = 0;          // capacity of EACH ring buffer
+    void* d_sp_ring[kRing] = {nullptr, nullptr, nullptr};     // sparse transport (th_predict_sparse_async): a piece's bitmaps, ranks
+    size_t sp_ring_bytes = 0;                                 // and stored values as they arrive, expanded into d_in_ring[r]
     hipEvent_t ev_h2d[kRing] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_free[kRing] = {nullptr, nullptr, nullptr};
     bool ring_used[kRing] = {false, false, false};
@@ -1773,6 +1775,7 @@ void th_model_free(th_model* m) {
     for (Buffer& b : m->bufs) if (b.dev) cached_free(b.dev);
     for (int r = 0; r < th_model::kRing; ++r) {
         if (m->d_in_ring[r]) cached_free(m->d_in_ring[r]);
+        if (m->d_sp_ring[r]) cached_free(m->d_sp_ring[r]);
         if (m->ev_h2d[r]) (void)hipEventDestroy(m->ev_h2d[r]);
         if (m->ev_free[r]) (void)hipEventDestroy(m->ev_free[r]);
     }
@@ -1828,7 +1831,15 @@ static bool host_ptr_is_pinned(const void* p) {
     return a.type == hipMemoryTypeHost;
 }
 
-static int predict_async_locked(th_model* m, const void* frames, int dtype, int64_t n, float* probs_out, unsigned flags, int* ticket);
+// a batch of sparse float32 frames in HOST memory (the sections of a THSPF001 blob, include/timed_hip.h)
+struct SparseBatch {
+    const uint64_t* vidx;      // [n + 1] cumulative stored-element counts
+    const uint32_t* bits;      // [n][W]
+    const float* values;       // values[vidx[i] - vidx[0] ...] belong to frame i
+    int E, W;
+};
+static int predict_async_locked(th_model* m, const void* frames, int dtype, int64_t n, float* probs_out, unsigned flags, int* ticket,
+                                const SparseBatch* sp = nullptr);
 
 int th_predict_async(th_model* m, const void* frames, int dtype, int64_t n, float* probs_out, unsigned flags, int* ticket) {
     if (n < 0) TH_FAIL(TH_EINVAL, "negative frame count");
@@ -1848,7 +1859,8 @@ int th_predict_async(th_model* m, const void* frames, int dtype, int64_t n, floa
     return rc;
 }
 
-static int predict_async_locked(th_model* m, const void* frames, int dtype, int64_t n, float* probs_out, unsigned flags, int* ticket) {
+static int predict_async_locked(th_model* m, const void* frames, int dtype, int64_t n, float* probs_out, unsigned flags, int* ticket,
+                                const SparseBatch* sp) {
     const size_t esz = dtype_size(dtype);
     if (!esz) TH_FAIL(TH_EINVAL, "unknown frame dtype %d", dtype);
     HIP_TRY(hipSetDevice(m->device));
@@ -1894,7 +1906,7 @@ static int predict_async_locked(th_model* m, const void* frames, int dtype, int6
         t.h_out_floats = std::max<size_t>(floats, 1024);
     }
     const bool in_device = (flags & TH_PREDICT_IN_DEVICE) != 0;         // frames are on the device already: no ring, no copies
-    const bool pinned = !in_device && n > 0 && host_ptr_is_pinned(frames);
+    const bool pinned = !in_device && n > 0 && host_ptr_is_pinned(sp ? (const void*)sp->values : frames);
     // (Shorter first pieces do not help: PCIe moves 252 k fp32 frames/s against 216 k computed, so a copy only stays
     // hidden behind the previous piece's kernels if pieces grow by <= 1.17x — measured, a 256/512/1024 ramp ends within
     // 0.5 % of equal pieces.  The one unhidden copy costs ~4 ms per call: 0.94x the device-resident rate at 16 k frames,
@@ -1911,10 +1923,41 @@ static int predict_async_locked(th_model* m, const void* frames, int dtype, int6
             if (pinned) HIP_TRY(hipStreamWaitEvent(m->copy_stream, m->ev_free[r], 0));
             else HIP_TRY(hipEventSynchronize(m->ev_free[r]));
         }
+        if (sp) {
+            // sparse transport: the piece's bitmaps, ranks and stored values travel (a tenth of the dense bytes for Gaussian frames);
+            // k_sparse_expand rebuilds the dense frames in the ring buffer, on the compute stream, in front of the first layer
+            const size_t bits_b = (size_t)cnt * sp->W * 4, vidx_b = (size_t)(cnt + 1) * 8;
+            const uint64_t v0 = sp->vidx[off], v1 = sp->vidx[off + cnt];
+            const size_t val_b = (size_t)(v1 - v0) * 4;
+            const size_t o_vidx = (bits_b + 15) / 16 * 16, o_val = (o_vidx + vidx_b + 15) / 16 * 16, need = o_val + val_b + 16;
+            if (m->sp_ring_bytes < need) {
+                HIP_TRY(hipStreamSynchronize(m->copy_stream));
+                HIP_TRY(hipStreamSynchronize(m->stream));
+                for (int q = 0; q < th_model::kRing; ++q) {
+                    if (m->d_sp_ring[q]) cached_free(m->d_sp_ring[q]);
+                    m->d_sp_ring[q] = nullptr;
+                }
+                m->sp_ring_bytes = 0;
+                const size_t cap = need + need / 4;
+                for (int q = 0; q < th_model::kRing; ++q)
+                    if (int rc = cached_malloc(&m->d_sp_ring[q], cap, m->device)) return rc;
+                m->sp_ring_bytes = cap;
+            }
+            char* const d = (char*)m->d_sp_ring[r];
+            HIP_TRY(hipMemcpyAsync(d, sp->bits + (size_t)off * sp->W, bits_b, hipMemcpyHostToDevice, m->copy_stream));
+            HIP_TRY(hipMemcpyAsync(d + o_vidx, sp->vidx + off, vidx_b, hipMemcpyHostToDevice, m->copy_stream));
+            if (val_b) HIP_TRY(hipMemcpyAsync(d + o_val, sp->values + (v0 - sp->vidx[0]), val_b, hipMemcpyHostToDevice, m->copy_stream));
+            HIP_TRY(hipEventRecord(m->ev_h2d[r], m->copy_stream));
+            HIP_TRY(hipStreamWaitEvent(m->stream, m->ev_h2d[r], 0));
+            int rc = launch_sparse_expand(m->stream, cnt, (const uint32_t*)d, (const uint64_t*)(d + o_vidx), (const float*)(d + o_val),
+                                          (float*)m->d_in_ring[r], sp->E, sp->W);
+            if (rc) return rc;
+        } else {
         HIP_TRY(hipMemcpyAsync(m->d_in_ring[r], (const char*)frames + (size_t)off * frame_bytes, (size_t)cnt * frame_bytes,
                                hipMemcpyHostToDevice, m->copy_stream));
         HIP_TRY(hipEventRecord(m->ev_h2d[r], m->copy_stream));
         HIP_TRY(hipStreamWaitEvent(m->stream, m->ev_h2d[r], 0));
+        }
         int rc = run_device(m, m->d_in_ring[r], dtype, cnt, (out_on_device ? probs_out : t.d_out) + (size_t)off * width, flags,
                             /*sync=*/false);
         if (rc) return rc;
@@ -1932,6 +1975,41 @@ static int predict_async_locked(th_model* m, const void* frames, int dtype, int6
     t.busy = true;
     *ticket = ti;
     return TH_OK;
+}
+
+int th_predict_sparse_async(th_model* m, const void* blob, size_t blob_bytes, float* probs_out, unsigned flags, int* ticket) {
+    if (!m || !ticket || !blob) TH_FAIL(TH_EINVAL, "null argument");
+    if (flags & TH_PREDICT_IN_DEVICE) TH_FAIL(TH_EINVAL, "a sparse batch is host memory");
+    const char* const b = (const char*)blob;
+    if (blob_bytes < 32 || std::memcmp(b, TH_SPARSE_MAGIC, 8)) TH_FAIL(TH_EINVAL, "not a THSPF001 sparse frame batch");
+    uint32_t n32, E, W, esz;
+    uint64_t nval;
+    std::memcpy(&n32, b + 8, 4); std::memcpy(&E, b + 12, 4); std::memcpy(&W, b + 16, 4); std::memcpy(&esz, b + 20, 4); std::memcpy(&nval, b + 24, 8);
+    const Node& in = m->nodes[m->input_node];
+    if (esz != 4 || (int64_t)E != (int64_t)in.D * in.H * in.W * in.C)
+        TH_FAIL(TH_EINVAL, "sparse batch: %u elements of %u bytes per frame, the model reads %d float32", E, esz, in.D * in.H * in.W * in.C);
+    if (W < (E + 31) / 32 || W % 4) TH_FAIL(TH_EINVAL, "sparse batch: %u bitmap words per frame for %u elements", W, E);
+    const size_t o_vidx = 32, o_bits = (o_vidx + ((size_t)n32 + 1) * 8 + 15) / 16 * 16, o_val = o_bits + (size_t)n32 * W * 4;
+    if (blob_bytes < o_val + nval * 4) TH_FAIL(TH_EINVAL, "sparse batch: %zu bytes, its header describes %zu", blob_bytes, o_val + (size_t)nval * 4);
+    SparseBatch sp;
+    sp.vidx = (const uint64_t*)(b + o_vidx); sp.bits = (const uint32_t*)(b + o_bits); sp.values = (const float*)(b + o_val);
+    sp.E = (int)E; sp.W = (int)W;
+    if (n32 && (sp.vidx[n32] - sp.vidx[0] != nval)) TH_FAIL(TH_EINVAL, "sparse batch: the ranks end at %llu, the header says %llu values",
+                                                                   (unsigned long long)(sp.vidx[n32] - sp.vidx[0]), (unsigned long long)nval);
+    for (uint32_t i = 0; i < n32; ++i)
+        if (sp.vidx[i + 1] < sp.vidx[i] || sp.vidx[i + 1] - sp.vidx[i] > E) TH_FAIL(TH_EINVAL, "sparse batch: frame %u has an impossible stored-element count", i);
+    if (n32 > 0 && !probs_out) TH_FAIL(TH_EINVAL, "null argument");
+    std::lock_guard<std::mutex> lock(m->mu);
+    int rc = predict_async_locked(m, blob, TH_F32, n32, probs_out, flags, ticket, &sp);
+    if (rc) {
+        const std::string keep = th_last_error();
+        (void)hipStreamSynchronize(m->copy_stream);
+        (void)hipStreamSynchronize(m->stream);
+        (void)hipStreamSynchronize(m->d2h_stream);
+        (void)hipGetLastError();
+        th_set_error("%s", keep.c_str());
+    }
+    return rc;
 }
 
 int th_predict_wait(th_model* m, int ticket) {

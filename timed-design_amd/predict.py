@@ -182,6 +182,21 @@ def _row_groups(n_rows, batch_size, start_batch, frames_per_call):
     return groups
 
 
+def _is_sparse(X) -> bool:
+    return type(X).__name__ == "SparseFrames"
+
+
+def _models_take_sparse(models) -> bool:
+    """every model of the round-robin is a HIP engine handle (or the sharded wrapper around one): only those read SparseFrames"""
+    for m in models:
+        inner = getattr(m, "sparse_ok", None)
+        if inner is None:
+            inner = hasattr(m, "_predict_async_sparse")
+        if not inner:
+            return False
+    return True
+
+
 def _run_groups(models, dataset_path, flat_dataset_map, groups, consume, gpu_decode=False):
     """Pipeline over the call groups, three stages on three threads:
          loader thread   load_batch of group g+1 (reference utils.py:487-530)
@@ -202,6 +217,13 @@ def _run_groups(models, dataset_path, flat_dataset_map, groups, consume, gpu_dec
     ring = []
     from timed_hip import framepack
     plain_h5 = not framepack.is_pack(dataset_path) and not framepack.is_structure(dataset_path)
+    # a float32 pack with sparse transport files (framepack.sparsify): the loader hands out SparseFrames batches — a tenth of the
+    # bytes cross PCIe, the device rebuilds the dense frames (th_predict_sparse_async).  TIMED_SPARSE=0: the dense rows as before
+    sparse_pack = None
+    if framepack.is_pack(dataset_path) and os.environ.get("TIMED_SPARSE", "1") != "0" and getattr(models[0], "device", None) is not None:
+        fp = du._frame_pack(dataset_path)
+        if fp.sparse is not None and _models_take_sparse(models):
+            sparse_pack = fp
     # loader threads: two on GPU-inflated datasets (see below), one elsewhere.  The ring is sized for ALL of them: when the device
     # decode falls back to the host reader mid-run (an unsupported file, TH_ENOMEM), both loaders keep filling host buffers, and
     # a ring sized for one would hand group k + 2 the slot of a group whose ticket may still be outstanding
@@ -230,7 +252,31 @@ def _run_groups(models, dataset_path, flat_dataset_map, groups, consume, gpu_dec
     # outstanding + the one waiting to be submitted + the one being filled.  TIMED_STAGING=0 hands out the mapped rows as before.
     staging = [None]
 
+    sparse_ring = [None]
+
+    def _stage_sparse(X):
+        # a sparse batch (views of the memory-mapped transport files) is assembled into ONE page-locked blob: rank table, bitmaps, values
+        if sparse_ring[0] is False:
+            return X, None
+        if sparse_ring[0] is None:
+            sparse_ring[0] = False
+            try:
+                from timed_hip import _lib, engine
+                cpus = int(_lib.load().th_host_cpus())
+                ranks_here = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))
+                threads = int(os.environ.get("TIMED_STAGING_THREADS", str(max(1, min(8, (cpus - 2) // ranks_here)))))
+                if os.environ.get("TIMED_STAGING", "1") != "0":
+                    sparse_ring[0] = engine.BlobRing(3 * len(models) + 2, threads)
+            except Exception:
+                sparse_ring[0] = False
+            if sparse_ring[0] is False:
+                return X, None
+        got, slot = sparse_ring[0].stage(X)
+        return got, (None if slot is None else ("sparse", slot))
+
     def _stage(X):
+        if _is_sparse(X):
+            return _stage_sparse(X)
         if staging[0] is False or not isinstance(X, np.memmap) or getattr(models[0], "device", None) is None:
             return X, None
         if staging[0] is None:
@@ -255,6 +301,10 @@ def _run_groups(models, dataset_path, flat_dataset_map, groups, consume, gpu_dec
 
     def _load_rows(k):
         lo, hi = groups[k]
+        if sparse_pack is not None:
+            rows = sparse_pack.contiguous_rows(flat_dataset_map[lo:hi])
+            if rows is not None:
+                return sparse_pack.sparse_batch(*rows), sparse_pack.labels[rows[0]:rows[1]].astype(float)
         if decode_on_gpu[0]:
             # gzip .hdf5: the chunks of this group are inflated ON the GPU that will predict it (th_h5_decode_device) — the
             # frames never exist on the host; a dataset that cannot take the path (other filters, a layout h5lite does not read ...) says so
@@ -283,7 +333,9 @@ def _run_groups(models, dataset_path, flat_dataset_map, groups, consume, gpu_dec
         import time
         t0 = time.perf_counter()
         probs = ticket.result()
-        if slot is not None:
+        if isinstance(slot, tuple):
+            sparse_ring[0].release(slot[1])
+        elif slot is not None:
             staging[0].release(slot)
         t1 = time.perf_counter()
         consume(probs, labels)
@@ -318,6 +370,14 @@ def _run_groups(models, dataset_path, flat_dataset_map, groups, consume, gpu_dec
                 du.give_back_staging_ring(staging[0])    # kept for the next call; du.release_device_memory() (the CLI, at its end) closes it
             else:
                 staging[0].close()
+        if sparse_ring[0]:
+            if not completed:
+                for ticket, *_rest in pending:
+                    try:
+                        ticket.result()
+                    except Exception:
+                        pass
+            sparse_ring[0].close()
     if os.environ.get("TIMED_PIPELINE_TRACE"):
         print(f"[pipeline] load_batch calls took {load_seconds[0]:.3f} s in the loader thread(s); the writer thread waited {write_seconds[0]:.3f} s "
               f"for results and spent {write_seconds[1]:.3f} s formatting / appending", file=sys.stderr)
@@ -539,6 +599,8 @@ def _predict_sharded(model, gather, rank, world, dataset_path, flat_dataset_map,
                     return d_local.download((self.rows, width), np.float32, offset=self.row * width * 4)
 
             class _ToDevice:          # the model facade _run_groups drives: outputs land in d_local at the shard row
+                sparse_ok = True          # predict_async_device reads SparseFrames batches too
+
                 def __init__(self):
                     self.row = 0
                     self.device = model.device

@@ -36,6 +36,7 @@ PROTOTYPES = {
     "th_predict": (_i, [_vp, _vp, _i, _i64, _vp, _u]),
     "th_predict_device": (_i, [_vp, _vp, _i, _i64, _vp, _u]),
     "th_predict_async": (_i, [_vp, _vp, _i, _i64, _vp, _u, _pi]),
+    "th_predict_sparse_async": (_i, [_vp, _vp, _sz, _vp, _u, _pi]),
     "th_predict_wait": (_i, [_vp, _i]),
     "th_host_alloc": (_i, [_sz, C.POINTER(_vp)]),
     "th_host_free": (_i, [_vp]),

@@ -66,6 +66,8 @@ class HipFrameModel:
     def predict(self, X, batch_size: Optional[int] = None, verbose=0, logits: bool = False, **_ignored) -> np.ndarray:
         """X[B,D,H,W,C] -> float32 [B,n_classes].  ``batch_size``/``verbose`` are accepted for
         signature compatibility with ``Model.predict``; chunking is internal."""
+        if isinstance(X, SparseFrames):
+            return self.predict_async(X, logits=logits).result()
         X = np.asarray(X)
         if X.ndim != 5 or tuple(X.shape[1:]) != self.input_shape:
             raise ValueError(f"expected frames of shape (B, {', '.join(map(str, self.input_shape))}), got {X.shape}")
@@ -87,7 +89,27 @@ class HipFrameModel:
     def predict_async(self, X, logits: bool = False) -> "PendingPrediction":
         if isinstance(X, DeviceFrames):
             return self.predict_async_frames_on_device(X, logits=logits)
+        if isinstance(X, SparseFrames):
+            return self._predict_async_sparse(X, None, logits=logits)
         return self._predict_async_host(X, logits=logits)
+
+    def _predict_async_sparse(self, X: "SparseFrames", d_out, logits: bool = False) -> "PendingPrediction":
+        """A batch in the sparse transport form (SparseFrames: bitmap + stored values, timed_hip/framepack.py): a tenth of the
+        bytes of dense Gaussian frames cross PCIe, the dense frames are rebuilt bit for bit on the device (th_predict_sparse_async)."""
+        if tuple(X.shape[1:]) != self.input_shape:
+            raise ValueError(f"expected frames of shape (B, {', '.join(map(str, self.input_shape))}), got {X.shape}")
+        blob = X.blob()
+        n = X.shape[0]
+        flags = _lib.TH_PREDICT_LOGITS if logits else 0
+        out = None
+        if d_out is None:
+            out = np.empty((n, self.logits_width if logits else self.n_classes), dtype=np.float32)
+        else:
+            flags |= _lib.TH_PREDICT_OUT_DEVICE
+        ticket = C.c_int(-1)
+        _lib.check(self._lib.th_predict_sparse_async(self._h, blob.ctypes.data, blob.nbytes,
+                                                     C.c_void_p(d_out) if d_out is not None else out.ctypes.data, flags, C.byref(ticket)))
+        return PendingPrediction(self, ticket.value, (X, blob), out)
 
     def _predict_async_host(self, X, logits: bool = False) -> "PendingPrediction":
         """Queue ``X`` (copy to the device, kernels, copy of the probabilities back) and return at once; the
@@ -115,6 +137,8 @@ class HipFrameModel:
         """As predict_async, but the probability rows are left in device memory at address ``d_out`` (this model's
         device, room for len(X) * n_classes floats) — e.g. a shard buffer that th_comm_gather_rows sends over xGMI.
         ``result()`` returns None once the rows are there."""
+        if isinstance(X, SparseFrames):
+            return self._predict_async_sparse(X, d_out)
         if isinstance(X, DeviceFrames):          # frames on the device already (GPU-inflated .hdf5 batches): nothing is copied
             if tuple(X.shape[1:]) != self.input_shape or X.device != self.device:
                 raise ValueError(f"device frames of shape {X.shape} on device {X.device} do not fit this model")
@@ -271,6 +295,163 @@ class PinnedBuffer:
             self.free()
         except Exception:
             pass
+
+
+SPARSE_MAGIC = b"THSPF001"
+
+
+def sparse_blob_layout(n: int, words: int, n_values: int):
+    """byte offsets of the sections of a THSPF001 blob (include/timed_hip.h): (ranks, bitmaps, values, total)"""
+    o_rank = 32
+    o_bits = (o_rank + (n + 1) * 8 + 15) // 16 * 16
+    o_val = o_bits + n * words * 4
+    return o_rank, o_bits, o_val, o_val + n_values * 4
+
+
+class SparseFrames:
+    """A batch of float32 frames in the sparse transport form: ``bits`` [n, W] uint32 (bit k of word w set <=> element 32 w + k
+    is stored), ``rank`` [n + 1] uint64 (stored elements in front of frame i, relative to any base) and ``values`` (the stored
+    elements of the n frames in order).  Lossless: every element whose bit pattern is not +0.0 is stored.  ``blob()`` is the
+    THSPF001 buffer th_predict_sparse_async reads — built into ``out`` (e.g. a page-locked slot of a BlobRing) when given."""
+
+    def __init__(self, bits, rank, values, frame_shape):
+        self.bits, self.rank, self.values = bits, rank, values
+        self.frame_shape = tuple(int(d) for d in frame_shape)
+        self.shape = (int(bits.shape[0]),) + self.frame_shape
+        self.dtype = np.dtype(np.float32)
+        self._blob = None
+
+    def __len__(self):
+        return self.shape[0]
+
+    @property
+    def n_values(self) -> int:
+        return int(self.rank[-1] - self.rank[0]) if len(self.rank) else 0
+
+    @property
+    def blob_bytes(self) -> int:
+        return sparse_blob_layout(self.shape[0], int(self.bits.shape[1]), self.n_values)[3]
+
+    @property
+    def dense_bytes(self) -> int:
+        return int(np.prod(self.shape)) * 4
+
+    def blob(self, out: Optional[np.ndarray] = None, pool=None, threads: int = 1) -> np.ndarray:
+        if out is None and self._blob is not None:
+            return self._blob
+        n, W, nv = self.shape[0], int(self.bits.shape[1]), self.n_values
+        o_rank, o_bits, o_val, total = sparse_blob_layout(n, W, nv)
+        buf = np.empty(total + 16, np.uint8) if out is None else out
+        if buf.nbytes < total or buf.ctypes.data % 16:
+            raise ValueError("sparse blob: the target buffer is too small or not 16-byte aligned")
+        buf[:8] = np.frombuffer(SPARSE_MAGIC, np.uint8)
+        buf[8:24].view(np.uint32)[:] = (n, int(np.prod(self.frame_shape)), W, 4)
+        buf[24:32].view(np.uint64)[0] = nv
+        buf[o_rank:o_rank + (n + 1) * 8].view(np.uint64)[:] = self.rank
+        dst_bits = buf[o_bits:o_bits + n * W * 4].view(np.uint32).reshape(n, W)
+        dst_val = buf[o_val:o_val + nv * 4].view(np.float32)
+        src_val = self.values[:nv]
+        if pool is not None and threads > 1 and nv > (1 << 20):       # NumPy copies release the interpreter lock
+            cuts = [nv * i // threads for i in range(threads + 1)]
+            jobs = [pool.submit(np.copyto, dst_val[a:b], src_val[a:b]) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+            jobs.append(pool.submit(np.copyto, dst_bits, self.bits))
+            for j in jobs:
+                j.result()
+        else:
+            np.copyto(dst_bits, self.bits)
+            np.copyto(dst_val, src_val)
+        view = buf[:total]
+        if out is None:
+            self._blob = view
+        return view
+
+    def staged(self, blob: np.ndarray) -> "SparseFrames":
+        """the same batch with its blob already built in (page-locked) memory owned by somebody else"""
+        sf = SparseFrames(self.bits, self.rank, self.values, self.frame_shape)
+        sf._blob = blob
+        return sf
+
+    def dense(self) -> np.ndarray:
+        """the frames as an ordinary [n, *frame_shape] float32 array (host expansion: tests, CPU-side consumers)"""
+        n, E = self.shape[0], int(np.prod(self.frame_shape))
+        mask = np.unpackbits(np.ascontiguousarray(self.bits).view(np.uint8), axis=1, bitorder="little")[:, :E].astype(bool)
+        out = np.zeros((n, E), np.float32)
+        out[mask] = np.asarray(self.values[:self.n_values])
+        return out.reshape(self.shape)
+
+    @classmethod
+    def from_dense(cls, frames: np.ndarray) -> "SparseFrames":
+        frames = np.ascontiguousarray(frames, dtype=np.float32)
+        n = frames.shape[0]
+        E = int(np.prod(frames.shape[1:]))
+        W = ((E + 31) // 32 + 3) // 4 * 4
+        flat = frames.reshape(n, E)
+        mask = flat.view(np.uint32) != 0
+        padded = np.zeros((n, W * 32), bool)
+        padded[:, :E] = mask
+        bits = np.packbits(padded, axis=1, bitorder="little").view(np.uint32).reshape(n, W)
+        rank = np.concatenate([[0], np.cumsum(mask.sum(1, dtype=np.int64))]).astype(np.uint64)
+        return cls(bits, rank, flat[mask], frames.shape[1:])
+
+
+class BlobRing:
+    """Page-locked byte buffers for sparse batches between a memory-mapped pack and th_predict_sparse_async — StagingRing's
+    counterpart for variable-size blobs: a slot grows (and is re-registered) when a batch does not fit."""
+
+    def __init__(self, slots: int, threads: int = 8):
+        import queue
+        from concurrent.futures import ThreadPoolExecutor
+        self._lib = _lib.load()
+        self._arrays = [None] * slots
+        self._pinned = [False] * slots
+        self._free = queue.SimpleQueue()
+        for i in range(slots):
+            self._free.put(i)
+        self._threads = max(1, int(threads))
+        self._pool = ThreadPoolExecutor(max_workers=self._threads, thread_name_prefix="stage_sparse")
+        self.enabled = True
+
+    def stage(self, X: SparseFrames):
+        if not self.enabled or len(X) == 0:
+            return X, None
+        need = X.blob_bytes
+        slot = self._free.get()
+        try:
+            a = self._arrays[slot]
+            if a is None or a.nbytes < need:
+                if a is not None and self._pinned[slot]:
+                    self._lib.th_host_unregister(C.c_void_p(a.ctypes.data))
+                    self._pinned[slot] = False
+                raw = np.empty(need + need // 8 + 4096 + 16, np.uint8)
+                off = (-raw.ctypes.data) % 16
+                a = self._arrays[slot] = raw[off:]
+            blob = X.blob(out=a, pool=self._pool, threads=self._threads)
+            if not self._pinned[slot]:
+                if self._lib.th_host_register(C.c_void_p(a.ctypes.data), a.nbytes) != 0:
+                    self.enabled = False
+                    self._free.put(slot)
+                    return X, None
+                self._pinned[slot] = True
+            return X.staged(blob), slot
+        except BaseException:
+            self._free.put(slot)
+            raise
+
+    def release(self, slot) -> None:
+        if slot is not None:
+            self._free.put(slot)
+
+    def close(self) -> None:
+        if self._pool is None:
+            return
+        self._pool.shutdown(wait=True)
+        self._pool = None
+        for i, a in enumerate(self._arrays):
+            if a is not None and self._pinned[i]:
+                self._lib.th_host_unregister(C.c_void_p(a.ctypes.data))
+                self._pinned[i] = False
+        self._arrays = [None] * len(self._arrays)
+        self.enabled = False
 
 
 class StagingRing:
