@@ -159,7 +159,16 @@ def predict_py_e2e(cfg, weights, n_pack=20000, n_hdf5=2000, batch_size=500, work
             stem = os.path.join(td, "synth_f32")
             make_frame_pack(stem, n_pack, gaussian=True)
             run(stem + ".framepack", "predict_py_framepack_f32", n_pack)
-            for s in (".frames.npy",):
+            res["predict_py_framepack_f32_pcie_bytes_per_frame"] = os.path.getsize(stem + ".frames.npy") / n_pack
+            # the same pack with the sparse transport files (framepack.sparsify): bitmap + stored values cross PCIe, the device
+            # rebuilds the dense frames (th_predict_sparse_async); the output files are the dense run's, byte for byte (tests)
+            from timed_hip import framepack
+            t0 = time.perf_counter()
+            dense_b, sparse_b = framepack.sparsify(stem)
+            res["sparsify_s"] = time.perf_counter() - t0
+            run(stem + ".framepack", "predict_py_framepack_sparse_f32", n_pack)
+            res["predict_py_framepack_sparse_f32_pcie_bytes_per_frame"] = sparse_b / n_pack
+            for s in (".frames.npy",) + tuple(framepack.SPARSE_SUFFIXES):
                 os.remove(stem + s)
             stem = os.path.join(td, "synth_u8")
             make_frame_pack(stem, n_pack, gaussian=False)

@@ -81,7 +81,8 @@ def _other(o: dict) -> dict:
 
 
 _E2E_KEYS = ("device_resident_fps", "device_resident_u8_fps", "th_predict_sync_pageable_fps", "th_predict_async_pinned_fps",
-             "predict_py_framepack_f32_fps", "predict_py_framepack_u8_fps", "predict_py_rotamer_fps",
+             "predict_py_framepack_f32_fps", "predict_py_framepack_sparse_f32_fps", "predict_py_framepack_sparse_f32_pcie_bytes_per_frame",
+             "predict_py_framepack_u8_fps", "predict_py_rotamer_fps",
              "predict_py_hdf5_gzip_f64_first_call_fps", "predict_py_hdf5_gzip_f64_fps", "predict_py_hdf5_cold_process_fps",
              "config1_predict_py_from_pdb_s",
              "config1_cpu_oracle_forward_s")
