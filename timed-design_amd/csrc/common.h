@@ -45,6 +45,7 @@ struct ThKnobs {
     int guard = 1;             // TH_GUARD: load-time check of the fast plans against the direct fp32 plan (0: off)
     int first_wino = 1;        // TH_FIRST_WINO=0: k_conv_first instead of k_conv_first_w
     int first_split = 1;       // TH_FIRST_SPLIT: the aposteriori first layer on bf16 MFMA with exactly split operands (conv_first_b3.hip)
+    int first_int = 1;         // TH_FIRST_INT: uint8 / bool frames on the one-piece form of conv_first_b3 (0: the general six-product kernel)
     int first_zb = 0;          // TH_FIRST_ZB: brick depth of the first-layer kernel (tuning)
     int first_dbg = 0;         // TH_FIRST_DBG: timing knock-outs (results wrong)
     int no_pool_first = 0;     // TH_NO_POOL_FIRST: act / BN before the max-pool even when the chain is monotone

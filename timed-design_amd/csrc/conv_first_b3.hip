@@ -111,7 +111,12 @@ constexpr B3Slot kB3Slot[3][8] = {
 // DBG (TH_FIRST_DBG with the split kernel, results WRONG unless noted): 1 no split arithmetic (the pieces are raw bit patterns),
 // 2 no MFMAs, 4 no staging (the ring keeps the first planes), 8 no epilogue chain / stores, 64 (results right) the compiler's own
 // instruction order inside the windows, 128 no weight-fragment reads, 256 no raw-voxel reads
-template <int DBG>
+// INT: the frames hold integers 0 .. 255 (uint8 / bool datasets: what the reference builds for voxels_as_gaussian=False,
+// design_utils/utils.py:518-521).  Every voxel and the three difference points d0 - d2, d2 - d1, d1 - d3 are then exact in ONE bf16
+// piece (|x| <= 255), the sum point d1 + d2 (<= 510) in two: 3 products per multiply-add instead of 6 (5 at the sum point) and no
+// split arithmetic except one subtraction at the sum point.  The products that remain run in the order the general form runs
+// them, and the ones dropped are exact zeros there: the results are bit-identical to the fp32-frame run of the same values.
+template <int DBG, int INT = 0>
 __global__ void __launch_bounds__(512, 1) k_conv_first_b3(const ConvFirstB3Args a) {
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     float* const A = reinterpret_cast<float*>(smem);
@@ -128,6 +133,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_first_b3(const ConvFirstB3Args 
     // ---- staging: planes [S, S2) of the workgroup's plane sequence (22 per frame), two voxels per thread -------------------
     const int64_t frame_elems = (int64_t)kFD * kFD * kFD * a.Cin;
     const bool fast6 = a.vec8 != 0;
+    const bool fastu8 = INT && a.vec8 == 0 && a.Cin == 6 && (a.dtype == TH_U8 || a.dtype == TH_BOOL) && ((uintptr_t)a.in % 2) == 0;
     float e[2][6];
     int sdst[2];
     // per-thread constants of its two voxels v = tid, tid + 512 of a PAIR of planes (2 x 484): which plane of the pair, the
@@ -169,6 +175,12 @@ __global__ void __launch_bounds__(512, 1) k_conv_first_b3(const ConvFirstB3Args 
                     const float2* p2 = reinterpret_cast<const float2*>((const float*)a.in + base);
                     const float2 u0 = p2[0], u1 = p2[1], u2 = p2[2];
                     e[u][0] = u0.x; e[u][1] = u0.y; e[u][2] = u1.x; e[u][3] = u1.y; e[u][4] = u2.x; e[u][5] = u2.y;
+                } else if (fastu8) {          // six bytes of a voxel as three 16-bit loads (a voxel starts at an even byte)
+                    const unsigned short* p16 = reinterpret_cast<const unsigned short*>((const unsigned char*)a.in + base);
+                    const unsigned w0 = p16[0], w1 = p16[1], w2 = p16[2];
+                    const unsigned b[6] = {w0 & 255u, w0 >> 8, w1 & 255u, w1 >> 8, w2 & 255u, w2 >> 8};
+#pragma unroll
+                    for (int c2 = 0; c2 < 6; ++c2) e[u][c2] = a.dtype == TH_BOOL ? (b[c2] ? 1.f : 0.f) : (float)b[c2];
                 } else {
 #pragma unroll
                     for (int c2 = 0; c2 < 6; ++c2)
@@ -350,8 +362,18 @@ __global__ void __launch_bounds__(512, 1) k_conv_first_b3(const ConvFirstB3Args 
                     }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) hh[q] = b3_pk(x[q]);
+                    if (INT && p != 1) {           // exact in one piece
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { PA[buf][0][q] = hh[q]; PA[buf][1][q] = 0u; PA[buf][2][q] = 0u; }
+                        return;
+                    }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) r1[q] = x[q] - b3_unpk(hh[q]);
+                    if (INT) {                     // the sum point d1 + d2 <= 510: exact in two
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { PA[buf][0][q] = hh[q]; PA[buf][1][q] = b3_pk(r1[q]); PA[buf][2][q] = 0u; }
+                        return;
+                    }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) mm[q] = b3_pk(r1[q]);
 #pragma unroll
@@ -373,16 +395,17 @@ __global__ void __launch_bounds__(512, 1) k_conv_first_b3(const ConvFirstB3Args 
                         return;
                     }
                     auto A8 = [&](int piece) { return __builtin_bit_cast(bf16x8, (u32x4){PA[buf][piece][0], PA[buf][piece][1], PA[buf][piece][2], PA[buf][piece][3]}); };
-                    acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A8(2), PB[buf][0], acc[p], 0, 0, 0);      // l H
-                    acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A8(1), PB[buf][0], acc[p], 0, 0, 0);      // m H
+                    if (!INT) acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A8(2), PB[buf][0], acc[p], 0, 0, 0);      // l H
+                    if (!INT || p == 1) acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A8(1), PB[buf][0], acc[p], 0, 0, 0);      // m H
                     acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A8(0), PB[buf][0], acc[p], 0, 0, 0);      // h H
-                    acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A8(1), PB[buf][1], acc[p], 0, 0, 0);      // m M
+                    if (!INT || p == 1) acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A8(1), PB[buf][1], acc[p], 0, 0, 0);      // m M
                     acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A8(0), PB[buf][1], acc[p], 0, 0, 0);      // h M
                     acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A8(0), PB[buf][2], acc[p], 0, 0, 0);      // h L
                 };
 // a window's instruction order: N times "one MFMA, then up to V VALU and L LDS instructions"
 #define B3_PIPE(V, L) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, V, 0); __builtin_amdgcn_sched_group_barrier(0x100, L, 0);
-#define B3_WIN6 { if (!(DBG & 64)) { B3_PIPE(7, 4) B3_PIPE(7, 4) B3_PIPE(7, 4) B3_PIPE(7, 4) B3_PIPE(7, 4) B3_PIPE(7, 4) } __builtin_amdgcn_sched_barrier(0); }
+#define B3_WIN6 { if (!(DBG & 64)) { if (INT) { B3_PIPE(10, 6) B3_PIPE(10, 6) B3_PIPE(10, 6) B3_PIPE(10, 6) B3_PIPE(10, 6) } \
+                                      else { B3_PIPE(7, 4) B3_PIPE(7, 4) B3_PIPE(7, 4) B3_PIPE(7, 4) B3_PIPE(7, 4) B3_PIPE(7, 4) } } __builtin_amdgcn_sched_barrier(0); }
 #define B3_WIN3 { if (!(DBG & 64)) { B3_PIPE(15, 8) B3_PIPE(15, 8) B3_PIPE(15, 8) } __builtin_amdgcn_sched_barrier(0); }
                 // ---- prologue: tap 8 (fp32), the raw voxels of k-step 0, the fragments of unit 0
                 v2f d8p[4];
@@ -494,7 +517,7 @@ std::string conv_first_b3_label(int nnb) {
     (void)nnb;
     char buf[256];
     snprintf(buf, sizeof buf, "conv_first_b3<F(2,3) along x; pool before the chain> persistent, ring of %d planes, lds%zuK; bf16x3 split operands, 6 products, "
-             "fp32 accumulate (weights in LDS, direct input) [k_conv_first_b3]", kRing, kB3Lds / 1024);
+             "fp32 accumulate; uint8 / bool frames: one-piece data, 3 products (weights in LDS, direct input) [k_conv_first_b3]", kRing, kB3Lds / 1024);
     return buf;
 }
 
@@ -563,7 +586,9 @@ int launch_conv_first_b3(hipStream_t s, int64_t n, const ConvMfmaPlan& p, const 
     // equal trips: every workgroup streams ceil(n / grid) or one frame fewer
     const int64_t trips = (n + resident - 1) / resident;
     const int64_t grid = (n + trips - 1) / trips;
-    FirstB3Kernel k = k_conv_first_b3<0>;
+    // integer frames (uint8 / bool): one-piece data, 3 products (TH_FIRST_INT=0: the general kernel, same bits)
+    const bool ints = (dtype == TH_U8 || dtype == TH_BOOL) && kn.first_int;
+    FirstB3Kernel k = ints ? k_conv_first_b3<0, 1> : k_conv_first_b3<0>;
     if (kn.first_dbg > 0)
         for (const FirstB3Dbg& d : kFirstB3Dbg) if (d.code == kn.first_dbg) k = d.k;
     HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -67,6 +67,7 @@ void th_knobs_read(ThKnobs* k) {
     num("TH_GUARD", &k->guard, 0, 2);
     num("TH_FIRST_WINO", &k->first_wino, 0, 1);
     num("TH_FIRST_SPLIT", &k->first_split, 0, 1);
+    num("TH_FIRST_INT", &k->first_int, 0, 1);
     num("TH_FIRST_ZB", &k->first_zb, 0, 1 << 20);
     num("TH_FIRST_DBG", &k->first_dbg, 0, 1 << 20);
     flag("TH_NO_POOL_FIRST", &k->no_pool_first);

@@ -447,9 +447,7 @@ def step_pipe(step):
     if "bf16x3" in step["label"]:
         # k_conv_first_b3 runs 8 of its 9 (dz, dy) taps as six bf16 products and tap 8 as fp32-input MFMAs, which cost 16 bf16-pipe
         # FLOPs per FLOP (the fp32 form runs at 1/16 of the bf16 rate on the same pipe): 8/9 x 6 + 1/9 x 16
-        mult = (8.0 * 6.0 + 16.0) / 9.0 if "k_conv_first_b3" in step["label"] and "u8x1" not in step["label"] else 6.0
-        if "bf16x3:3p" in step["label"]:          # exact single-piece data (uint8 / bool frames): 3 products per multiply-add
-            mult = 3.0
+        mult = (8.0 * 6.0 + 16.0) / 9.0 if "k_conv_first_b3" in step["label"] else 6.0
         return "bf16", PEAK_BF16_MFMA_TFLOPS, mult * step["flops"]
     return "fp32", PEAK_FP32_MFMA_TFLOPS, step["flops"]
 
