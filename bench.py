@@ -299,8 +299,8 @@ def main():
                        "algo_mflop_per_frame": cost["algo_flops"] / 1e6, "kernel_mflop_per_frame": kernel_flops / 1e6,
                        "exec_mflop_per_frame": cost["exec_flops"] / 1e6, "winograd_layers": sum("k_wino_gemm" in s["label"] for s in model.steps()),
                        "split_gemm_layers": sum("bf16x3" in s["label"] for s in model.steps()),      # (steps, the first layer included)
-                       "arithmetic": "fp32-input MFMA; first layer and 5^3 Winograd GEMMs: operands split exactly into 3 bf16 pieces, "
-                                     "6 products on bf16 MFMA, fp32 accumulate (tests hold the same 5e-6 bound)",
+                       "arithmetic": "bf16 MFMA on operands split exactly into 3 bf16 pieces (6 products, fp32 accumulate) in every 3x3x3 layer of "
+                                     "TIMED: first layer, fused 10^3 layer, 5^3 Winograd GEMMs; fp32-input MFMA elsewhere (tests hold the same 5e-6 bound)",
                        "emulated_fp32": True,      # fp32 results from bf16-pipe products on exactly split operands (5 of the plan's steps)
                        "knobs": model.knobs(), "guard": {k: (round(v, 9) if isinstance(v, float) else v) for k, v in model.guard().items() if k != "note"},
                        "device": f"{model.device_arch} {model.device_cus} CUs"},
