@@ -255,6 +255,15 @@ void conv_first_b3_pack_weights(int Cin, int Cout, const float* w_keras, float* 
 int launch_conv_first_b3(hipStream_t s, int64_t n, const ConvMfmaPlan& p, const void* frames, int dtype, int Cin, TView out, int Cout,
                          const float* wpk, const float* bias, PostOps post);
 
+// 5x5x5 'same' convolution on the model input, <= 8 channels -> <= 16 filters, 2^3 max-pool behind it (conv_first5.hip): ProDCoNN's stem
+bool conv_first5_ok(int Din, int Hin, int Win, int Cin, int Cout, const ConvGeom& g, int pool);
+size_t conv_first5_wpk_floats();
+double conv_first5_exec_flops();
+std::string conv_first5_label();
+void conv_first5_pack_weights(int Cin, int Cout, const float* w_keras, float* dst);
+int launch_conv_first5(hipStream_t s, int64_t n, const ThKnobs* knobs, const void* frames, int dtype, int Cin, TView out, int Cout,
+                       const float* wpk, const float* bias, PostOps post);
+
 // ---- pointwise (1x1x1) streaming convolution (conv_pointwise.hip); plan.cfg in [300, 309) ----
 bool conv_pw_plan(const TView& in, const TView& out_conv, const ConvGeom& g, int Cin, int Cout, int pool, ConvMfmaPlan* plan);
 void conv_pw_pack_weights(const ConvMfmaPlan& p, int Cin, int Cout, const float* w_keras, float* dst);

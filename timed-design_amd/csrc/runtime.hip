@@ -610,7 +610,17 @@ int plan(th_model* m) {
             TView ov; ov.D = n.D; ov.H = n.H; ov.W = n.W; ov.C = n.C; ov.fs = (int64_t)n.D * n.H * n.W * n.C;
             ConvMfmaPlan mp;
             bool ok = false;
-            if (use_mfma && fuse && f.src == m->input_node && f.pre.empty()) {
+            if (use_mfma && fuse && f.src == m->input_node && f.pre.empty() && f.pool >= 0 && N[f.pool].op == OP_MAXPOOL &&
+                conv_first5_ok(src.D, src.H, src.W, src.C, n.C, g, 1)) {
+                // ProDCoNN's 5x5x5 stem: direct form on the bf16 pipe, input split once at staging (conv_first5.hip); cfg 101
+                mp = ConvMfmaPlan();
+                mp.cfg = 101; mp.pool = 1; mp.nnb = 1;
+                mp.knobs = &th_knobs_planning();
+                mp.exec_flops = conv_first5_exec_flops();
+                mp.label = conv_first5_label();
+                ok = true;
+            }
+            if (!ok && use_mfma && fuse && f.src == m->input_node && f.pre.empty()) {
                 if (f.pool >= 0) ok = conv_first_plan(src.D, src.H, src.W, src.C, ov, g, n.C, N[f.pool].op == OP_MAXPOOL ? 1 : 2, &mp);
                 if (!ok && f.pool < 0) ok = conv_first_plan(src.D, src.H, src.W, src.C, ov, g, n.C, 0, &mp);
             }
@@ -641,7 +651,7 @@ int plan(th_model* m) {
     m->need_convert = false;
     for (int c : N[m->input_node].consumers) {
         bool direct = false;
-        for (auto& kv : fus) if (kv.second.src == m->input_node && (kv.first == c) && mplans.count(kv.first) && mplans[kv.first].cfg == 100) direct = true;
+        for (auto& kv : fus) if (kv.second.src == m->input_node && (kv.first == c) && mplans.count(kv.first) && (mplans[kv.first].cfg == 100 || mplans[kv.first].cfg == 101)) direct = true;
         if (!direct) m->need_convert = true;
     }
     if (m->output_node == m->input_node) m->need_convert = true;
@@ -979,6 +989,18 @@ int plan(th_model* m) {
                         st.label = n.name + ": " + (sn.blk ? label_note(conv_wf_label(fp, pre), " (input chunk-blocked)") : conv_wf_label(fp, pre));
                         st.run = [=](hipStream_t s, int64_t cnt) {
                             return launch_conv_wf(s, cnt, fp, M->view(src), M->view(dst), dw, dbias, pre, po);
+                        };
+                    } else if (mplans.count(i) && mplans[i].cfg == 101) {
+                        const ConvMfmaPlan mp = mplans[i];
+                        std::vector<float> packed(conv_first5_wpk_floats());
+                        conv_first5_pack_weights(Cin, Cout, hw, packed.data());
+                        float* dw;
+                        if ((rc = upload(M, packed.data(), packed.size(), &dw))) return rc;
+                        st.exec_flops = mp.exec_flops;
+                        st.label = n.name + ": " + mp.label;
+                        const ThKnobs* kn = mp.knobs;
+                        st.run = [=](hipStream_t s, int64_t cnt) {
+                            return launch_conv_first5(s, cnt, kn, M->cur_in, M->cur_dtype, Cin, M->view(dst), Cout, dw, dbias, po);
                         };
                     } else if (mplans.count(i) && mplans[i].cfg == 100) {
                         const ConvMfmaPlan mp = mplans[i];
@@ -1465,7 +1487,8 @@ constexpr double kGuardTol = 1e-5;
 bool has_fast_steps(const th_model* m) {
     for (const Step& s : m->steps)
         if (s.label.find("conv_wino") != std::string::npos || s.label.find("conv_wf<") != std::string::npos ||
-            s.label.find("k_conv_first_w") != std::string::npos || s.label.find("k_conv_first_b3") != std::string::npos)
+            s.label.find("k_conv_first_w") != std::string::npos || s.label.find("k_conv_first_b3") != std::string::npos ||
+            s.label.find("k_conv_first5") != std::string::npos)
             return true;
     return false;
 }
