@@ -121,6 +121,9 @@ __global__ void __launch_bounds__(512, 1) k_conv_wfs(const ConvWfsArgs a) {
         f = ok ? ff : a.nframes - 1;
     };
     const int nphases = my_units * a.nkh;
+    // (experiments, results right; ms per 4096 dense frames against 1.330 as shipped) 2048: the second-dispatched half of the workgroup
+    // at priority 1: 1.329; 4096 / 8192: interleave quotas of 5 / 12 VALU per MFMA instead of 8: 1.354 / 1.367; 32: no quota: 1.364
+    if ((DBG & 2048) && wave >= 4) __builtin_amdgcn_s_setprio(1);
 
     // ---- zero V (zero / dump records) and R (halo) once
     for (int k = tid; k < 2 * VBUF; k += 512) V4[k] = make_uint4(0u, 0u, 0u, 0u);
@@ -349,7 +352,8 @@ __global__ void __launch_bounds__(512, 1) k_conv_wfs(const ConvWfsArgs a) {
         //   groups 1..4: the next position's transform, a column of a 4-channel half per group          4 / 26 / 4 / 26 VALU
         //   group 5: fold of THIS step's first accumulator (complete after group 4)                     36 adds
 #define WFS_PIPE(V, L) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, V, 0); __builtin_amdgcn_sched_group_barrier(0x080, L, 0);
-#define WFS_SLOT { if (!(DBG & 32)) { WFS_PIPE(8, 2) WFS_PIPE(8, 2) WFS_PIPE(8, 2) WFS_PIPE(8, 2) WFS_PIPE(8, 2) WFS_PIPE(8, 2) } __builtin_amdgcn_sched_barrier(0); }
+#define WFS_P1 { if (DBG & 4096) { WFS_PIPE(5, 2) } else if (DBG & 8192) { WFS_PIPE(12, 3) } else { WFS_PIPE(8, 2) } }
+#define WFS_SLOT { if (!(DBG & 32)) { WFS_P1 WFS_P1 WFS_P1 WFS_P1 WFS_P1 WFS_P1 } __builtin_amdgcn_sched_barrier(0); }
         loadA1(0, 2); loadA1(0, 1); loadA1(0, 0);
         loadB(0, 0);
         if (tr) tr_issue(Next{}, 0, 0);
@@ -388,6 +392,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_wfs(const ConvWfsArgs a) {
             WFS_SLOT
         }
 #undef WFS_SLOT
+#undef WFS_P1
 #undef WFS_PIPE
         wfs_dma_wait();                                   // this wave's pieces of the next step's weights (and slice) have landed
         if (!(DBG & 1024)) __syncthreads();               // V / B of the next step complete
@@ -513,7 +518,7 @@ const WfsGeo kWfsGeo[] = {WFS_INST(10, 10, 10)};
 #undef WFS_INST
 struct WfsDbg { int code; WfsKernel k; };
 #define WFS_DBG(c) {c, k_conv_wfs<10, 10, 10, 1, c>}
-const WfsDbg kWfsDbg[] = {WFS_DBG(1), WFS_DBG(2), WFS_DBG(3), WFS_DBG(4), WFS_DBG(8), WFS_DBG(16), WFS_DBG(20), WFS_DBG(21), WFS_DBG(32), WFS_DBG(29), WFS_DBG(533), WFS_DBG(1045), WFS_DBG(1565), WFS_DBG(1024)};
+const WfsDbg kWfsDbg[] = {WFS_DBG(1), WFS_DBG(2), WFS_DBG(3), WFS_DBG(4), WFS_DBG(8), WFS_DBG(16), WFS_DBG(20), WFS_DBG(21), WFS_DBG(32), WFS_DBG(29), WFS_DBG(533), WFS_DBG(1045), WFS_DBG(1565), WFS_DBG(1024), WFS_DBG(2048), WFS_DBG(4096), WFS_DBG(8192), WFS_DBG(6144)};
 #undef WFS_DBG
 
 inline uint16_t wfs_bf16_rne(float f) {
