@@ -156,11 +156,11 @@ __global__ void __launch_bounds__(512, 1) k_conv_first5(const ConvF5Args a) {
     };
 
     // ---- per-lane row geometry of the wave's tiles: tile = wave + 8 k; row = 16 tile + i16 = 8 q + (dz2, dy2, dx2) ------------
-    const int ntiles = wave == 0 ? 4 : 3;
+    // tiles wave, wave + 8, wave + 16 are this wave's; tile 24 goes to wave (unit & 7) — a ninth of the SIMDs' imbalance of a fixed owner
     int rowbase[4], zsel[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int tile = std::min(wave + 8 * k, kF5Tiles - 1);
+        const int tile = k < 3 ? wave + 8 * k : kF5Tiles - 1;
         const int r = 16 * tile + i16, q = r >> 3, mm = r & 7;
         const int pyl = q / 10, px = q - 10 * pyl;
         rowbase[k] = (2 * pyl + ((mm >> 1) & 1)) * kF5X + 2 * px + (mm & 1);
@@ -203,30 +203,49 @@ __global__ void __launch_bounds__(512, 1) k_conv_first5(const ConvF5Args a) {
                 int base[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) base[t] = ((2 * pz + zsel[t] + dz) % kF5Ring) * kF5PlaneVox + rowbase[t];
+                // 21 items (k-step, own tile) of six MFMAs; the fragments of item it + 1 are requested before the MFMAs of item it and the
+                // items are fenced: left alone hipcc reads a fragment right in front of its first use and every item starts with an
+                // LDS round trip that only one other wave per SIMD can cover
+                bf16x8 Af[2][3], Bf[2][3];
+                auto loadA = [&](int t, int ks, int set) __attribute__((always_inline)) {
+                    const int ad = base[t] + koff[ks];
+                    Af[set][0] = __builtin_bit_cast(bf16x8, D3[ad]);
+                    Af[set][1] = __builtin_bit_cast(bf16x8, D3[kF5Piece + ad]);
+                    Af[set][2] = __builtin_bit_cast(bf16x8, D3[2 * kF5Piece + ad]);
+                };
+                auto loadB = [&](int ks, int set) __attribute__((always_inline)) {
 #pragma unroll
-                for (int ks = 0; ks < kF5KS; ++ks) {
-                    bf16x8 Bf[3];
+                    for (int pc = 0; pc < 3; ++pc) Bf[set][pc] = __builtin_bit_cast(bf16x8, Bc[(ks * 3 + pc) * 64]);
+                };
+                auto mma6 = [&](f32x4& c, const bf16x8 (&A)[3], const bf16x8 (&B)[3]) __attribute__((always_inline)) {
+                    if (DBG & 2) { c[0] += __builtin_bit_cast(float, __builtin_bit_cast(uint4, A[0]).x ^ __builtin_bit_cast(uint4, B[1]).y); return; }
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[2], B[0], c, 0, 0, 0);      // l H
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[1], B[0], c, 0, 0, 0);      // m H
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0], B[0], c, 0, 0, 0);      // h H
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[1], B[1], c, 0, 0, 0);      // m M
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0], B[1], c, 0, 0, 0);      // h M
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0], B[2], c, 0, 0, 0);      // h L
+                };
+                loadB(0, 0);
+                loadA(0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int pc = 0; pc < 3; ++pc) Bf[pc] = __builtin_bit_cast(bf16x8, Bc[(ks * 3 + pc) * 64]);
+                for (int it = 0; it < 3 * kF5KS; ++it) {
+                    const int ks = it / 3, t = it % 3;
+                    if (it + 1 < 3 * kF5KS) {
+                        const int nks = (it + 1) / 3, nt = (it + 1) % 3;
+                        if (nt == 0) loadB(nks, nks & 1);
+                        loadA(nt, nks, (it + 1) & 1);
+                    }
+                    mma6(acc[t], Af[it & 1], Bf[ks & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (wave == (u & 7)) {                        // tile 24
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        if (t < ntiles) {
-                            const int ad = base[t] + koff[ks];
-                            const bf16x8 Ah = __builtin_bit_cast(bf16x8, D3[ad]);
-                            const bf16x8 Am = __builtin_bit_cast(bf16x8, D3[kF5Piece + ad]);
-                            const bf16x8 Al = __builtin_bit_cast(bf16x8, D3[2 * kF5Piece + ad]);
-                            if (!(DBG & 2)) {
-                                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bf[0], acc[t], 0, 0, 0);      // l H
-                                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bf[0], acc[t], 0, 0, 0);      // m H
-                                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bf[0], acc[t], 0, 0, 0);      // h H
-                                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bf[1], acc[t], 0, 0, 0);      // m M
-                                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bf[1], acc[t], 0, 0, 0);      // h M
-                                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bf[2], acc[t], 0, 0, 0);      // h L
-                            } else {
-                                acc[t][0] += __builtin_bit_cast(float, __builtin_bit_cast(uint4, Ah).x ^ __builtin_bit_cast(uint4, Al).y ^
-                                                                        __builtin_bit_cast(uint4, Am).z ^ __builtin_bit_cast(uint4, Bf[ks % 3]).w);
-                            }
-                        }
+                    for (int ks = 0; ks < kF5KS; ++ks) {
+                        loadB(ks, 0);
+                        loadA(3, ks, 0);
+                        mma6(acc[3], Af[0], Bf[0]);
                     }
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the next weights (and the prefetched voxels)
@@ -235,7 +254,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_first5(const ConvF5Args a) {
             // ---- the unit's outputs: bias, (chain,) 2^3 max over a lane's four rows and its neighbour 16 lanes away, (chain,) store
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                if (t >= ntiles) continue;
+                if (t == 3 && wave != (u & 7)) continue;
                 float v[4] = {acc[t][0] + bv, acc[t][1] + bv, acc[t][2] + bv, acc[t][3] + bv};
                 if (!pool_first) {
 #pragma unroll
@@ -244,7 +263,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_first5(const ConvF5Args a) {
                 float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
                 mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
                 if (pool_first) mx = th_post(mx, cc, a.post);
-                const int tile = wave + 8 * t, q = 2 * tile + (kg >> 1);
+                const int tile = t < 3 ? wave + 8 * t : kF5Tiles - 1, q = 2 * tile + (kg >> 1);
                 const int pyl = q / 10, px = q - 10 * pyl;
                 if (cok && !(kg & 1)) outb[(int64_t)((pz * a.Ho + 5 * yh + pyl) * a.Wo + px) * a.out_cs] = mx;
             }
