@@ -136,6 +136,10 @@ def test_bad_sparse_blobs_are_refused_with_error_codes(gpu):
     assert call(bad) == _lib.TH_EINVAL                                   # another frame size than the model's
     bad = good.copy(); bad[32 + 8:32 + 16].view(np.uint64)[0] = 10 ** 9
     assert call(bad) == _lib.TH_EINVAL                                   # an impossible rank table
+    shifted = np.empty(good.nbytes + 32, np.uint8)
+    off = (-shifted.ctypes.data) % 16 + 8                                # 8 bytes off a 16-byte boundary
+    shifted[off:off + good.nbytes] = good
+    assert lib.th_predict_sparse_async(m._h, shifted.ctypes.data + off, good.nbytes, out.ctypes.data, 0, C.byref(t)) == _lib.TH_EINVAL
     assert call(good) == _lib.TH_OK
     _lib.check(lib.th_predict_wait(m._h, t.value))
     assert out.tobytes() == m.predict(sf.dense()).tobytes()

@@ -6,12 +6,12 @@
 // Direct form (125 taps: a minimal-filtering form would need 6 points per x pair and three times the staged data), products as
 // v_mfma_f32_16x16x32_bf16 on operands split exactly into three bf16 pieces, six of nine piece products, fp32 accumulation — the
 // scheme of conv_first_b3.hip / conv_wfsplit.hip, and like the latter the data is split ONCE, when it is staged:
-//   D3  [piece 3][ring of 6 planes][14 rows][25 x] x 16 bytes   a voxel's (<= 8) channels as one bf16x8 record per piece, zero halo
+//   D3  [piece 3][ring of 6 planes][14 rows][25 of 28 x] x 16 bytes   a voxel's (<= 8) channels as one bf16x8 record per piece, zero halo
 //   B   [2 buffers][7 k-steps][piece 3][lane 64] x 16 bytes     the weights of ONE z tap, LDS-DMA, double-buffered over the 5 z taps
 // A k-step (K = 32) is four voxel records: for a (dz, dy) row the taps dx = 0..3 (lane group kg <-> dx), and the fifth tap dx = 4
 // of four different dy rides in a "tail" k-step (kg <-> dy): 7 k-steps per z tap, 750 of 1120 k-slots useful.
 // Work unit = (frame, half of the y range, pooled z plane): 400 conv outputs = 25 tiles of 16 rows; a row is a MEMBER of a pool
-// window (row = 8 pooled voxel + (dz2, dy2, dx2)), so that a lane's four accumulator rows and its neighbour 16 lanes away hold
+// window (row = 8 pooled voxel + (dx2, dz2, dy2)), so that a lane's four accumulator rows and its neighbour 16 lanes away hold
 // one window.  One persistent 8-wave workgroup per CU walks frame -> y half -> pooled plane; consecutive planes share four of
 // their six input planes: the two new ones are requested when a unit starts and written (split) when it ends.
 #include "common.h"
@@ -31,9 +31,15 @@ namespace {
 
 constexpr int kF5D = 21;                       // frame extent
 constexpr int kF5X = 25, kF5Y = 14;            // staged x (-2 .. 22) and rows (y0 - 2 .. y0 + 11) of a plane half
-constexpr int kF5PlaneVox = kF5X * kF5Y;       // 350
+constexpr int kF5PlaneVox = kF5X * kF5Y;       // 350 staged voxels per plane half
+// LDS strides in records: a row is 28 records and a plane 392 (= 8 mod 16), and a tile row is 8 pooled voxel + (dx2, dz2, dy2):
+// with these the 16 lanes that one cycle of a ds_read_b128 serves (MI355X_MICROARCH.md §LDS) fall on 16 different 16-byte slots
+// of the 256-byte bank row in every k-step (or on the same record).  With the dense strides 25 / 350 and the order (dz2, dy2, dx2)
+// every A fragment read was a two-way bank conflict (5.60 -> 5.04 ms per 4096 frames).
+constexpr int kF5RS = 28, kF5PS = kF5Y * kF5RS;
+static_assert(kF5PS % 16 == 8, "plane stride");
 constexpr int kF5Ring = 6;
-constexpr int kF5Piece = kF5Ring * kF5PlaneVox;        // records per piece
+constexpr int kF5Piece = kF5Ring * kF5PS;              // records per piece
 constexpr int kF5KS = 7;                       // k-steps per z tap
 constexpr int kF5Frags = kF5KS * 3;            // B fragments per z tap
 constexpr int kF5Tiles = 25;
@@ -118,6 +124,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_first5(const ConvF5Args a) {
         D3[2 * kF5Piece + dst] = make_uint4(l[0], l[1], l[2], l[3]);
     };
     auto slot_of = [&](int z) { return (z + 2) % kF5Ring; };
+    auto lds_of = [&](int v) { const int row = v / kF5X; return row * kF5RS + (v - row * kF5X); };
     // the two planes z_lo, z_lo + 1 (700 voxels): requested here ...
     auto issue2 = [&](int64_t f, int yh, int z_lo) {
 #pragma unroll
@@ -127,7 +134,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_first5(const ConvF5Args a) {
             if (idx < 2 * kF5PlaneVox) {
                 const int pl = idx >= kF5PlaneVox ? 1 : 0, v = idx - pl * kF5PlaneVox;
                 load_voxel(f, yh, z_lo + pl, v, e[k]);
-                sdst[k] = slot_of(z_lo + pl) * kF5PlaneVox + v;
+                sdst[k] = slot_of(z_lo + pl) * kF5PS + lds_of(v);
             }
         }
     };
@@ -141,7 +148,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_first5(const ConvF5Args a) {
             const int pl = idx / kF5PlaneVox, v = idx - pl * kF5PlaneVox;
             float x[8];
             load_voxel(f, yh, z_lo + pl, v, x);
-            store_voxel(slot_of(z_lo + pl) * kF5PlaneVox + v, x);
+            store_voxel(slot_of(z_lo + pl) * kF5PS + lds_of(v), x);
         }
     };
     // weights of z tap dz into buffer `buf`: 21 wave-wide 1 KB loads, three per wave (the ragged third round repeats the second)
@@ -155,7 +162,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_first5(const ConvF5Args a) {
         }
     };
 
-    // ---- per-lane row geometry of the wave's tiles: tile = wave + 8 k; row = 16 tile + i16 = 8 q + (dz2, dy2, dx2) ------------
+    // ---- per-lane row geometry of the wave's tiles: tile = wave + 8 k; row = 16 tile + i16 = 8 q + (dx2, dz2, dy2) ------------
     // tiles wave, wave + 8, wave + 16 are this wave's; tile 24 goes to wave (unit & 7) — a ninth of the SIMDs' imbalance of a fixed owner
     int rowbase[4], zsel[4];
 #pragma unroll
@@ -163,13 +170,13 @@ __global__ void __launch_bounds__(512, 1) k_conv_first5(const ConvF5Args a) {
         const int tile = k < 3 ? wave + 8 * k : kF5Tiles - 1;
         const int r = 16 * tile + i16, q = r >> 3, mm = r & 7;
         const int pyl = q / 10, px = q - 10 * pyl;
-        rowbase[k] = (2 * pyl + ((mm >> 1) & 1)) * kF5X + 2 * px + (mm & 1);
-        zsel[k] = mm >> 2;
+        rowbase[k] = (2 * pyl + (mm & 1)) * kF5RS + 2 * px + (mm >> 2);
+        zsel[k] = (mm >> 1) & 1;
     }
     // k-step offsets (records): main k-step ks = dy: + dy 25 + kg; tail 5: dy = kg, dx = 4; tail 6: dy = 4, dx = 4 (kg 0 only)
     int koff[kF5KS];
 #pragma unroll
-    for (int ks = 0; ks < kF5KS; ++ks) koff[ks] = ks < 5 ? ks * kF5X + kg : (ks == 5 ? kg * kF5X + 4 : 4 * kF5X + 4);
+    for (int ks = 0; ks < kF5KS; ++ks) koff[ks] = ks < 5 ? ks * kF5RS + kg : (ks == 5 ? kg * kF5RS + 4 : 4 * kF5RS + 4);
 
     const int co = i16;
     const bool cok = co < a.Cout;
@@ -202,7 +209,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_first5(const ConvF5Args a) {
                 const uint4* const Bc = (buf ? Bb : Ba) + lane;
                 int base[4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) base[t] = ((2 * pz + zsel[t] + dz) % kF5Ring) * kF5PlaneVox + rowbase[t];
+                for (int t = 0; t < 4; ++t) base[t] = ((2 * pz + zsel[t] + dz) % kF5Ring) * kF5PS + rowbase[t];
                 // 21 items (k-step, own tile) of six MFMAs; the fragments of item it + 1 are requested before the MFMAs of item it and the
                 // items are fenced: left alone hipcc reads a fragment right in front of its first use and every item starts with an
                 // LDS round trip that only one other wave per SIMD can cover

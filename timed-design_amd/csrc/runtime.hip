@@ -2005,6 +2005,7 @@ int th_predict_sparse_async(th_model* m, const void* blob, size_t blob_bytes, fl
     if (!m || !ticket || !blob) TH_FAIL(TH_EINVAL, "null argument");
     if (flags & TH_PREDICT_IN_DEVICE) TH_FAIL(TH_EINVAL, "a sparse batch is host memory");
     const char* const b = (const char*)blob;
+    if ((uintptr_t)blob % 16) TH_FAIL(TH_EINVAL, "sparse batch: the blob is not 16-byte aligned");
     if (blob_bytes < 32 || std::memcmp(b, TH_SPARSE_MAGIC, 8)) TH_FAIL(TH_EINVAL, "not a THSPF001 sparse frame batch");
     uint32_t n32, E, W, esz;
     uint64_t nval;
