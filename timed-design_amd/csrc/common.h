@@ -45,6 +45,7 @@ struct ThKnobs {
     int guard = 1;             // TH_GUARD: load-time check of the fast plans against the direct fp32 plan (0: off)
     int first_wino = 1;        // TH_FIRST_WINO=0: k_conv_first instead of k_conv_first_w
     int first_split = 1;       // TH_FIRST_SPLIT: the aposteriori first layer on bf16 MFMA with exactly split operands (conv_first_b3.hip)
+    int dense_gemm = 1;        // TH_DENSE_GEMM: Dense layers of >= 64 features and 8..128 outputs as a batch GEMM on fp32 MFMA (dense_gemm.hip)
     int first_int = 1;         // TH_FIRST_INT: uint8 / bool frames on the one-piece form of conv_first_b3 (0: the general six-product kernel)
     int first_zb = 0;          // TH_FIRST_ZB: brick depth of the first-layer kernel (tuning)
     int first_dbg = 0;         // TH_FIRST_DBG: timing knock-outs (results wrong)
@@ -130,6 +131,9 @@ int launch_eltwise(hipStream_t s, int64_t n, TView in, TView out, PostOps ops);
 int launch_global_pool(hipStream_t s, int64_t n, TView in, TView out, int is_max);
 // dense on a contiguous [n, F] input (in.C = F, V = 1); weights [F, out]
 int launch_dense(hipStream_t s, int64_t n, TView in, TView out, const float* w, const float* bias, PostOps post);
+// dense_gemm.hip: the same layer as one fp32-MFMA GEMM over the batch
+bool dense_gemm_ok(int F, int O, int64_t xfs);
+int launch_dense_gemm(hipStream_t s, int64_t n, TView in, TView out, const float* w, const float* bias, PostOps post);
 int launch_softmax(hipStream_t s, int64_t n, TView in, TView out);
 // GlobalAveragePooling3D -> Softmax in one launch (<= 512 channels): writes the pooled logits and the probabilities
 int launch_gap_softmax(hipStream_t s, int64_t n, TView in, TView logits, TView probs);

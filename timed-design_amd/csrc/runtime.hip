@@ -68,6 +68,7 @@ void th_knobs_read(ThKnobs* k) {
     num("TH_FIRST_WINO", &k->first_wino, 0, 1);
     num("TH_FIRST_SPLIT", &k->first_split, 0, 1);
     num("TH_FIRST_INT", &k->first_int, 0, 1);
+    num("TH_DENSE_GEMM", &k->dense_gemm, 0, 1);
     num("TH_FIRST_ZB", &k->first_zb, 0, 1 << 20);
     num("TH_FIRST_DBG", &k->first_dbg, 0, 1 << 20);
     flag("TH_NO_POOL_FIRST", &k->no_pool_first);
@@ -1128,8 +1129,13 @@ int plan(th_model* m) {
                     if ((rc = upload(M, hw, (size_t)F * O, &dw))) return rc;
                     st.flops = st.exec_flops = 2.0 * F * O;
                     st.bytes = 4.0 * (F + O);
-                    st.label = n.name + ": dense";
-                    st.run = [=](hipStream_t s, int64_t cnt) { return launch_dense(s, cnt, M->view(src), M->view(dst), dw, dbias, po); };
+                    if (th_knobs_planning().dense_gemm && dense_gemm_ok(F, O, (int64_t)M->bufs[sn.buf].floats_per_frame)) {
+                        st.label = n.name + ": dense as a batch GEMM, 16 frames x all outputs per workgroup, F in four quarters (16x16x4 fp32 MFMA) [k_dense_gemm]";
+                        st.run = [=](hipStream_t s, int64_t cnt) { return launch_dense_gemm(s, cnt, M->view(src), M->view(dst), dw, dbias, po); };
+                    } else {
+                        st.label = n.name + ": dense";
+                        st.run = [=](hipStream_t s, int64_t cnt) { return launch_dense(s, cnt, M->view(src), M->view(dst), dw, dbias, po); };
+                    }
                 }
                 if (n.op == OP_CONV3D) {
                     // a 3x3x3 stride-1 layer that stays on a direct kernel says why no minimal-filtering form took it (tools/plan_report.py)
