@@ -45,6 +45,7 @@ struct ThKnobs {
     int guard = 1;             // TH_GUARD: load-time check of the fast plans against the direct fp32 plan (0: off)
     int first_wino = 1;        // TH_FIRST_WINO=0: k_conv_first instead of k_conv_first_w
     int first_split = 1;       // TH_FIRST_SPLIT: the aposteriori first layer on bf16 MFMA with exactly split operands (conv_first_b3.hip)
+    int conv_gl = 1;           // TH_CONV_GL: 1 strided convolutions and those with <= 64 outputs per frame on conv_gl.hip (2: every eligible layer, 0: none)
     int dense_gemm = 1;        // TH_DENSE_GEMM: Dense layers of >= 64 features and 8..128 outputs as a batch GEMM on fp32 MFMA (dense_gemm.hip)
     int first_int = 1;         // TH_FIRST_INT: uint8 / bool frames on the one-piece form of conv_first_b3 (0: the general six-product kernel)
     int first_zb = 0;          // TH_FIRST_ZB: brick depth of the first-layer kernel (tuning)
@@ -131,6 +132,14 @@ int launch_eltwise(hipStream_t s, int64_t n, TView in, TView out, PostOps ops);
 int launch_global_pool(hipStream_t s, int64_t n, TView in, TView out, int is_max);
 // dense on a contiguous [n, F] input (in.C = F, V = 1); weights [F, out]
 int launch_dense(hipStream_t s, int64_t n, TView in, TView out, const float* w, const float* bias, PostOps post);
+// conv_gl.hip: small-volume / strided convolutions as an implicit GEMM with rows across the batch, operands straight from L2
+inline bool conv_gl_wanted(int knob, const ConvGeom& g, int Vo) { return knob == 2 || (knob == 1 && (g.sd > 1 || g.sh > 1 || g.sw > 1 || Vo <= 64)); }
+bool conv_gl_ok(int Cin, int Cout, int in_cs, int in_coff, int64_t in_fs);
+size_t conv_gl_wpk_floats(const ConvGeom& g, int Cin, int Cout);
+double conv_gl_exec_flops(const ConvGeom& g, int Cin, int Cout, int Vo);
+std::string conv_gl_label(int Cout);
+void conv_gl_pack_weights(const ConvGeom& g, int Cin, int Cout, const float* w, float* dst);
+int launch_conv_gl(hipStream_t s, int64_t n, TView in, TView out, ConvGeom g, int Cin, int Cout, const float* wpk, const float* bias, PostOps post);
 // dense_gemm.hip: the same layer as one fp32-MFMA GEMM over the batch
 bool dense_gemm_ok(int F, int O, int64_t xfs);
 int launch_dense_gemm(hipStream_t s, int64_t n, TView in, TView out, const float* w, const float* bias, PostOps post);

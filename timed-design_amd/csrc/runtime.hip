@@ -69,6 +69,7 @@ void th_knobs_read(ThKnobs* k) {
     num("TH_FIRST_SPLIT", &k->first_split, 0, 1);
     num("TH_FIRST_INT", &k->first_int, 0, 1);
     num("TH_DENSE_GEMM", &k->dense_gemm, 0, 1);
+    num("TH_CONV_GL", &k->conv_gl, 0, 2);
     num("TH_FIRST_ZB", &k->first_zb, 0, 1 << 20);
     num("TH_FIRST_DBG", &k->first_dbg, 0, 1 << 20);
     flag("TH_NO_POOL_FIRST", &k->no_pool_first);
@@ -1060,6 +1061,17 @@ int plan(th_model* m) {
                         st.run = [=](hipStream_t s, int64_t cnt) {
                             return launch_conv_pw(s, cnt, mp, M->view(src), M->view(dst), Cin, Cout, dw, dbias, pre, po);
                         };
+                    } else if (conv_gl_wanted(M->knobs.conv_gl, g, n.D * n.H * n.W) && f.pool < 0 && f.pre.empty() && !sn.blk && !N[dst].blk &&
+                               (!mplans.count(i) || mplans[i].cfg < 100) &&
+                               conv_gl_ok(Cin, Cout, sn.cs, sn.coff, (int64_t)M->bufs[sn.buf].floats_per_frame)) {
+                        // strided / few-outputs-per-frame layers: implicit GEMM with rows across the batch, operands from L2 (conv_gl.hip)
+                        std::vector<float> packed(conv_gl_wpk_floats(g, Cin, Cout));
+                        conv_gl_pack_weights(g, Cin, Cout, hw, packed.data());
+                        float* dw;
+                        if ((rc = upload(M, packed.data(), packed.size(), &dw))) return rc;
+                        st.exec_flops = conv_gl_exec_flops(g, Cin, Cout, n.D * n.H * n.W);
+                        st.label = n.name + ": " + conv_gl_label(Cout);
+                        st.run = [=](hipStream_t s, int64_t cnt) { return launch_conv_gl(s, cnt, M->view(src), M->view(dst), g, Cin, Cout, dw, dbias, po); };
                     } else if (mplans.count(i)) {
                         ConvMfmaPlan mp = mplans[i];
                         // heterogeneous Cout blocks: the last, mostly empty 128-column block on a narrower instantiation

@@ -50,21 +50,22 @@ class KerasGraphBuilder:
         return -(-n // s) if same else (n - k) // s + 1
 
     # -- layers -----------------------------------------------------------------------------
-    def conv3d(self, x, filters, k=3, strides=1, padding="same", activation="linear", use_bias=True):
+    def conv3d(self, x, filters, k=3, strides=1, padding="same", activation="linear", use_bias=True, dilation_rate=1):
         d, h, w, cin = self.shapes[x]
         same = padding == "same"
         ks = (k, k, k) if isinstance(k, int) else tuple(k)   # anisotropic kernels allowed: k=(3, 1, 3)
+        st = (strides,) * 3 if isinstance(strides, int) else tuple(strides)
+        dl = (dilation_rate,) * 3 if isinstance(dilation_rate, int) else tuple(dilation_rate)
         fan_in = ks[0] * ks[1] * ks[2] * cin
         kern = (self.rng.standard_normal((*ks, cin, filters)) * np.sqrt(2.0 / fan_in)).astype(np.float32)
         ws = [kern]
         if use_bias:
             ws.append((self.rng.standard_normal(filters) * self.bias_std).astype(np.float32))
-        shape = (self._out(d, ks[0], strides, same), self._out(h, ks[1], strides, same), self._out(w, ks[2], strides, same),
-                 filters)
+        shape = tuple(self._out(n, (kk - 1) * dd + 1, ss, same) for n, kk, ss, dd in zip((d, h, w), ks, st, dl)) + (filters,)
         name = self._emit("Conv3D", "conv3d",
-                          dict(filters=filters, kernel_size=list(ks), strides=[strides] * 3, padding=padding,
-                               data_format="channels_last", dilation_rate=[1, 1, 1], groups=1,
-                               activation=activation, use_bias=use_bias, trainable=True, dtype="float32"),
+                          dict(filters=filters, kernel_size=list(ks), strides=list(st), padding=padding,
+                               data_format="channels_last", dilation_rate=list(dl), groups=1,
+                               activation=activation or "linear", use_bias=use_bias, trainable=True, dtype="float32"),
                           [x], shape)
         self.weights[name] = ws
         return name
