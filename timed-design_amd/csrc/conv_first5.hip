@@ -79,6 +79,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_first5(const ConvF5Args a) {
     __shared__ __attribute__((aligned(16))) uint4 D3[3 * kF5Piece];
     __shared__ __attribute__((aligned(16))) uint4 Ba[kF5Frags * 64];
     __shared__ __attribute__((aligned(16))) uint4 Bb[kF5Frags * 64];
+    __shared__ __attribute__((aligned(16))) f32x4 Px[kF5KS * 64];         // tile 24's partial sums, one per k-step owner
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -163,7 +164,9 @@ __global__ void __launch_bounds__(512, 1) k_conv_first5(const ConvF5Args a) {
     };
 
     // ---- per-lane row geometry of the wave's tiles: tile = wave + 8 k; row = 16 tile + i16 = 8 q + (dx2, dz2, dy2) ------------
-    // tiles wave, wave + 8, wave + 16 are this wave's; tile 24 goes to wave (unit & 7) — a ninth of the SIMDs' imbalance of a fixed owner
+    // tiles wave, wave + 8, wave + 16 are this wave's; tile 24 (k = 3) is nobody's: wave w < 7 runs its k-step w in every phase (22 items
+    // per wave and phase instead of 21 and 28 on one, for which the other seven waited at the phase's barrier: MFMA busy was 57 %), the
+    // seven partial sums meet in LDS when the unit ends and wave 7 adds them in a fixed order
     int rowbase[4], zsel[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -246,22 +249,29 @@ __global__ void __launch_bounds__(512, 1) k_conv_first5(const ConvF5Args a) {
                     }
                     mma6(acc[t], Af[it & 1], Bf[ks & 1]);
                     __builtin_amdgcn_sched_barrier(0);
-                }
-                if (wave == (u & 7)) {                        // tile 24
-#pragma unroll
-                    for (int ks = 0; ks < kF5KS; ++ks) {
-                        loadB(ks, 0);
-                        loadA(3, ks, 0);
-                        mma6(acc[3], Af[0], Bf[0]);
+                    if (t == 2 && wave == ks) {               // this wave's k-step of tile 24, with the weights it holds anyway
+                        bf16x8 Ax[3];
+                        const int ad = base[3] + koff[ks];
+                        Ax[0] = __builtin_bit_cast(bf16x8, D3[ad]);
+                        Ax[1] = __builtin_bit_cast(bf16x8, D3[kF5Piece + ad]);
+                        Ax[2] = __builtin_bit_cast(bf16x8, D3[2 * kF5Piece + ad]);
+                        mma6(acc[3], Ax, Bf[ks & 1]);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
+                if (dz == 4 && wave < kF5KS) Px[wave * 64 + lane] = acc[3];
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the next weights (and the prefetched voxels)
                 __syncthreads();                                       // everybody is done with this phase's buffer and, after dz = 4, the planes
+            }
+            if (wave == kF5KS) {
+                acc[3] = Px[lane];
+#pragma unroll
+                for (int w = 1; w < kF5KS; ++w) acc[3] += Px[w * 64 + lane];
             }
             // ---- the unit's outputs: bias, (chain,) 2^3 max over a lane's four rows and its neighbour 16 lanes away, (chain,) store
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                if (t == 3 && wave != (u & 7)) continue;
+                if (t == 3 && wave != kF5KS) continue;
                 float v[4] = {acc[t][0] + bv, acc[t][1] + bv, acc[t][2] + bv, acc[t][3] + bv};
                 if (!pool_first) {
 #pragma unroll
