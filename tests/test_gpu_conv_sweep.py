@@ -187,14 +187,18 @@ def test_first_block_pools_before_a_monotone_epilogue_only(gpu, monkeypatch, neg
     ((9, 9, 9), 16, 20, 3, 2, "same"), ((10, 9, 8), 24, 48, 3, 2, "valid"), ((11, 11, 11), 6, 32, 3, 2, "same"),
     ((12, 10, 9), 5, 40, 5, 2, "same"), ((9, 9, 9), 32, 64, 3, 3, "same"), ((8, 8, 8), 48, 16, 1, 2, "same"),
 ])
-def test_strided_convolutions_on_the_brick_kernel(gpu, shape, cin, cout, k, stride, padding):
+def test_strided_convolutions_on_the_brick_kernel(gpu, monkeypatch, shape, cin, cout, k, stride, padding):
     """stride > 1 (ProDCoNN-style down-sampling convolutions): the brick kernel's row table carries the stride, the
-    staged brick covers (n-1)*s + k input planes; Keras 'same' padding with a stride is asymmetric."""
+    staged brick covers (n-1)*s + k input planes; Keras 'same' padding with a stride is asymmetric.  Since round 6 the strided
+    layers with Cin % 16 == 0 go to conv_gl.hip by default: both kernels are held to the oracle here."""
     def build(b, x):
         return b.elu(b.conv3d(x, cout, k, strides=stride, padding=padding))
 
     cfg, weights = _net(shape, cin, build, seed=41)
     frames = _frames(5, shape, cin, 9)
+    labels = _check(cfg, weights, frames)
+    assert any(("conv_gl" if cin % 16 == 0 else "conv_mfma") in l for l in labels), labels
+    monkeypatch.setenv("TH_CONV_GL", "0")
     labels = _check(cfg, weights, frames)
     assert any("conv_mfma" in l for l in labels), labels
     _check(cfg, weights, frames, chunk=2)

@@ -1,7 +1,6 @@
 """Dense behind Flatten as one batch GEMM on the fp32 matrix pipe (csrc/dense_gemm.hip: 16 frames x all outputs per workgroup,
 the features in four quarters, v_mfma_f32_16x16x4_f32) against the CPU oracle and against the kernel it replaces (k_dense,
-TH_DENSE_GEMM=0): output counts that are not multiples of 16, feature counts that are not multiples of 16 (the last block of a
-quarter is partly beyond the end), batches that are not multiples of 16 frames, fused activations behind it, and the
+TH_DENSE_GEMM=0): output counts that are not multiples of 16, feature counts that are not multiples of 16 or 64 (ragged quarters, a last block partly beyond the end), batches that are not multiples of 16 frames, fused activations behind it, and the
 layers it does not take.  Serves reference predict.py:142 (ProDCoNN's Flatten -> Dense(relu) -> Dense(softmax))."""
 import numpy as np
 import pytest
@@ -32,10 +31,10 @@ def _run(cfg, w, x, chunk=None):
 
 # (input shape, Dense widths, activation, frames)
 CASES = [
-    ((3, 3, 3, 64), (96, 20), "relu", 37),          # ProDCoNN's head: 1728 -> 96 -> 20
-    ((5, 5, 5, 4), (33, 20), "elu", 16),            # 500 features (31.25 blocks of 16), 33 outputs (three tiles, one column in the last)
-    ((2, 2, 2, 8), (128, 8), "tanh", 5),            # 64 features (one block per quarter), 128 outputs; then 128 -> 8
-    ((1, 1, 4, 17), (100, 338), "relu", 49),        # 68 features; the 338-way layer stays on k_dense (> 128 outputs)
+    ((3, 3, 3, 64), (96, 20), "relu", 37),          # ProDCoNN's head: 1728 -> 96 (-> 20 on k_dense)
+    ((5, 5, 5, 8), (33, 20), "elu", 16),            # 1000 features (62.5 blocks of 16), 33 outputs (three tiles, one column in the last)
+    ((4, 4, 4, 8), (128, 8), "tanh", 5),            # 512 features (8 blocks per quarter), 128 outputs
+    ((1, 4, 8, 17), (100, 338), "relu", 49),        # 544 features (34 blocks: ragged quarters); the 338-way layer stays on k_dense
 ]
 
 
@@ -58,8 +57,8 @@ def test_dense_gemm_per_element(gpu, monkeypatch, shape, outs, act, n):
 
 
 def test_layers_the_gemm_does_not_take(gpu):
-    """fewer than 64 features, fewer than 8 or more than 128 outputs, a feature count that is not a multiple of 4: k_dense"""
-    for shape, outs in (((1, 1, 1, 48), (32, 20)), ((2, 2, 2, 16), (4, 20)), ((1, 1, 2, 65), (16, 20)), ((2, 2, 2, 16), (200, 20))):
+    """fewer than 512 features, fewer than 8 or more than 128 outputs, a feature count that is not a multiple of 4: k_dense"""
+    for shape, outs in (((1, 1, 4, 64), (32, 20)), ((4, 4, 4, 8), (4, 20)), ((1, 1, 9, 65), (16, 20)), ((4, 4, 4, 8), (200, 20))):
         cfg, w = _net(shape, outs, "relu", seed=3)
         x = np.random.default_rng(1).standard_normal((6, *shape)).astype(np.float32)
         got, labels = _run(cfg, w, x)

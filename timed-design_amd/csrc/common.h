@@ -46,7 +46,7 @@ struct ThKnobs {
     int first_wino = 1;        // TH_FIRST_WINO=0: k_conv_first instead of k_conv_first_w
     int first_split = 1;       // TH_FIRST_SPLIT: the aposteriori first layer on bf16 MFMA with exactly split operands (conv_first_b3.hip)
     int conv_gl = 1;           // TH_CONV_GL: 1 strided convolutions and those with <= 64 outputs per frame on conv_gl.hip (2: every eligible layer, 0: none)
-    int dense_gemm = 1;        // TH_DENSE_GEMM: Dense layers of >= 64 features and 8..128 outputs as a batch GEMM on fp32 MFMA (dense_gemm.hip)
+    int dense_gemm = 1;        // TH_DENSE_GEMM: Dense layers of >= 512 features and 8..128 outputs as a batch GEMM on fp32 MFMA (dense_gemm.hip)
     int first_int = 1;         // TH_FIRST_INT: uint8 / bool frames on the one-piece form of conv_first_b3 (0: the general six-product kernel)
     int first_zb = 0;          // TH_FIRST_ZB: brick depth of the first-layer kernel (tuning)
     int first_dbg = 0;         // TH_FIRST_DBG: timing knock-outs (results wrong)

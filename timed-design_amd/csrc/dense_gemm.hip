@@ -95,7 +95,8 @@ __global__ void __launch_bounds__(256) k_dense_gemm(const DenseGemmArgs a) {
 }  // namespace
 
 // plan time: F features (contiguous per frame, frames xfs floats apart), O outputs
-bool dense_gemm_ok(int F, int O, int64_t xfs) { return F >= 64 && F % 4 == 0 && xfs % 4 == 0 && O >= 8 && O <= 128; }
+// (F >= 512: below that k_dense costs microseconds, and the one-launch tails of kernels_generic.hip promise k_dense's bits)
+bool dense_gemm_ok(int F, int O, int64_t xfs) { return F >= 512 && F % 4 == 0 && xfs % 4 == 0 && O >= 8 && O <= 128; }
 
 int launch_dense_gemm(hipStream_t s, int64_t n, TView in, TView out, const float* w, const float* bias, PostOps post) {
     if (n <= 0) return TH_OK;

@@ -23,7 +23,7 @@ python tools/rocpd_summary.py --kernel-trace "$KT" --pmc FETCH_SIZE="$FE" --pmc 
     --json "$OUT/pmc_latest.json" > "$OUT/summary.txt" 2> "$OUT/summary.err"
 [ -n "$SQ" ] && python tools/pmc_table.py "$SQ" > "$OUT/sq_table.txt" 2>> "$OUT/summary.err"
 # every plan step's roofline fraction recomputed from a kernel trace alone (FLOPs x frames / avg us / 157.3)
-timeout 600 python tools/roofline_table.py --chunk 4096 --reps 5 timed densecpd timed_rotamer > "$OUT/roofline_table.txt" 2>> "$OUT/summary.err"
+timeout 600 python tools/roofline_table.py --chunk 4096 --reps 5 timed densecpd timed_rotamer prodconn > "$OUT/roofline_table.txt" 2>> "$OUT/summary.err"
 # BASELINE config 5 (the sampler) under the kernel trace
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/sampler" -o sampler -- python $ROOT/tools/bench_sampler.py > "$OUT/sampler_bench.json" 2> "$OUT/sampler.log"
