@@ -24,7 +24,7 @@ for k in range(2):
 PY
 cd /tmp
 python /tmp/run_sparse.py $ROOT 2>&1 | grep -v Predicting
-rocprofv3 --kernel-trace --memory-copy-trace --stats -d $OUT/prof -o sp -- python /tmp/run_sparse.py $ROOT > $OUT/prof.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o sp -- python /tmp/run_sparse.py $ROOT > $OUT/prof.log 2>&1
 F=$(find $OUT/prof -name '*kernel_stats.csv' | head -1); head -20 $F | cut -c1-160
 F2=$(find $OUT/prof -name '*memory_copy_stats.csv' | head -1); head -8 $F2 | cut -c1-160
 rm -rf $OUT/prof/*.db $OUT/prof/*/*.db
