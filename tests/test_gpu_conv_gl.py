@@ -90,3 +90,31 @@ def test_default_rule_and_layers_it_leaves_alone(gpu):
         assert not any("k_conv_gl" in l for l in labels), labels
         want = cnn_oracle.forward(cfg, w, x, np.float64)
         assert float(np.abs(got - want).max()) <= 2e-5 * max(1.0, float(np.abs(want).max()))
+
+
+def test_conv_gl_random_geometries(gpu, monkeypatch):
+    """thirty seeded draws of (extent, kernel, stride, dilation, padding, Cin in {16, 32, 48}, 1..128 filters, 1..9 frames): every one
+    within 5e-6 x scale of the float64 oracle, on the kernel whenever the layer is eligible"""
+    monkeypatch.setenv("TH_CONV_GL", "2")
+    rng = np.random.default_rng(2024)
+    ran = 0
+    for case in range(30):
+        shape = tuple(int(v) for v in rng.integers(3, 10, 3))
+        k = tuple(int(v) for v in rng.integers(1, 5, 3))
+        st = tuple(int(v) for v in rng.integers(1, 4, 3))
+        dl = tuple(int(v) for v in rng.integers(1, 3, 3)) if case % 3 == 0 else (1, 1, 1)
+        if any(d > 1 for d in dl):
+            st = (1, 1, 1)                                              # Keras: strides and dilation do not combine
+        padding = "same" if case % 2 else "valid"
+        if padding == "valid" and any((kk - 1) * dd + 1 > n for kk, dd, n in zip(k, dl, shape)):
+            padding = "same"
+        cin, cout, n = int(rng.choice([16, 32, 48])), int(rng.integers(1, 129)), int(rng.integers(1, 10))
+        kw = dict(filters=cout, kernel_size=k, strides=st, dilation_rate=dl, padding=padding)
+        cfg, w = _net((*shape, cin), _build(kw, ("none", "elu", "relu_bn")[case % 3]), seed=case)
+        x = rng.standard_normal((n, *shape, cin)).astype(np.float32)
+        want = cnn_oracle.forward(cfg, w, x, np.float64)
+        got, labels = _run(cfg, w, x)
+        ran += any("k_conv_gl" in l for l in labels)
+        assert got.shape == want.shape, (case, kw, shape)
+        assert float(np.abs(got - want).max()) <= 5e-6 * max(1.0, float(np.abs(want).max())), (case, kw, shape, cin, n, labels)
+    assert ran >= 20, ran
