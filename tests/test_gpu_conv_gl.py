@@ -74,6 +74,29 @@ def test_conv_gl_per_element(gpu, monkeypatch, shape, kw, chain, n):
     assert float(np.abs(got - want).max()) <= 1.5 * float(np.abs(ref - want).max()) + 2e-7 * scale
 
 
+@pytest.mark.parametrize("act", ["relu", "elu", None])
+def test_conv_gl_input_prologue(gpu, monkeypatch, act):
+    """BN -> activation in FRONT of the convolution (DenseCPD's growth layers; here on the model input, where no producer can absorb
+    it): applied to the loaded voxels in registers, and the 'same' padding pads the ACTIVATED tensor — zeros, not act(shift)"""
+    monkeypatch.setenv("TH_CONV_GL", "2")
+
+    def build(b, x):
+        x = b.batchnorm(x)
+        if act:
+            x = b.activation(x, act)
+        return b.conv3d(x, 24, 3, strides=2, padding="same")
+
+    cfg, w = _net((6, 5, 4, 32), build, seed=12)
+    x = np.random.default_rng(3).standard_normal((5, 6, 5, 4, 32)).astype(np.float32)
+    want = cnn_oracle.forward(cfg, w, x, np.float64)
+    got, labels = _run(cfg, w, x)
+    assert any("k_conv_gl" in l for l in labels), labels
+    assert float(np.abs(got - want).max()) <= 5e-6 * max(1.0, float(np.abs(want).max()))
+    monkeypatch.setenv("TH_CONV_GL", "0")
+    ref, _ = _run(cfg, w, x)
+    assert float(np.abs(got - ref).max()) <= 3e-6 * max(1.0, float(np.abs(ref).max()))
+
+
 def test_default_rule_and_layers_it_leaves_alone(gpu):
     """by default: strided layers and those with at most 64 outputs per frame; a stride-1 'same' layer on 10^3 keeps its kernel, and
     so does one whose Cin is not a multiple of 16"""

@@ -139,7 +139,7 @@ size_t conv_gl_wpk_floats(const ConvGeom& g, int Cin, int Cout);
 double conv_gl_exec_flops(const ConvGeom& g, int Cin, int Cout, int Vo);
 std::string conv_gl_label(int Cout);
 void conv_gl_pack_weights(const ConvGeom& g, int Cin, int Cout, const float* w, float* dst);
-int launch_conv_gl(hipStream_t s, int64_t n, TView in, TView out, ConvGeom g, int Cin, int Cout, const float* wpk, const float* bias, PostOps post);
+int launch_conv_gl(hipStream_t s, int64_t n, TView in, TView out, ConvGeom g, int Cin, int Cout, const float* wpk, const float* bias, PreOp pre, PostOps post);
 // dense_gemm.hip: the same layer as one fp32-MFMA GEMM over the batch
 bool dense_gemm_ok(int F, int O, int64_t xfs);
 int launch_dense_gemm(hipStream_t s, int64_t n, TView in, TView out, const float* w, const float* bias, PostOps post);

@@ -5,7 +5,8 @@
 // GEMM rows are output voxels numbered across the whole batch (row = frame x Vo + voxel: tiles do not stop at a frame's end), a wave
 // owns 32 rows (two 16-row tiles) x all output channels (<= 8 tiles of 16 columns) and walks K = taps x 16-channel blocks with
 // v_mfma_f32_16x16x4_f32.  Per block a lane reads ONE float4 per row tile — channels 4 kq .. 4 kq + 3 of its row's input voxel
-// under the tap (a row's 16 channels are 64 contiguous bytes, padding reads as zero by predication) — and one float4 per column
+// under the tap (a row's 16 channels are 64 contiguous bytes, padding reads as zero by predication; an input
+// prologue BN -> activation is applied to the loaded values in registers) — and one float4 per column
 // tile from the prepacked weights (lane-contiguous, 1 KB per wave load); element s of both feeds MFMA step s, so the k order inside
 // a block is (kq, s) on both sides.  A frame's input (128 KB at most here) is read 27/8 times by the four waves that share it and
 // the weights by every wave: both live in L2 / L1.  Three blocks are in flight per wave and several waves per SIMD cover the rest.
@@ -26,11 +27,12 @@ struct ConvGlArgs {
     int ncb;                          // 16-channel blocks of Cin
     const float4* wpk;                // [tap][block][column tile][lane] x 4
     const float* bias; PostOps post;
+    PreOp pre;                        // BN -> activation in front of the convolution (DenseCPD), applied to real voxels only
     float* out; int64_t out_fs; int out_cs, out_coff, Cout;
     int64_t rows;                     // frames x Do Ho Wo
 };
 
-template <int NT>
+template <int NT, bool PRE>
 __global__ void __launch_bounds__(256) k_conv_gl(const ConvGlArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i16 = lane & 15, kq = lane >> 4;
@@ -57,7 +59,7 @@ __global__ void __launch_bounds__(256) k_conv_gl(const ConvGlArgs a) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    struct Blk { float4 x[2]; float4 w[NT]; };
+    struct Blk { float4 x[2]; float4 w[NT]; float4 sc, sh; bool ok[2]; };
     Blk R[3];
     int dz = 0, dy = 0, dx = 0, cb = 0;                      // the block the next load() fetches (wave-uniform)
     const float4* wp = a.wpk + lane;
@@ -68,6 +70,11 @@ __global__ void __launch_bounds__(256) k_conv_gl(const ConvGlArgs a) {
             const bool ok = rok[m] && iz >= 0 && iz < a.D && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
             B.x[m] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (ok) B.x[m] = *reinterpret_cast<const float4*>(pb[m] + (int64_t)((iz * a.H + iy) * a.W + ix) * a.in_cs + 16 * cb);
+            if (PRE) B.ok[m] = ok;
+        }
+        if (PRE && a.pre.scale) {
+            B.sc = *reinterpret_cast<const float4*>(a.pre.scale + 16 * cb + 4 * kq);
+            B.sh = *reinterpret_cast<const float4*>(a.pre.shift + 16 * cb + 4 * kq);
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) B.w[t] = wp[t * 64];
@@ -81,7 +88,20 @@ __global__ void __launch_bounds__(256) k_conv_gl(const ConvGlArgs a) {
         }
     };
     auto mma = [&](const Blk& B) __attribute__((always_inline)) {
-        const float xs[2][4] = {{B.x[0].x, B.x[0].y, B.x[0].z, B.x[0].w}, {B.x[1].x, B.x[1].y, B.x[1].z, B.x[1].w}};
+        float xs[2][4] = {{B.x[0].x, B.x[0].y, B.x[0].z, B.x[0].w}, {B.x[1].x, B.x[1].y, B.x[1].z, B.x[1].w}};
+        if (PRE) {                                           // the padding of the convolution is a padding of the ACTIVATED tensor: zeros stay zeros
+            const float sc[4] = {B.sc.x, B.sc.y, B.sc.z, B.sc.w}, sh[4] = {B.sh.x, B.sh.y, B.sh.z, B.sh.w};
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                if (a.pre.scale) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) xs[m][k] = fmaf(xs[m][k], sc[k], sh[k]);
+                }
+                th_act_vec<4>(xs[m], a.pre.act, a.pre.alpha);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) xs[m][k] = B.ok[m] ? xs[m][k] : 0.f;
+            }
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -155,7 +175,7 @@ void conv_gl_pack_weights(const ConvGeom& g, int Cin, int Cout, const float* w, 
 }
 
 int launch_conv_gl(hipStream_t s, int64_t n, TView in, TView out, ConvGeom g, int Cin, int Cout, const float* wpk, const float* bias,
-                   PostOps post) {
+                   PreOp pre, PostOps post) {
     if (n <= 0) return TH_OK;
     if (in.blk || out.blk || !conv_gl_ok(Cin, Cout, in.cs, in.coff, in.fs) || ((uintptr_t)in.p % 16))
         TH_FAIL(TH_EINVAL, "conv_gl: %d -> %d channels, input stride %d offset %d", Cin, Cout, in.cs, in.coff);
@@ -165,19 +185,23 @@ int launch_conv_gl(hipStream_t s, int64_t n, TView in, TView out, ConvGeom g, in
     a.Do = out.D; a.Ho = out.H; a.Wo = out.W;
     a.g = g; a.ncb = Cin / 16;
     a.wpk = reinterpret_cast<const float4*>(wpk);
-    a.bias = bias; a.post = post;
+    a.bias = bias; a.post = post; a.pre = pre;
     a.out = out.p; a.out_fs = out.fs; a.out_cs = out.cs; a.out_coff = out.coff; a.Cout = Cout;
     a.rows = n * (int64_t)out.V();
     const int64_t waves = (a.rows + 31) / 32;
     const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    const bool has_pre = pre.scale || pre.act != ACT_LINEAR;
+#define GL_LAUNCH(NT_) do { if (has_pre) hipLaunchKernelGGL((k_conv_gl<NT_, true>), grid, block, 0, s, a); \
+                            else hipLaunchKernelGGL((k_conv_gl<NT_, false>), grid, block, 0, s, a); } while (0)
     switch (nt_of(Cout)) {
-        case 1: hipLaunchKernelGGL(k_conv_gl<1>, grid, block, 0, s, a); break;
-        case 2: hipLaunchKernelGGL(k_conv_gl<2>, grid, block, 0, s, a); break;
-        case 3: hipLaunchKernelGGL(k_conv_gl<3>, grid, block, 0, s, a); break;
-        case 4: hipLaunchKernelGGL(k_conv_gl<4>, grid, block, 0, s, a); break;
-        case 6: hipLaunchKernelGGL(k_conv_gl<6>, grid, block, 0, s, a); break;
-        default: hipLaunchKernelGGL(k_conv_gl<8>, grid, block, 0, s, a); break;
+        case 1: GL_LAUNCH(1); break;
+        case 2: GL_LAUNCH(2); break;
+        case 3: GL_LAUNCH(3); break;
+        case 4: GL_LAUNCH(4); break;
+        case 6: GL_LAUNCH(6); break;
+        default: GL_LAUNCH(8); break;
     }
+#undef GL_LAUNCH
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) TH_FAIL(TH_EHIP, "k_conv_gl launch failed: %s", hipGetErrorString(e));
     return TH_OK;

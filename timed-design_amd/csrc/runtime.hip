@@ -1061,8 +1061,8 @@ int plan(th_model* m) {
                         st.run = [=](hipStream_t s, int64_t cnt) {
                             return launch_conv_pw(s, cnt, mp, M->view(src), M->view(dst), Cin, Cout, dw, dbias, pre, po);
                         };
-                    } else if (conv_gl_wanted(M->knobs.conv_gl, g, n.D * n.H * n.W) && f.pool < 0 && f.pre.empty() && !sn.blk && !N[dst].blk &&
-                               (!mplans.count(i) || mplans[i].cfg < 100) &&
+                    } else if (conv_gl_wanted(M->knobs.conv_gl, g, n.D * n.H * n.W) && f.pool < 0 && !sn.blk && !N[dst].blk &&
+                               (!mplans.count(i) || mplans[i].cfg < 100) &&             // (the 16-wide kernel keeps its layers: 42 against 62 us on DenseCPD's 2^3 ones)
                                conv_gl_ok(Cin, Cout, sn.cs, sn.coff, (int64_t)M->bufs[sn.buf].floats_per_frame)) {
                         // strided / few-outputs-per-frame layers: implicit GEMM with rows across the batch, operands from L2 (conv_gl.hip)
                         std::vector<float> packed(conv_gl_wpk_floats(g, Cin, Cout));
@@ -1071,7 +1071,7 @@ int plan(th_model* m) {
                         if ((rc = upload(M, packed.data(), packed.size(), &dw))) return rc;
                         st.exec_flops = conv_gl_exec_flops(g, Cin, Cout, n.D * n.H * n.W);
                         st.label = n.name + ": " + conv_gl_label(Cout);
-                        st.run = [=](hipStream_t s, int64_t cnt) { return launch_conv_gl(s, cnt, M->view(src), M->view(dst), g, Cin, Cout, dw, dbias, po); };
+                        st.run = [=](hipStream_t s, int64_t cnt) { return launch_conv_gl(s, cnt, M->view(src), M->view(dst), g, Cin, Cout, dw, dbias, pre, po); };
                     } else if (mplans.count(i)) {
                         ConvMfmaPlan mp = mplans[i];
                         // heterogeneous Cout blocks: the last, mostly empty 128-column block on a narrower instantiation
