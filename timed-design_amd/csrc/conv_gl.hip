@@ -3,7 +3,7 @@
 // 'valid' ones with a few dozen outputs per frame.  SURVEY.md §8(a) P2a; the call served is reference predict.py:142.
 //
 // GEMM rows are output voxels numbered across the whole batch (row = frame x Vo + voxel: tiles do not stop at a frame's end), a wave
-// owns 32 rows (two 16-row tiles) x all output channels (<= 8 tiles of 16 columns) and walks K = taps x 16-channel blocks with
+// owns 32 rows (two 16-row tiles; one on small layers) x all output channels (<= 8 tiles of 16 columns) and walks K = taps x 16-channel blocks with
 // v_mfma_f32_16x16x4_f32.  Per block a lane reads ONE float4 per row tile — channels 4 kq .. 4 kq + 3 of its row's input voxel
 // under the tap (a row's 16 channels are 64 contiguous bytes, padding reads as zero by predication; an input
 // prologue BN -> activation is applied to the loaded values in registers) — and one float4 per column
@@ -32,18 +32,18 @@ struct ConvGlArgs {
     int64_t rows;                     // frames x Do Ho Wo
 };
 
-template <int NT, bool PRE>
+template <int NT, bool PRE, int MT>
 __global__ void __launch_bounds__(256) k_conv_gl(const ConvGlArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i16 = lane & 15, kq = lane >> 4;
-    const int64_t tile0 = ((int64_t)blockIdx.x * 4 + wave) * 2;
+    const int64_t tile0 = ((int64_t)blockIdx.x * 4 + wave) * MT;
     const int Vo = a.Do * a.Ho * a.Wo, HWo = a.Ho * a.Wo;
     if (tile0 * 16 >= a.rows) return;
-    const float* pb[2];
-    int iz0[2], iy0[2], ix0[2];
-    bool rok[2];
+    const float* pb[MT];
+    int iz0[MT], iy0[MT], ix0[MT];
+    bool rok[MT];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < MT; ++m) {
         const int64_t r = (tile0 + m) * 16 + i16;
         rok[m] = r < a.rows;
         const int64_t rr = rok[m] ? r : a.rows - 1;
@@ -53,19 +53,19 @@ __global__ void __launch_bounds__(256) k_conv_gl(const ConvGlArgs a) {
         iz0[m] = oz * a.g.sd - a.g.pz; iy0[m] = oy * a.g.sh - a.g.py; ix0[m] = ox * a.g.sw - a.g.px;
         pb[m] = a.in + f * a.in_fs + 4 * kq;
     }
-    f32x4 acc[2][NT];
+    f32x4 acc[MT][NT];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    struct Blk { float4 x[2]; float4 w[NT]; float4 sc, sh; bool ok[2]; };
+    struct Blk { float4 x[MT]; float4 w[NT]; float4 sc, sh; bool ok[MT]; };
     Blk R[3];
     int dz = 0, dy = 0, dx = 0, cb = 0;                      // the block the next load() fetches (wave-uniform)
     const float4* wp = a.wpk + lane;
     auto load = [&](Blk& B) __attribute__((always_inline)) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
+        for (int m = 0; m < MT; ++m) {
             const int iz = iz0[m] + dz * a.g.dd, iy = iy0[m] + dy * a.g.dh, ix = ix0[m] + dx * a.g.dw;
             const bool ok = rok[m] && iz >= 0 && iz < a.D && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
             B.x[m] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -88,11 +88,13 @@ __global__ void __launch_bounds__(256) k_conv_gl(const ConvGlArgs a) {
         }
     };
     auto mma = [&](const Blk& B) __attribute__((always_inline)) {
-        float xs[2][4] = {{B.x[0].x, B.x[0].y, B.x[0].z, B.x[0].w}, {B.x[1].x, B.x[1].y, B.x[1].z, B.x[1].w}};
+        float xs[MT][4];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) { xs[m][0] = B.x[m].x; xs[m][1] = B.x[m].y; xs[m][2] = B.x[m].z; xs[m][3] = B.x[m].w; }
         if (PRE) {                                           // the padding of the convolution is a padding of the ACTIVATED tensor: zeros stay zeros
             const float sc[4] = {B.sc.x, B.sc.y, B.sc.z, B.sc.w}, sh[4] = {B.sh.x, B.sh.y, B.sh.z, B.sh.w};
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
+            for (int m = 0; m < MT; ++m) {
                 if (a.pre.scale) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) xs[m][k] = fmaf(xs[m][k], sc[k], sh[k]);
@@ -108,7 +110,7 @@ __global__ void __launch_bounds__(256) k_conv_gl(const ConvGlArgs a) {
             for (int t = 0; t < NT; ++t) {
                 const float ws = s == 0 ? B.w[t].x : s == 1 ? B.w[t].y : s == 2 ? B.w[t].z : B.w[t].w;
 #pragma unroll
-                for (int m = 0; m < 2; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[m][s], ws, acc[m][t], 0, 0, 0);
+                for (int m = 0; m < MT; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[m][s], ws, acc[m][t], 0, 0, 0);
             }
     };
     const int nblk = a.g.kd * a.g.kh * a.g.kw * a.ncb;
@@ -128,15 +130,29 @@ __global__ void __launch_bounds__(256) k_conv_gl(const ConvGlArgs a) {
         const int co = 16 * t + i16;
         if (co >= a.Cout) continue;
         const float bv = a.bias ? a.bias[co] : 0.f;
+        float y[4 * MT];                                     // the lane's values of channel co: the epilogue chain decoded once for all
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[4 * m + r] = acc[m][t][r] + bv;
+        for (int i = 0; i < a.post.n; ++i) {
+            if (a.post.type[i] == POP_AFFINE) {
+                const float sc = a.post.scale[i][co], sh = a.post.shift[i][co];
+#pragma unroll
+                for (int k = 0; k < 4 * MT; ++k) y[k] = fmaf(y[k], sc, sh);
+            } else {
+                th_act_vec<4 * MT>(y, a.post.act[i], a.post.alpha[i]);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int64_t row = (tile0 + m) * 16 + 4 * kq + r;
                 if (row >= a.rows) continue;
                 const int64_t f = row / Vo;
                 const int v = (int)(row - f * Vo);
-                a.out[f * a.out_fs + (int64_t)v * a.out_cs + a.out_coff + co] = th_post(acc[m][t][r] + bv, co, a.post);
+                a.out[f * a.out_fs + (int64_t)v * a.out_cs + a.out_coff + co] = y[4 * m + r];
             }
     }
 }
@@ -188,11 +204,14 @@ int launch_conv_gl(hipStream_t s, int64_t n, TView in, TView out, ConvGeom g, in
     a.bias = bias; a.post = post; a.pre = pre;
     a.out = out.p; a.out_fs = out.fs; a.out_cs = out.cs; a.out_coff = out.coff; a.Cout = Cout;
     a.rows = n * (int64_t)out.V();
-    const int64_t waves = (a.rows + 31) / 32;
+    // row tiles per wave: two share every weight fragment; ONE when the layer is so small that two leave SIMDs short of waves
+    // (ProDCoNN's 'valid' layer, 3 456 such waves: 0.262 -> 0.247 ms with one; its strided layer, 16 000: 0.528 -> 0.586 ms with one)
+    const int mt = (a.rows + 31) / 32 < 8 * 1024 ? 1 : 2;
+    const int64_t waves = (a.rows + 16 * mt - 1) / (16 * mt);
     const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
     const bool has_pre = pre.scale || pre.act != ACT_LINEAR;
-#define GL_LAUNCH(NT_) do { if (has_pre) hipLaunchKernelGGL((k_conv_gl<NT_, true>), grid, block, 0, s, a); \
-                            else hipLaunchKernelGGL((k_conv_gl<NT_, false>), grid, block, 0, s, a); } while (0)
+#define GL_LAUNCH(NT_) do { if (has_pre) { if (mt == 1) hipLaunchKernelGGL((k_conv_gl<NT_, true, 1>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_conv_gl<NT_, true, 2>), grid, block, 0, s, a); } \
+                            else { if (mt == 1) hipLaunchKernelGGL((k_conv_gl<NT_, false, 1>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_conv_gl<NT_, false, 2>), grid, block, 0, s, a); } } while (0)
     switch (nt_of(Cout)) {
         case 1: GL_LAUNCH(1); break;
         case 2: GL_LAUNCH(2); break;
